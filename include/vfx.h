@@ -1,0 +1,158 @@
+/*
+ * vfx.h -- C ABI of libvfx.so: MI355X-native (gfx950) VoiceFixer 44.1 kHz inference hot path.
+ *
+ * Drop-in boundary for the reference haoheliu/voicefixer_main.  The reference is pure
+ * Python/PyTorch and has no FFI of its own; each entry point below replaces the arithmetic
+ * of one reference call (file:line cited) and is what a ctypes binding inside the
+ * reference's own modules would bind.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers to contiguous fp32 unless stated otherwise;
+ *     the caller (PyTorch) owns inputs and outputs, the library never frees them;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, no entry point synchronises the device except
+ *     vfx_create / vfx_load_tensor / vfx_finalize_weights / vfx_reserve / vfx_take_flags;
+ *   - the handle owns a copy of the weights and one workspace arena; it is NOT thread-safe;
+ *   - every function returns 0 on success, non-zero on failure; vfx_last_error() then
+ *     returns a human-readable message (thread-local).
+ *   - T = L / hop + 1 frames (center=True framing); Tpad = 64*ceil(T/64).
+ */
+#ifndef VFX_H_
+#define VFX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vfx_handle vfx_handle;
+
+#define VFX_MAX_STAGES 8
+
+/* model ids for weights / plans */
+enum { VFX_MODEL_UNET_MEL = 0, VFX_MODEL_UNET_SPEC = 1, VFX_MODEL_VOCODER = 2,
+       VFX_MODEL_FRONTEND = 3 /* buffers of f_helper / mel: "mel.fb" (1025,128) */ };
+
+/* sticky device-side flags returned by vfx_take_flags */
+enum { VFX_FLAG_NEGATIVE_INPUT = 1 /* to_log saw a negative value (pytorch_util.py:158) */ };
+
+typedef struct vfx_config {
+  /* front-end: config/vctk_base_voicefixer_unet.json:68-78 */
+  int sample_rate;  /* 44100 */
+  int n_fft;        /* 2048 (only value supported by the FFT kernels) */
+  int hop;          /* 441 */
+  int n_mels;       /* 128 */
+  /* TFGAN vocoder layer table (third-party `voicefixer` package; see oracle/vocoder.py) */
+  int voc_cond_channels;              /* 512 */
+  int voc_cond_layers;                /* 5 */
+  int voc_channels;                   /* 1024 */
+  int voc_n_stages;                   /* 4 */
+  int voc_scales[VFX_MAX_STAGES];     /* 7,7,3,3 */
+  int voc_depth[VFX_MAX_STAGES];      /* 8,8,8,8 */
+  int voc_dilation_base;              /* 3 */
+  float voc_min_db;                   /* -115 */
+  float voc_amp_floor;                /* 1e-5 */
+  float voc_norm_range;               /* 4 */
+  float voc_up_slope;                 /* 0.2 */
+  float voc_res_slope;                /* 0.01 */
+} vfx_config;
+
+/* Fill *cfg with the reference's hyper-parameters. */
+int vfx_default_config(vfx_config* cfg);
+
+/* Create / destroy a handle bound to HIP device `device`. */
+int vfx_create(int device, const vfx_config* cfg, vfx_handle** out);
+int vfx_destroy(vfx_handle* h);
+const char* vfx_last_error(void);
+
+/*
+ * Weights.  `name` is the reference state_dict key (models/components/unet.py:22-53,
+ * modules.py:223-261) for the UNet models, or the vocoder key convention documented in
+ * oracle/vocoder.py.  `data` is a HOST pointer to contiguous fp32 of the given shape
+ * (PyTorch layout).  Replaces `load_from_checkpoint` + `model.to(device)`
+ * (eval_gsr_voicefixer.py:33-40).  vfx_finalize_weights folds eval-mode BatchNorm into
+ * per-channel affine pairs, re-packs conv weights into the kernels' K-chunked layout and
+ * uploads them.
+ */
+int vfx_load_tensor(vfx_handle* h, int model, const char* name, const float* data,
+                    const int64_t* shape, int ndim);
+int vfx_finalize_weights(vfx_handle* h, int model);
+
+/* Workspace (bytes) a call of `model` needs for batch B and T frames; vfx_reserve grows the
+ * arena up-front so that later calls never allocate (required before graph capture). */
+size_t vfx_workspace_bytes(vfx_handle* h, int model, int B, int T);
+int vfx_reserve(vfx_handle* h, int model, int B, int T);
+
+/*
+ * STFT front-end: FDomainHelper.wav_to_spectrogram_phase (tools/pytorch/modules/
+ * fDomainHelper.py:60-89) fused with MelScale.forward (tools/pytorch/mel_scale.py:52-64) and
+ * optionally to_log (tools/pytorch/pytorch_util.py:157-159).
+ *   wav (B, L) -> any non-NULL of: sp, cosp, sinp (B, T, 1025) ; mel (B, T, 128).
+ * log10_mel != 0 writes log10(max(mel, 1e-8)) instead of linear mel.
+ */
+int vfx_stft_mel(vfx_handle* h, const float* wav, int B, int L, float* mel, float* sp,
+                 float* cosp, float* sinp, int log10_mel, void* stream);
+
+/* MelScale.forward alone (tools/pytorch/mel_scale.py:52-64): sp (rows, 1025) -> mel (rows, 128). */
+int vfx_mel_project(vfx_handle* h, const float* sp, int64_t rows, float* mel, void* stream);
+
+/* torchlibrosa ISTFT via FDomainHelper.istft (fDomainHelper.py:30-32, used unet_v2.py:141):
+ * re, im (B, T, 1025) -> wav (B, L). */
+int vfx_istft(vfx_handle* h, const float* re, const float* im, int B, int T, int L, float* wav,
+              void* stream);
+
+/* Generator.forward of models/gsr_voicefixer.py:86-91 with the mel ResUNet
+ * (models/components/unet.py:60-103): linear mel (B, T, 128) >= 0 -> log10 mel (B, T, 128). */
+int vfx_resunet_mel(vfx_handle* h, const float* mel_linear, int B, int T, float* logmel_out,
+                    void* stream);
+
+/* UNetResComplex_100Mb.forward of models/components/unet_v2.py:86-148 (ssr_unet / gsr_unet):
+ * sp (B, T, 1025), wav (B, L) -> wav_out (B, L). */
+int vfx_resunet_spec(vfx_handle* h, const float* sp, const float* wav, int B, int T, int L,
+                     float* wav_out, void* stream);
+
+/* voicefixer.Vocoder.__call__ (call site eval_gsr_voicefixer.py:66):
+ * linear mel (B, T, 128) -> wav (B, vfx_vocoder_out_len(T)). */
+int64_t vfx_vocoder_out_len(vfx_handle* h, int T);
+int vfx_vocoder(vfx_handle* h, const float* mel_linear, int B, int T, float* wav_out, void* stream);
+
+/*
+ * Whole per-segment body of handler() (eval_gsr_voicefixer.py:47-74) for a batch of
+ * equal-length clips: pre -> model -> from_log -> [amp_to_original_f] -> vocoder ->
+ * per-clip peak normalise -> trim_center.  wav (B, L) -> wav_out (B, L).
+ * flags: bit0 = unify_energy (meta["unify_energy"], tools/utils.py:50-55).
+ * logmel_out (B, T, 128) optional (may be NULL): the model's log-mel estimate.
+ */
+int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_out,
+                    float* logmel_out, int flags, void* stream);
+
+/* Read-and-clear the sticky device flags (synchronises `stream`). */
+int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out);
+
+/*
+ * Kernel-level entry points (used by the parity tests to check each kernel against the
+ * oracle in isolation; not part of the reference surface).
+ * vfx_op_conv: generic tap-convolution on channels-last activations.
+ *   x (B, H, W, Cin) -> y (B, H, W, Cout); weight in PyTorch Conv2d layout (Cout, Cin, kh, kw)
+ *   on the HOST; scale/shift (Cin) HOST arrays or NULL (identity prologue);
+ *   act: 0 none, 1 leaky(slope), 2 elu; bias (Cout) HOST or NULL; residual device or NULL;
+ *   dil_w: dilation along W; reflect_w: reflect padding along W instead of zeros.
+ */
+int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, int Cin, const float* weight,
+                int Cout, int kh, int kw, int dil_w, int reflect_w, const float* scale,
+                const float* shift, int act, float slope, const float* bias,
+                const float* residual, float* y, void* stream);
+/* ConvTranspose (stride s, PyTorch layout (Cin, Cout, kh, kw) on the HOST):
+ *   2-D: kh=kw=3, s=2, padding 0, output pruned to (2H, 2W+1) or (2H, 2W) when prune_w;
+ *   1-D: kh=1, kw=2s, padding s/2+s%2, output_padding s%2, output (B,1,W*s,Cout). */
+int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H, int W, int Cin,
+                          const float* weight, int Cout, int kh, int kw, int stride, int prune_w,
+                          const float* scale, const float* shift, int act, float slope,
+                          const float* bias, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFX_H_ */

@@ -1,0 +1,133 @@
+"""GPU parity tests of the individual HIP kernels against the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(y):
+    return y.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 127, 32, 32), (1, 20, 7, 64, 128), (2, 5, 1, 384, 384),
+                                            (1, 16, 63, 32, 64), (3, 4, 3, 96, 256)])
+def test_conv3x3_prologue_residual(engine, B, H, W, Cin, Cout):
+    """3x3 conv with BN-affine + LeakyReLU prologue, bias and residual epilogue vs fp64 torch."""
+    x = _rand((B, Cin, H, W), 1)
+    w = _rand((Cout, Cin, 3, 3), 2, 0.1)
+    scale = torch.rand(Cin, generator=torch.Generator().manual_seed(3)) + 0.5
+    shift = _rand((Cin,), 4, 0.2)
+    bias = _rand((Cout,), 5, 0.1)
+    res = _rand((B, Cout, H, W), 6)
+    a = F.leaky_relu(x.double() * scale.double()[None, :, None, None] + shift.double()[None, :, None, None], 0.01)
+    ref = F.conv2d(a, w.double(), bias.double(), padding=1) + res.double()
+    y = engine.op_conv(_nhwc(x), w.numpy(), scale.numpy(), shift.numpy(), act=1, slope=0.01, bias=bias.numpy(),
+                       residual=_nhwc(res))
+    err = (_nchw(y.cpu()).double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv1d_dilated_and_reflect(engine):
+    B, T, C = 2, 300, 64
+    x = _rand((B, C, T), 11)
+    w3 = _rand((C, C, 3), 12, 0.1)
+    bias = _rand((C,), 13, 0.1)
+    for d in (1, 3, 27, 243):
+        ref = F.conv1d(F.leaky_relu(x.double(), 0.01), w3.double(), bias.double(), padding=d, dilation=d)
+        y = engine.op_conv(x.permute(0, 2, 1)[:, None].contiguous(), w3[:, :, None, :].numpy(), act=1, slope=0.01,
+                           bias=bias.numpy(), dil_w=d)
+        err = (y.cpu()[:, 0].permute(0, 2, 1).double() - ref).abs().max().item()
+        assert err < 2e-5, (d, err)
+    w7 = _rand((128, C, 7), 14, 0.1)
+    ref = F.conv1d(F.pad(F.elu(x.double()), (3, 3), mode="reflect"), w7.double())
+    y = engine.op_conv(x.permute(0, 2, 1)[:, None].contiguous(), w7[:, :, None, :].numpy(), act=2, reflect_w=True)
+    err = (y.cpu()[:, 0].permute(0, 2, 1).double() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("prune_w,H,W", [(False, 5, 1), (False, 10, 3), (True, 4, 16)])
+def test_conv_transpose2d(engine, prune_w, H, W):
+    B, Cin, Cout = 2, 64, 32
+    x = _rand((B, Cin, H, W), 21)
+    w = _rand((Cin, Cout, 3, 3), 22, 0.1)
+    scale = torch.rand(Cin, generator=torch.Generator().manual_seed(23)) + 0.5
+    shift = _rand((Cin,), 24, 0.2)
+    a = F.relu(x.double() * scale.double()[None, :, None, None] + shift.double()[None, :, None, None])
+    ref = F.conv_transpose2d(a, w.double(), stride=2)
+    ref = ref[:, :, :-1, :-1] if prune_w else ref[:, :, :-1, :]
+    y = engine.op_conv_transpose(_nhwc(x), w.numpy(), 2, prune_w=prune_w, scale=scale.numpy(), shift=shift.numpy(),
+                                 act=1, slope=0.0)
+    assert tuple(_nchw(y).shape) == tuple(ref.shape)
+    err = (_nchw(y.cpu()).double() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("s", [7, 3])
+def test_conv_transpose1d(engine, s):
+    B, Cin, Cout, T = 2, 64, 32, 50
+    x = _rand((B, Cin, T), 31)
+    w = _rand((Cin, Cout, 2 * s), 32, 0.1)
+    bias = _rand((Cout,), 33, 0.1)
+    ref = F.conv_transpose1d(F.leaky_relu(x.double(), 0.2), w.double(), bias.double(), stride=s,
+                             padding=s // 2 + s % 2, output_padding=s % 2)
+    y = engine.op_conv_transpose(x.permute(0, 2, 1)[:, None].contiguous(), w[:, :, None, :].numpy(), s, act=1,
+                                 slope=0.2, bias=bias.numpy())
+    got = y.cpu()[:, 0].permute(0, 2, 1).double()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-5
+
+
+def test_stft_mag_phase_mel(engine):
+    from oracle import dsp
+    from voicefixer_main_amd import synth
+    wav = synth.make_clips(3, 0.75)[:, 0]        # (3, L), L = 33075 -> T = 76
+    mag, cos, sin = dsp.spectrogram_phase(wav[:, None].astype(np.float64))
+    mel = dsp.mel_project(mag, dsp.mel_filterbank().astype(np.float64))
+    out = engine.stft(wav, want_mel=True, want_sp=True, want_phase=True)
+    sp = out["sp"].cpu().numpy().astype(np.float64)
+    scale = mag.max()
+    assert np.abs(sp - mag[:, 0]).max() < 2e-6 * scale
+    # phase compared through re/im so that near-zero bins do not dominate
+    re_g, im_g = sp * out["cos"].cpu().numpy(), sp * out["sin"].cpu().numpy()
+    assert np.abs(re_g - (mag * cos)[:, 0]).max() < 3e-6 * scale
+    assert np.abs(im_g - (mag * sin)[:, 0]).max() < 3e-6 * scale
+    melg = out["mel"].cpu().numpy().astype(np.float64)
+    assert np.abs(melg - mel[:, 0]).max() < 1e-5 * mel.max()
+    lg = engine.stft(wav, want_mel=True, log10_mel=True)["mel"].cpu().numpy()
+    assert np.abs(lg - dsp.to_log(mel[:, 0])).max() < 1e-3
+    assert np.abs(lg - dsp.to_log(mel[:, 0])).mean() < 1e-5
+
+
+def test_istft_roundtrip_and_oracle(engine):
+    from oracle import dsp
+    from voicefixer_main_amd import synth
+    wav = synth.make_clips(2, 0.6)[:, 0]
+    L = wav.shape[-1]
+    re, im = dsp.stft(wav.astype(np.float64))
+    got = engine.istft(re.astype(np.float32), im.astype(np.float32), L).cpu().numpy()
+    ref = dsp.istft(re, im, L)
+    assert np.abs(got - ref).max() < 5e-6
+    # STFT -> ISTFT perfect reconstruction (tools/dsp/base.py:214-232)
+    o = engine.stft(wav, want_mel=False, want_sp=True, want_phase=True)
+    back = engine.istft(o["sp"] * o["cos"], o["sp"] * o["sin"], L).cpu().numpy()
+    n = (L // 441) * 441
+    assert np.abs(back[:, :n] - wav[:, :n]).max() < 1e-5
+
+
+def test_mel_project(engine):
+    from oracle import dsp
+    sp = np.abs(np.random.default_rng(0).normal(size=(2, 1, 7, 1025))).astype(np.float32)
+    ref = dsp.mel_project(sp.astype(np.float64), dsp.mel_filterbank().astype(np.float64))
+    got = engine.mel_project(torch.from_numpy(sp)).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-5 * ref.max()

@@ -1,0 +1,62 @@
+"""GPU parity of the model stages / whole path against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# Tolerance of the path: fp32 arithmetic on both sides, different summation order.
+LOGMEL_L1_TOL = 1e-4       # north_star bar is 1e-3
+LOGMEL_MAX_TOL = 2e-3
+
+
+def _mel_input(B, T, seed=0):
+    rng = np.random.default_rng(seed)
+    return (10.0 ** (rng.normal(size=(B, 1, T, 128)) * 1.2 - 2.5)).astype(np.float32)
+
+
+@pytest.mark.parametrize("B,T", [(1, 101), (2, 64), (1, 130)])
+def test_resunet_mel_vs_oracle(engine, unet_sd, B, T):
+    from oracle import resunet
+    mel = _mel_input(B, T)
+    ref = resunet.generator_mel(unet_sd, torch.from_numpy(mel)).numpy()[:, 0]
+    got = engine.resunet_mel(torch.from_numpy(mel[:, 0])).cpu().numpy()
+    d = np.abs(got - ref)
+    assert d.mean() < LOGMEL_L1_TOL, d.mean()
+    assert d.max() < LOGMEL_MAX_TOL, d.max()
+    # unet.py:78,99: the last mel bin of the UNet output is exactly 0 -> out = to_log(mel) there
+    assert np.abs(got[..., 127] - np.log10(np.clip(mel[:, 0, :, 127], 1e-8, None))).max() < 1e-6
+    assert engine.take_flags() == 0
+
+
+def test_resunet_negative_input_flag(engine):
+    mel = _mel_input(1, 64)
+    mel[0, 0, 3, 5] = -1.0
+    engine.resunet_mel(torch.from_numpy(mel[:, 0]))
+    assert engine.take_flags() & 1
+    assert engine.take_flags() == 0
+
+
+@pytest.mark.parametrize("B,T", [(1, 21), (2, 10)])
+def test_vocoder_vs_oracle(engine, voc_sd, B, T):
+    from oracle import vocoder as voc
+    mel = _mel_input(B, T, seed=3)
+    ref = voc.vocoder(voc_sd, torch.from_numpy(mel)).numpy()[:, 0]
+    got = engine.vocoder(torch.from_numpy(mel[:, 0])).cpu().numpy()
+    assert got.shape == ref.shape == (B, (T + T % 2 + 4) * 441)
+    assert np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max()
+
+
+def test_restore_gsr_vs_oracle(engine, unet_sd, voc_sd):
+    from oracle import pipeline
+    from voicefixer_main_amd import synth
+    wav = synth.make_clips(2, 0.8)
+    ref = pipeline.restore_gsr(unet_sd, voc_sd, wav)
+    out, logmel = engine.restore_gsr(torch.from_numpy(wav[:, 0]), want_logmel=True)
+    out, logmel = out.cpu().numpy(), logmel.cpu().numpy()
+    d = np.abs(logmel - ref["logmel"][:, 0])
+    assert d.mean() < LOGMEL_L1_TOL, d.mean()
+    assert out.shape == wav[:, 0].shape
+    err = out - ref["wav"][:, 0]
+    sisdr = 10 * np.log10((ref["wav"] ** 2).sum() / ((err ** 2).sum() + 1e-20))
+    assert sisdr > 60.0, sisdr

@@ -1,0 +1,93 @@
+"""ctypes binding of libvfx.so (the C ABI declared in include/vfx.h).
+
+The product path has NO fallback: if the shared library cannot be loaded, or a call
+fails, a RuntimeError is raised.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvfx.so")
+CSRC = os.path.join(HERE, "csrc")
+
+VFX_MAX_STAGES = 8
+MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER, MODEL_FRONTEND = 0, 1, 2, 3
+FLAG_NEGATIVE_INPUT = 1
+
+
+class VfxConfig(ctypes.Structure):
+    _fields_ = [
+        ("sample_rate", c_int), ("n_fft", c_int), ("hop", c_int), ("n_mels", c_int),
+        ("voc_cond_channels", c_int), ("voc_cond_layers", c_int), ("voc_channels", c_int),
+        ("voc_n_stages", c_int), ("voc_scales", c_int * VFX_MAX_STAGES), ("voc_depth", c_int * VFX_MAX_STAGES),
+        ("voc_dilation_base", c_int), ("voc_min_db", c_float), ("voc_amp_floor", c_float),
+        ("voc_norm_range", c_float), ("voc_up_slope", c_float), ("voc_res_slope", c_float),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/vfx.h declares
+SIGNATURES = {
+    "vfx_default_config": (c_int, [POINTER(VfxConfig)]),
+    "vfx_create": (c_int, [c_int, POINTER(VfxConfig), POINTER(c_void_p)]),
+    "vfx_destroy": (c_int, [c_void_p]),
+    "vfx_last_error": (c_char_p, []),
+    "vfx_load_tensor": (c_int, [c_void_p, c_int, c_char_p, c_void_p, POINTER(c_int64), c_int]),
+    "vfx_finalize_weights": (c_int, [c_void_p, c_int]),
+    "vfx_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "vfx_reserve": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "vfx_stft_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfx_mel_project": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "vfx_istft": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vfx_resunet_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vfx_resunet_spec": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vfx_vocoder_out_len": (c_int64, [c_void_p, c_int]),
+    "vfx_vocoder": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vfx_restore_gsr": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfx_take_flags": (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
+    "vfx_op_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                            c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfx_op_conv_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                      c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libvfx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout[-4000:])
+        print(out.stderr[-4000:])
+    if out.returncode != 0:
+        raise RuntimeError("building libvfx.so failed")
+    return LIB_PATH
+
+
+def load():
+    """Load libvfx.so; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libvfx.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the product path)" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise RuntimeError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().vfx_last_error()
+        raise RuntimeError("%s failed: %s" % (what, msg.decode() if msg else "unknown error"))

@@ -1,0 +1,609 @@
+// api.cpp -- handle, weight staging, arena and the extern "C" entry points of libvfx.so.
+#include <cmath>
+#include <cstring>
+
+#include "vfx_internal.h"
+
+namespace vfx {
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device blob / arena planner
+// ---------------------------------------------------------------------------------------------
+void* DeviceBlob::alloc(size_t bytes) {
+  void* p = nullptr;
+  VFX_HIP(hipMalloc(&p, bytes ? bytes : 16));
+  allocs.push_back(p);
+  return p;
+}
+float* DeviceBlob::upload(const float* p, size_t n) {
+  float* d = static_cast<float*>(alloc(n * sizeof(float)));
+  if (n) VFX_HIP(hipMemcpy(d, p, n * sizeof(float), hipMemcpyHostToDevice));
+  return d;
+}
+int* DeviceBlob::upload_i(const std::vector<int>& v) {
+  int* d = static_cast<int*>(alloc(v.size() * sizeof(int)));
+  if (!v.empty()) VFX_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+  return d;
+}
+void DeviceBlob::release() {
+  for (void* p : allocs) (void)hipFree(p);
+  allocs.clear();
+}
+
+size_t ArenaPlanner::alloc(size_t bytes) {
+  bytes = (bytes + 255) & ~size_t(255);
+  if (bytes == 0) bytes = 256;
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    Block& b = blocks[i];
+    if (b.free && b.size >= bytes) {
+      if (b.size > bytes) {
+        Block rest{b.off + bytes, b.size - bytes, true};
+        b.size = bytes;
+        b.free = false;
+        const size_t off = b.off;
+        blocks.insert(blocks.begin() + i + 1, rest);
+        return off;
+      }
+      b.free = false;
+      return b.off;
+    }
+  }
+  // extend: merge with a trailing free block if there is one
+  if (!blocks.empty() && blocks.back().free) {
+    Block& b = blocks.back();
+    b.size = bytes;
+    b.free = false;
+    high = b.off + bytes;
+    return b.off;
+  }
+  blocks.push_back(Block{high, bytes, false});
+  const size_t off = high;
+  high += bytes;
+  return off;
+}
+
+void ArenaPlanner::free(size_t off) {
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    if (blocks[i].off == off && !blocks[i].free) {
+      blocks[i].free = true;
+      if (i + 1 < blocks.size() && blocks[i + 1].free) {
+        blocks[i].size += blocks[i + 1].size;
+        blocks.erase(blocks.begin() + i + 1);
+      }
+      if (i > 0 && blocks[i - 1].free) {
+        blocks[i - 1].size += blocks[i].size;
+        blocks.erase(blocks.begin() + i);
+      }
+      return;
+    }
+  }
+  set_error("ArenaPlanner::free: unknown offset %zu", off);
+  throw Error();
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+// PyTorch Conv weight (Cout, CinTotal, KH, KW) -> [C/32][ntaps][Cout][32] for input channels
+// [c_lo, c_lo + C); taps are (kh, kw) pairs.
+std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int KW, int c_lo, int C,
+                             const std::vector<std::pair<int, int>>& taps) {
+  const int nt = (int)taps.size();
+  std::vector<float> out((size_t)C * nt * Cout);
+  for (int ch = 0; ch < C / kKC; ++ch)
+    for (int t = 0; t < nt; ++t)
+      for (int n = 0; n < Cout; ++n)
+        for (int cc = 0; cc < kKC; ++cc) {
+          const int c = c_lo + ch * kKC + cc;
+          out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
+              w[(((size_t)n * CinTotal + c) * KH + taps[t].first) * KW + taps[t].second];
+        }
+  return out;
+}
+
+// PyTorch ConvTranspose weight (Cin, Cout, KH, KW) -> [Cin/32][ntaps][Cout][32].
+std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,
+                                        const std::vector<std::pair<int, int>>& taps) {
+  const int nt = (int)taps.size();
+  std::vector<float> out((size_t)Cin * nt * Cout);
+  for (int ch = 0; ch < Cin / kKC; ++ch)
+    for (int t = 0; t < nt; ++t)
+      for (int n = 0; n < Cout; ++n)
+        for (int cc = 0; cc < kKC; ++cc) {
+          const int c = ch * kKC + cc;
+          out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
+              w[(((size_t)c * Cout + n) * KH + taps[t].first) * KW + taps[t].second];
+        }
+  return out;
+}
+
+void finish_params(TapConvParams& p) {
+  p.total_steps = 0;
+  for (int s = 0; s < p.nseg; ++s) {
+    VFX_CHECK(p.seg[s].C % kKC == 0 && p.seg[s].ntaps >= 1 && p.seg[s].ntaps <= kMaxTaps,
+              "tapconv: bad segment %d (C=%d ntaps=%d)", s, p.seg[s].C, p.seg[s].ntaps);
+    p.total_steps += p.seg[s].ntaps * (p.seg[s].C / kKC);
+  }
+  p.M = p.B * p.Hg * p.Wg;
+  VFX_CHECK((int64_t)p.B * p.Hg * p.Wg < (int64_t)1 << 31, "tapconv: too many output pixels");
+  VFX_CHECK((int64_t)p.B * p.Ho * p.Wo < (int64_t)1 << 31, "tapconv: too many output pixels");
+  VFX_CHECK((int64_t)p.B * p.Hi * p.Wi < (int64_t)1 << 31, "tapconv: too many input pixels");
+}
+
+// ---------------------------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------------------------
+void PlanBuilder::add_conv(TapConvParams p) {
+  finish_params(p);
+  const size_t idx = plan->host_params.size();
+  plan->host_params.push_back(p);
+  plan->conv_flops += tapconv_flops(p);
+  plan->n_conv += 1;
+  Plan* pl = plan;
+  plan->ops.push_back([pl, idx](const RunCtx& c) { launch_tapconv(pl->host_params[idx], pl->dev_params + idx, c.stream); });
+}
+
+static char* ensure_arena(vfx_handle* h, size_t bytes) {
+  if (bytes <= h->arena_bytes) return h->arena;
+  VFX_HIP(hipDeviceSynchronize());
+  if (h->arena) VFX_HIP(hipFree(h->arena));
+  h->arena = nullptr;
+  h->arena_bytes = 0;
+  const size_t want = bytes + (bytes >> 4);
+  void* p = nullptr;
+  VFX_HIP(hipMalloc(&p, want));
+  h->arena = static_cast<char*>(p);
+  h->arena_bytes = want;
+  return h->arena;
+}
+
+// Rebase the plan's arena-relative pointers on the (possibly re-allocated) arena and upload
+// the parameter blocks.
+void bind_plan(vfx_handle* h, Plan& plan) {
+  char* base = ensure_arena(h, plan.arena_bytes);
+  if (plan.bound_base == base && plan.dev_params) return;
+  std::vector<TapConvParams> abs = plan.host_params;
+  auto rebase = [&](const float* rel) -> const float* {
+    return reinterpret_cast<const float*>(base + reinterpret_cast<size_t>(rel) - 1);
+  };
+  for (auto& p : abs) {
+    for (int s = 0; s < p.nseg; ++s) p.seg[s].src = rebase(p.seg[s].src);
+    if (p.residual) p.residual = rebase(p.residual);
+    p.out = const_cast<float*>(rebase(p.out));
+  }
+  if (!plan.dev_params && !abs.empty())
+    plan.dev_params = static_cast<TapConvParams*>(plan.blob.alloc(abs.size() * sizeof(TapConvParams)));
+  if (!abs.empty())
+    VFX_HIP(hipMemcpy(plan.dev_params, abs.data(), abs.size() * sizeof(TapConvParams), hipMemcpyHostToDevice));
+  plan.bound_base = base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// front-end tables
+// ---------------------------------------------------------------------------------------------
+static double hz_to_mel(double f) { return 2595.0 * std::log10(1.0 + f / 700.0); }
+
+void set_mel_filterbank(vfx_handle* h, const float* fb) {
+  const int NB = h->cfg.n_fft / 2 + 1, NM = h->cfg.n_mels;
+  std::vector<float> val;
+  std::vector<int> start(NM), off(NM + 1);
+  for (int m = 0; m < NM; ++m) {
+    int lo = -1, hi = -1;
+    for (int f = 0; f < NB; ++f)
+      if (fb[(size_t)f * NM + m] != 0.f) {
+        if (lo < 0) lo = f;
+        hi = f;
+      }
+    off[m] = (int)val.size();
+    start[m] = lo < 0 ? 0 : lo;
+    if (lo >= 0)
+      for (int f = lo; f <= hi; ++f) val.push_back(fb[(size_t)f * NM + m]);
+  }
+  off[NM] = (int)val.size();
+  h->fe.fb_val = h->blob.upload(val);
+  h->fe.fb_start = h->blob.upload_i(start);
+  h->fe.fb_off = h->blob.upload_i(off);
+}
+
+void init_front_end(vfx_handle* h) {
+  const int N = h->cfg.n_fft;
+  VFX_CHECK(N == 2048, "only n_fft = 2048 is supported (got %d)", N);
+  VFX_CHECK(h->cfg.n_mels == 128, "only n_mels = 128 is supported (got %d)", h->cfg.n_mels);
+  std::vector<float> win(N), tw(2 * (N / 2)), rtw(2 * (N / 2 + 1));
+  for (int n = 0; n < N; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / N));
+  for (int m = 0; m < N / 2; ++m) {
+    tw[2 * m] = (float)std::cos(2.0 * M_PI * m / (N / 2));
+    tw[2 * m + 1] = (float)(-std::sin(2.0 * M_PI * m / (N / 2)));
+  }
+  for (int k = 0; k <= N / 2; ++k) {
+    rtw[2 * k] = (float)std::cos(2.0 * M_PI * k / N);
+    rtw[2 * k + 1] = (float)(-std::sin(2.0 * M_PI * k / N));
+  }
+  h->fe.window = h->blob.upload(win);
+  h->fe.twiddle = h->blob.upload(tw);
+  h->fe.rtwiddle = h->blob.upload(rtw);
+
+  // Default HTK mel filterbank (mel_scale.py:131-221) evaluated in double precision.  The
+  // reference evaluates it with float32 torch ops; the Python shim therefore overrides this
+  // table with the bit-identical one via vfx_load_tensor(VFX_MODEL_FRONTEND, "mel.fb").
+  const int NB = N / 2 + 1, NM = h->cfg.n_mels;
+  const double fmax = (double)(h->cfg.sample_rate / 2);
+  std::vector<double> fpts(NM + 2);
+  for (int i = 0; i < NM + 2; ++i) {
+    const double m = hz_to_mel(0.0) + (hz_to_mel(fmax) - hz_to_mel(0.0)) * i / (NM + 1);
+    fpts[i] = 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
+  }
+  std::vector<float> fb((size_t)NB * NM);
+  for (int f = 0; f < NB; ++f) {
+    const double hz = fmax * f / (NB - 1);
+    for (int m = 0; m < NM; ++m) {
+      const double up = (hz - fpts[m]) / (fpts[m + 1] - fpts[m]);
+      const double down = (fpts[m + 2] - hz) / (fpts[m + 2] - fpts[m + 1]);
+      fb[(size_t)f * NM + m] = (float)std::max(0.0, std::min(up, down));
+    }
+  }
+  set_mel_filterbank(h, fb.data());
+
+  // vocoder band weights: get_mel_weig (pytorch_util.py:141-155), base 10
+  std::vector<float> invw(NM);
+  const double norm0 = (fpts[2] - fpts[0]) / 2.0;
+  for (int m = 0; m < NM; ++m) invw[m] = (float)(1.0 / (((fpts[m + 2] - fpts[m]) / 2.0) / norm0));
+  h->fe.voc_inv_weight = h->blob.upload(invw);
+}
+
+// 1 / window-sumsquare envelope of T frames (librosa.filters.window_sumsquare semantics; bins
+// whose envelope is tiny are left undivided).
+const float* istft_envelope(vfx_handle* h, int T) {
+  if (h->fe.inv_env && h->fe.inv_env_T == T) return h->fe.inv_env;
+  const int N = h->cfg.n_fft, hop = h->cfg.hop;
+  std::vector<double> env((size_t)N + (size_t)hop * (T - 1), 0.0);
+  std::vector<double> w2(N);
+  for (int n = 0; n < N; ++n) {
+    const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * n / N);
+    w2[n] = w * w;
+  }
+  for (int t = 0; t < T; ++t)
+    for (int n = 0; n < N; ++n) env[(size_t)t * hop + n] += w2[n];
+  std::vector<float> inv(env.size());
+  for (size_t i = 0; i < env.size(); ++i) inv[i] = env[i] > 1.1754944e-38 ? (float)(1.0 / env[i]) : 1.0f;
+  VFX_HIP(hipDeviceSynchronize());
+  h->fe.inv_env = h->blob.upload(inv);  // previous tables stay allocated until destroy (few, small)
+  h->fe.inv_env_T = T;
+  return h->fe.inv_env;
+}
+
+}  // namespace vfx
+
+// =============================================================================================
+// extern "C"
+// =============================================================================================
+using namespace vfx;
+
+#define VFX_API_BEGIN try {
+#define VFX_API_END                         \
+  }                                         \
+  catch (const vfx::Error&) { return 1; }   \
+  catch (const std::exception& e) {         \
+    vfx::set_error("exception: %s", e.what()); \
+    return 2;                               \
+  }                                         \
+  return 0;
+
+extern "C" {
+
+const char* vfx_last_error(void) { return vfx::g_err.c_str(); }
+
+int vfx_default_config(vfx_config* cfg) {
+  if (!cfg) return 1;
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->sample_rate = 44100;
+  cfg->n_fft = 2048;
+  cfg->hop = 441;
+  cfg->n_mels = 128;
+  cfg->voc_cond_channels = 512;
+  cfg->voc_cond_layers = 5;
+  cfg->voc_channels = 1024;
+  cfg->voc_n_stages = 4;
+  const int scales[4] = {7, 7, 3, 3};
+  for (int i = 0; i < 4; ++i) {
+    cfg->voc_scales[i] = scales[i];
+    cfg->voc_depth[i] = 8;
+  }
+  cfg->voc_dilation_base = 3;
+  cfg->voc_min_db = -115.f;
+  cfg->voc_amp_floor = 1e-5f;
+  cfg->voc_norm_range = 4.f;
+  cfg->voc_up_slope = 0.2f;
+  cfg->voc_res_slope = 0.01f;
+  return 0;
+}
+
+int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
+  VFX_API_BEGIN
+  VFX_CHECK(out != nullptr, "vfx_create: out is NULL");
+  VFX_HIP(hipSetDevice(device));
+  auto h = std::make_unique<vfx_handle>();
+  h->device = device;
+  if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
+  VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
+  init_front_end(h.get());
+  h->d_flags = static_cast<int*>(h->blob.alloc(sizeof(int)));
+  VFX_HIP(hipMemset(h->d_flags, 0, sizeof(int)));
+  *out = h.release();
+  VFX_API_END
+}
+
+int vfx_destroy(vfx_handle* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  h->plans.clear();
+  if (h->arena) (void)hipFree(h->arena);
+  delete h;
+  return 0;
+}
+
+int vfx_load_tensor(vfx_handle* h, int model, const char* name, const float* data, const int64_t* shape, int ndim) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && name && data, "vfx_load_tensor: NULL argument");
+  VFX_CHECK(model >= 0 && model <= VFX_MODEL_FRONTEND, "vfx_load_tensor: bad model id %d", model);
+  HostTensor t;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    t.shape.push_back(shape[i]);
+    n *= shape[i];
+  }
+  t.data.assign(data, data + n);
+  h->staged[model][name] = std::move(t);
+  VFX_API_END
+}
+
+int vfx_finalize_weights(vfx_handle* h, int model) {
+  VFX_API_BEGIN
+  VFX_CHECK(h, "NULL handle");
+  VFX_HIP(hipSetDevice(h->device));
+  h->plans.clear();
+  if (model == VFX_MODEL_UNET_MEL || model == VFX_MODEL_UNET_SPEC) {
+    h->unet[model] = build_unet_weights(h, model);
+  } else if (model == VFX_MODEL_VOCODER) {
+    h->voc = build_vocoder_weights(h);
+  } else if (model == VFX_MODEL_FRONTEND) {
+    auto it = h->staged[model].find("mel.fb");
+    if (it != h->staged[model].end()) {
+      VFX_CHECK(it->second.shape.size() == 2 && it->second.shape[0] == h->cfg.n_fft / 2 + 1 &&
+                    it->second.shape[1] == h->cfg.n_mels,
+                "mel.fb must be (%d, %d)", h->cfg.n_fft / 2 + 1, h->cfg.n_mels);
+      VFX_HIP(hipDeviceSynchronize());
+      set_mel_filterbank(h, it->second.data.data());
+    }
+  } else {
+    VFX_CHECK(false, "vfx_finalize_weights: bad model id %d", model);
+  }
+  h->staged[model].clear();
+  VFX_API_END
+}
+
+int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && flags_out, "NULL argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int v = 0;
+  VFX_HIP(hipMemcpyAsync(&v, h->d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
+  VFX_HIP(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+  VFX_HIP(hipStreamSynchronize(s));
+  *flags_out = v;
+  VFX_API_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// front-end
+// ---------------------------------------------------------------------------------------------
+static int frames_of(const vfx_handle* h, int L) { return L / h->cfg.hop + 1; }
+
+int vfx_stft_mel(vfx_handle* h, const float* wav, int B, int L, float* mel, float* sp, float* cosp, float* sinp,
+                 int log10_mel, void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && wav, "NULL argument");
+  VFX_CHECK(B > 0 && L > h->cfg.n_fft / 2, "vfx_stft_mel: need B > 0 and L > n_fft/2 (reflect padding), got B=%d L=%d", B, L);
+  launch_stft_mel(h->fe, wav, B, L, frames_of(h, L), mel, sp, cosp, sinp, log10_mel, h->cfg.hop,
+                  static_cast<hipStream_t>(stream));
+  VFX_API_END
+}
+
+int vfx_mel_project(vfx_handle* h, const float* sp, int64_t rows, float* mel, void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && sp && mel && rows > 0, "bad argument");
+  launch_mel_project(h->fe, sp, rows, mel, static_cast<hipStream_t>(stream));
+  VFX_API_END
+}
+
+int vfx_istft(vfx_handle* h, const float* re, const float* im, int B, int T, int L, float* wav, void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && re && im && wav && B > 0 && T > 0 && L > 0, "bad argument");
+  const float* env = istft_envelope(h, T);
+  const size_t need = (size_t)B * T * h->cfg.n_fft * sizeof(float);
+  if (need > h->arena_bytes) h->plans.clear();  // plans hold absolute pointers into the old arena
+  // reuse the arena as the frame buffer (no plan is running concurrently: single stream, single thread)
+  Plan tmp;
+  tmp.arena_bytes = need;
+  bind_plan(h, tmp);
+  launch_istft(h->fe, re, im, B, T, L, h->cfg.hop, env, reinterpret_cast<float*>(h->arena), wav,
+               static_cast<hipStream_t>(stream));
+  VFX_API_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// model stages
+// ---------------------------------------------------------------------------------------------
+static std::shared_ptr<Plan> get_plan(vfx_handle* h, const std::string& key,
+                                      const std::function<void(PlanBuilder&)>& build) {
+  auto it = h->plans.find(key);
+  std::shared_ptr<Plan> plan;
+  if (it == h->plans.end()) {
+    plan = std::make_shared<Plan>();
+    PlanBuilder pb{h, plan.get(), {}};
+    build(pb);
+    plan->arena_bytes = pb.arena.high;
+    h->plans[key] = plan;
+  } else {
+    plan = it->second;
+  }
+  const char* old = h->arena;
+  bind_plan(h, *plan);
+  if (old && old != h->arena) {
+    // arena moved: every other cached plan re-binds lazily (bound_base mismatch)
+  }
+  return plan;
+}
+
+static std::string key_of(const char* tag, int B, int T, int x = 0) {
+  char buf[96];
+  snprintf(buf, sizeof(buf), "%s:%d:%d:%d", tag, B, T, x);
+  return buf;
+}
+
+static BufRef ext(int slot) {
+  BufRef b;
+  b.ext = true;
+  b.slot = slot;
+  return b;
+}
+static BufRef arena_buf(size_t off) {
+  BufRef b;
+  b.off = off;
+  return b;
+}
+
+size_t vfx_workspace_bytes(vfx_handle* h, int model, int B, int T) {
+  try {
+    Plan plan;
+    PlanBuilder pb{h, &plan, {}};
+    if (model == VFX_MODEL_UNET_MEL) build_unet_mel(pb, B, T, ext(0), ext(1));
+    else if (model == VFX_MODEL_UNET_SPEC) build_unet_spec(pb, B, T, ext(0), ext(1), ext(2), ext(3), ext(4));
+    else if (model == VFX_MODEL_VOCODER) build_vocoder(pb, B, T, ext(0), ext(1));
+    else return 0;
+    return pb.arena.high;
+  } catch (...) {
+    return 0;
+  }
+}
+
+int vfx_reserve(vfx_handle* h, int model, int B, int T) {
+  VFX_API_BEGIN
+  const size_t need = vfx_workspace_bytes(h, model, B, T);
+  VFX_CHECK(need > 0, "vfx_reserve: cannot plan model %d (weights finalized?): %s", model, vfx_last_error());
+  Plan tmp;
+  tmp.arena_bytes = need;
+  bind_plan(h, tmp);
+  VFX_API_END
+}
+
+int vfx_resunet_mel(vfx_handle* h, const float* mel_linear, int B, int T, float* logmel_out, void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && mel_linear && logmel_out && B > 0 && T > 0, "bad argument");
+  VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL], "vfx_resunet_mel: weights of the mel ResUNet are not finalized");
+  auto plan = get_plan(h, key_of("unet_mel", B, T),
+                       [&](PlanBuilder& pb) { build_unet_mel(pb, B, T, ext(0), ext(1)); });
+  RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), logmel_out}, h->d_flags};
+  plan->run(ctx);
+  VFX_API_END
+}
+
+int vfx_resunet_spec(vfx_handle* h, const float* sp, const float* wav, int B, int T, int L, float* wav_out,
+                     void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && sp && wav && wav_out && B > 0 && T > 0, "bad argument");
+  VFX_CHECK(h->unet[VFX_MODEL_UNET_SPEC], "vfx_resunet_spec: weights of the spectrogram ResUNet are not finalized");
+  VFX_CHECK(T == frames_of(h, L), "vfx_resunet_spec: T=%d does not match L=%d (expected %d frames)", T, L, frames_of(h, L));
+  const float* env = istft_envelope(h, T);
+  const size_t nsp = (size_t)B * T * (h->cfg.n_fft / 2 + 1);
+  auto plan = get_plan(h, key_of("unet_spec", B, T), [&](PlanBuilder& pb) {
+    auto& nm = pb.plan->named;
+    nm["cos"] = pb.alloc_f(nsp);
+    nm["sin"] = pb.alloc_f(nsp);
+    nm["re"] = pb.alloc_f(nsp);
+    nm["im"] = pb.alloc_f(nsp);
+    nm["frames"] = pb.alloc_f((size_t)B * T * h->cfg.n_fft);
+    build_unet_spec(pb, B, T, ext(0), arena_buf(nm["cos"]), arena_buf(nm["sin"]), arena_buf(nm["re"]), arena_buf(nm["im"]));
+  });
+  const size_t off_cos = plan->named["cos"], off_sin = plan->named["sin"], off_re = plan->named["re"],
+               off_im = plan->named["im"], off_frames = plan->named["frames"];
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* base = h->arena;
+  float* cosb = reinterpret_cast<float*>(base + off_cos);
+  float* sinb = reinterpret_cast<float*>(base + off_sin);
+  // second STFT of the same audio for the phase (unet_v2.py:96)
+  launch_stft_mel(h->fe, wav, B, L, T, nullptr, nullptr, cosb, sinb, 0, h->cfg.hop, s);
+  RunCtx ctx{s, {const_cast<float*>(sp)}, h->d_flags};
+  plan->run(ctx);
+  launch_istft(h->fe, reinterpret_cast<float*>(base + off_re), reinterpret_cast<float*>(base + off_im), B, T, L,
+               h->cfg.hop, env, reinterpret_cast<float*>(base + off_frames), wav_out, s);
+  VFX_API_END
+}
+
+int64_t vfx_vocoder_out_len(vfx_handle* h, int T) { return h ? vocoder_out_len(h->cfg, T) : -1; }
+
+int vfx_vocoder(vfx_handle* h, const float* mel_linear, int B, int T, float* wav_out, void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && mel_linear && wav_out && B > 0 && T > 0, "bad argument");
+  VFX_CHECK(h->voc, "vfx_vocoder: vocoder weights are not finalized");
+  auto plan = get_plan(h, key_of("vocoder", B, T), [&](PlanBuilder& pb) { build_vocoder(pb, B, T, ext(0), ext(1)); });
+  RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), wav_out}, h->d_flags};
+  plan->run(ctx);
+  VFX_API_END
+}
+
+int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_out, float* logmel_out, int flags,
+                    void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && wav && wav_out && B > 0, "bad argument");
+  VFX_CHECK(L > h->cfg.n_fft / 2, "vfx_restore_gsr: clip too short for reflect padding (L=%d)", L);
+  VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL] && h->voc, "vfx_restore_gsr: weights are not finalized");
+  const int T = frames_of(h, L);
+  const int64_t Llong = vocoder_out_len(h->cfg, T);
+  const int unify = flags & 1;
+  auto plan = get_plan(h, key_of("restore_gsr", B, T, unify), [&](PlanBuilder& pb) {
+    const int64_t nmel = (int64_t)B * T * 128;
+    const size_t o_mel = pb.alloc_f(nmel), o_log = pb.alloc_f(nmel), o_den = pb.alloc_f(nmel);
+    const size_t o_long = pb.alloc_f((int64_t)B * Llong), o_ws = pb.alloc_f(2 * B + 64);
+    vfx_handle* hh = pb.h;
+    Plan* pl = pb.plan;
+    // pre(): STFT -> magnitude -> mel (eval_gsr_voicefixer.py:19-25)
+    pl->ops.push_back([=](const RunCtx& c) {
+      launch_stft_mel(hh->fe, c.ext[0], B, L, T, reinterpret_cast<float*>(pl->bound_base + o_mel), nullptr, nullptr,
+                      nullptr, 0, hh->cfg.hop, c.stream);
+    });
+    build_unet_mel(pb, B, T, arena_buf(o_mel), arena_buf(o_log));
+    pl->ops.push_back([=](const RunCtx& c) {
+      float* lg = reinterpret_cast<float*>(pl->bound_base + o_log);
+      if (c.ext[2]) VFX_HIP(hipMemcpyAsync(c.ext[2], lg, sizeof(float) * nmel, hipMemcpyDeviceToDevice, c.stream));
+      launch_from_log(lg, reinterpret_cast<float*>(pl->bound_base + o_mel), B, T, unify,
+                      reinterpret_cast<float*>(pl->bound_base + o_ws), reinterpret_cast<float*>(pl->bound_base + o_den),
+                      c.stream);
+    });
+    build_vocoder(pb, B, T, arena_buf(o_den), arena_buf(o_long));
+    pl->ops.push_back([=](const RunCtx& c) {
+      launch_peak_trim(reinterpret_cast<float*>(pl->bound_base + o_long), B, Llong, L,
+                       reinterpret_cast<float*>(pl->bound_base + o_ws), c.ext[1], c.stream);
+    });
+  });
+  RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags};
+  plan->run(ctx);
+  VFX_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// small_ops.hip -- HBM-bound edge kernels around the tap-convolution engine (gfx950).
+// All activations are channels-last fp32; every kernel is written for 16-byte-per-lane
+// coalesced access along the channel axis (or along the innermost spatial axis when C == 1).
+#include "vfx_internal.h"
+
+namespace vfx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline unsigned nblocks(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// ---------------------------------------------------------------------------------------------
+// UNet input preparation
+// ---------------------------------------------------------------------------------------------
+// Generator.forward's to_log (models/gsr_voicefixer.py:87; pytorch_util.py:157-159) fused with
+// the time padding and last-bin drop of unet.py:75-78:  (B,T,128) -> (B,Tpad,127).
+__global__ void k_prep_logmel(const float* __restrict__ mel, int B, int T, int Tpad, float* __restrict__ x,
+                              int* __restrict__ flags) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * Tpad * 127;
+  if (idx >= total) return;
+  const int f = idx % 127;
+  const int64_t r = idx / 127;
+  const int i = r % Tpad;
+  const int b = r / Tpad;
+  float v = 0.f;
+  if (i < T) {
+    const float m = mel[((int64_t)b * T + i) * 128 + f];
+    if (m < 0.f) atomicOr(flags, VFX_FLAG_NEGATIVE_INPUT);
+    v = log10f(fmaxf(m, 1e-8f));
+  }
+  x[idx] = v;
+}
+
+// unet_v2.py:103-110: (B,T,1025) -> (B,Tpad,1024), zero rows beyond T, last bin dropped.
+__global__ void k_prep_spec(const float* __restrict__ sp, int B, int T, int Tpad, float* __restrict__ x) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * Tpad * 1024;
+  if (idx >= total) return;
+  const int f = idx & 1023;
+  const int64_t r = idx >> 10;
+  const int i = r % Tpad;
+  const int b = r / Tpad;
+  x[idx] = i < T ? sp[((int64_t)b * T + i) * 1025 + f] : 0.f;
+}
+
+void launch_prep_logmel(const float* mel, int B, int T, int Tpad, float* x, int* flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_prep_logmel, dim3(nblocks((int64_t)B * Tpad * 127, 256)), dim3(256), 0, s, mel, B, T, Tpad, x, flags);
+  VFX_HIP(hipGetLastError());
+}
+void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s) {
+  hipLaunchKernelGGL(k_prep_spec, dim3(nblocks((int64_t)B * Tpad * 1024, 256)), dim3(256), 0, s, sp, B, T, Tpad, x);
+  VFX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// First residual block, Cin = 1 (encoder_block1.conv_block1 of modules.py:223-271):
+//   h  = conv3x3( lrelu(scale*x + shift) )   zero halo AFTER the activation
+//   sc = shortcut_w * x + shortcut_b          (1x1 conv with bias on the raw input)
+// 8 lanes per pixel, 4 output channels each -> 16-byte coalesced stores.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_c1(const float* __restrict__ x, int B, int H, int W,
+                                                  const float* __restrict__ w9x32, float scale, float shift,
+                                                  float slope, const float* __restrict__ wsc,
+                                                  const float* __restrict__ bsc, float* __restrict__ h,
+                                                  float* __restrict__ sc) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t pix = gid >> 3;
+  const int cg = gid & 7;
+  if (pix >= (int64_t)B * H * W) return;
+  const int j = pix % W;
+  const int64_t r = pix / W;
+  const int i = r % H;
+  const float* xb = x + (r - i) * W;  // start of image b
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ii = i + kh - 1, jj = j + kw - 1;
+      float a = 0.f;
+      if (ii >= 0 && ii < H && jj >= 0 && jj < W) {
+        a = xb[(int64_t)ii * W + jj] * scale + shift;
+        a = a >= 0.f ? a : a * slope;
+      }
+      const f32x4 w = *reinterpret_cast<const f32x4*>(w9x32 + (kh * 3 + kw) * 32 + 4 * cg);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(a, w[e], acc[e]);
+    }
+  }
+  *reinterpret_cast<f32x4*>(h + pix * 32 + 4 * cg) = acc;
+  const float xv = xb[(int64_t)i * W + j];
+  const f32x4 ws = *reinterpret_cast<const f32x4*>(wsc + 4 * cg);
+  const f32x4 bs = *reinterpret_cast<const f32x4*>(bsc + 4 * cg);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = fmaf(xv, ws[e], bs[e]);
+  *reinterpret_cast<f32x4*>(sc + pix * 32 + 4 * cg) = o;
+}
+
+void launch_conv_c1(const float* x, int B, int H, int W, const float* w9x32, float scale, float shift, float slope,
+                    const float* wsc32, const float* bsc32, float* h, float* sc, hipStream_t s) {
+  hipLaunchKernelGGL(k_conv_c1, dim3(nblocks((int64_t)B * H * W * 8, 256)), dim3(256), 0, s, x, B, H, W, w9x32, scale,
+                     shift, slope, wsc32, bsc32, h, sc);
+  VFX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.avg_pool2d(kernel 2) with floor semantics (modules.py:183): (B,H,W,C) -> (B,H/2,W/2,C)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_avgpool2(const float* __restrict__ x, int H, int W, int C4, int Ho, int Wo, int64_t total,
+                           float* __restrict__ y) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = idx % C4;
+  int64_t r = idx / C4;
+  const int j = r % Wo;
+  r /= Wo;
+  const int i = r % Ho;
+  const int64_t b = r / Ho;
+  const f32x4* X = reinterpret_cast<const f32x4*>(x);
+  const int64_t p00 = ((b * H + 2 * i) * W + 2 * j) * C4 + c;
+  const f32x4 v = ((X[p00] + X[p00 + C4]) + X[p00 + (int64_t)W * C4]) + X[p00 + (int64_t)W * C4 + C4];
+  reinterpret_cast<f32x4*>(y)[idx] = v * 0.25f;
+}
+
+void launch_avgpool2(const float* x, int B, int H, int W, int C, float* y, hipStream_t s) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  hipLaunchKernelGGL(k_avgpool2, dim3(nblocks(total, 256)), dim3(256), 0, s, x, H, W, C4, Ho, Wo, total, y);
+  VFX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// after_conv2 (1x1, 32 -> 1, bias; unet.py:52-53,96) + "recover shape" (unet.py:99-100) fused
+// with the caller's epilogue.  8 lanes per pixel, float4 dot + 3 xor-shuffles.
+//   mode 0: out0[b,t,f] = (f < 127 ? v : 0) + log10(max(aux0[b,t,f], 1e-8))         (B,T,128)
+//           = Generator.forward's  out['mel'] + to_log(mel_orig)  (gsr_voicefixer.py:90)
+//   mode 1: mag = (f < 1024 ? v : 0); out0 = mag * aux0 (cos), out1 = mag * aux1 (sin)  (B,T,1025)
+//           = unet_v2.py:129-137
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_final_1x1(const float* __restrict__ y, int B, int Tpad, int W,
+                                                    const float* __restrict__ w32, float bias, int mode, int T,
+                                                    const float* __restrict__ aux0, const float* __restrict__ aux1,
+                                                    float* __restrict__ out0, float* __restrict__ out1) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t q = gid >> 3;  // pixel among B*T*W (only rows < T)
+  const int cg = gid & 7;
+  const bool active = q < (int64_t)B * T * W;
+  float v = 0.f;
+  int f = 0, t = 0;
+  int64_t b = 0;
+  if (active) {
+    f = q % W;
+    const int64_t r = q / W;
+    t = r % T;
+    b = r / T;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(y + (((b * Tpad + t) * W) + f) * 32 + 4 * cg);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(w32 + 4 * cg);
+    v = a[0] * w[0] + a[1] * w[1] + a[2] * w[2] + a[3] * w[3];
+  }
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  if (!active || cg != 0) return;
+  v += bias;
+  const int Fo = W + 1;
+  const int64_t o = (b * T + t) * Fo + f;
+  if (mode == 0) {
+    out0[o] = v + log10f(fmaxf(aux0[o], 1e-8f));
+    if (f == W - 1) out0[o + 1] = log10f(fmaxf(aux0[o + 1], 1e-8f));
+  } else {
+    out0[o] = v * aux0[o];
+    out1[o] = v * aux1[o];
+    if (f == W - 1) {
+      out0[o + 1] = 0.f;
+      out1[o + 1] = 0.f;
+    }
+  }
+}
+
+void launch_final_1x1(const float* y, int B, int Tpad, int W, const float* w32, float bias, int mode, int T,
+                      const float* aux0, const float* aux1, float* out0, float* out1, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_1x1, dim3(nblocks((int64_t)B * T * W * 8, 256)), dim3(256), 0, s, y, B, Tpad, W, w32, bias,
+                     mode, T, aux0, aux1, out0, out1);
+  VFX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vocoder input normalisation (voicefixer.Vocoder.__call__, see oracle/vocoder.py):
+//   (B,T,128) linear mel -> (B,Tp,128) conditioning in [-R, R], frames >= T filled with -R.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_voc_prep(const float* __restrict__ mel, int T, int Tp, const float* __restrict__ inv_w,
+                           float amp_floor, float min_db, float range, int64_t total, float* __restrict__ cond) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int f = idx & 127;
+  const int64_t r = idx >> 7;
+  const int t = r % Tp;
+  const int64_t b = r / Tp;
+  float v = -range;
+  if (t < T) {
+    const float m = fabsf(mel[(b * T + t) * 128 + f] * inv_w[f]);
+    float s = 20.f * log10f(fmaxf(m, amp_floor)) - 20.f;
+    s = (s - min_db) / (-min_db) * (2.f * range) - range;
+    v = fminf(fmaxf(s, -range), range);
+  }
+  cond[idx] = v;
+}
+
+void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_weight, float amp_floor, float min_db,
+                     float range, float* cond, hipStream_t s) {
+  const int64_t total = (int64_t)B * Tp * 128;
+  hipLaunchKernelGGL(k_voc_prep, dim3(nblocks(total, 256)), dim3(256), 0, s, mel, T, Tp, inv_weight, amp_floor, min_db,
+                     range, total, cond);
+  VFX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vocoder tail: LeakyReLU(slope) -> ReflectionPad1d(3) -> Conv1d(C -> 1, k7) -> tanh.
+// 8 lanes per output sample, C/8 channels each, rows re-read through L1 (each row serves 7 outputs).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, int T, int C,
+                                                    const float* __restrict__ w /*[7][C]*/, float bias, float slope,
+                                                    int64_t total, float* __restrict__ wav) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t q = gid >> 3;
+  const int g = gid & 7;
+  const bool active = q < total;
+  float acc = 0.f;
+  if (active) {
+    const int t = q % T;
+    const float* xb = x + (q - t) * C;
+    const int cpl = C >> 3;  // channels per lane (multiple of 4)
+    for (int k = 0; k < 7; ++k) {
+      int tt = t + k - 3;
+      tt = tt < 0 ? -tt : tt;
+      tt = tt >= T ? 2 * (T - 1) - tt : tt;
+      const float* row = xb + (int64_t)tt * C + g * cpl;
+      const float* wr = w + k * C + g * cpl;
+      for (int c = 0; c < cpl; c += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row + c);
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = a[e] >= 0.f ? a[e] : a[e] * slope;
+          acc = fmaf(v, ww[e], acc);
+        }
+      }
+    }
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  if (active && g == 0) wav[q] = tanhf(acc + bias);
+}
+
+void launch_voc_final(const float* x, int B, int T, int C, const float* w, float bias, float slope, float* wav,
+                      hipStream_t s) {
+  const int64_t total = (int64_t)B * T;
+  hipLaunchKernelGGL(k_voc_final, dim3(nblocks(total * 8, 256)), dim3(256), 0, s, x, T, C, w, bias, slope, total, wav);
+  VFX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// handler() glue
+// ---------------------------------------------------------------------------------------------
+// from_log (pytorch_util.py:161-163): 10 ** min(x, 5).  With `sums` != null also accumulates the
+// per-clip energy of mel bins 5..24 of the estimate and of the input (amp_to_original_f,
+// tools/utils.py:50-55): sums[2b] += est, sums[2b+1] += target.
+__global__ void k_from_log(const float* __restrict__ logmel, const float* __restrict__ mel_in, int T, int64_t total,
+                           float* __restrict__ sums, float* __restrict__ mel_out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float e = 0.f, g = 0.f;
+  int64_t b = 0;
+  if (idx < total) {
+    const float v = exp10f(fminf(logmel[idx], 5.f));
+    mel_out[idx] = v;
+    const int f = idx & 127;
+    b = (idx >> 7) / T;
+    if (sums && f >= 5 && f < 25) {
+      e = v;
+      g = mel_in[idx];
+    }
+  }
+  if (sums) {
+    // a block may straddle two clips only at a clip boundary; keep it simple: per-lane atomics
+    // are restricted to the 20 contributing bins.
+    if (e != 0.f || g != 0.f) {
+      atomicAdd(sums + 2 * b, e);
+      atomicAdd(sums + 2 * b + 1, g);
+    }
+  }
+}
+
+__global__ void k_scale_by_ratio(float* __restrict__ mel, int T, int64_t total, const float* __restrict__ sums) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t b = (idx >> 7) / T;
+  mel[idx] *= sums[2 * b + 1] / sums[2 * b];
+}
+
+void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int unify, float* sums, float* mel_out,
+                     hipStream_t s) {
+  const int64_t total = (int64_t)B * T * 128;
+  if (unify) VFX_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 2 * B, s));
+  hipLaunchKernelGGL(k_from_log, dim3(nblocks(total, 256)), dim3(256), 0, s, logmel, mel_in, T, total,
+                     unify ? sums : nullptr, mel_out);
+  if (unify) hipLaunchKernelGGL(k_scale_by_ratio, dim3(nblocks(total, 256)), dim3(256), 0, s, mel_out, T, total, sums);
+  VFX_HIP(hipGetLastError());
+}
+
+// Peak normalise (eval_gsr_voicefixer.py:68-70) + trim_center (tools/utils.py:57-70), per clip.
+__global__ void k_absmax(const float* __restrict__ x, int64_t n_per, unsigned* __restrict__ peak) {
+  const int b = blockIdx.y;
+  const float* xb = x + (int64_t)b * n_per;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per; i += (int64_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(xb[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(peak + b, __float_as_uint(m));
+}
+
+__global__ void k_trim_scale(const float* __restrict__ x, int64_t Llong, int L, int off, const unsigned* __restrict__ peak,
+                             float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= L) return;
+  const float p = __uint_as_float(peak[b]);
+  const float v = x[(int64_t)b * Llong + off + n];
+  out[(int64_t)b * L + n] = p > 1.0f ? v / p : v;
+}
+
+void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, float* out, hipStream_t s) {
+  VFX_HIP(hipMemsetAsync(ws, 0, sizeof(unsigned) * B, s));
+  const int gx = (int)std::min<int64_t>(1024, (Llong + 255) / 256);
+  hipLaunchKernelGGL(k_absmax, dim3(gx, B), dim3(256), 0, s, wav_long, Llong, reinterpret_cast<unsigned*>(ws));
+  const int64_t diff = Llong - L;
+  const int off = (int)(diff / 2);
+  hipLaunchKernelGGL(k_trim_scale, dim3((L + 255) / 256, B), dim3(256), 0, s, wav_long, Llong, L, off,
+                     reinterpret_cast<const unsigned*>(ws), out);
+  VFX_HIP(hipGetLastError());
+}
+
+}  // namespace vfx

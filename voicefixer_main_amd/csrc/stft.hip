@@ -1,0 +1,238 @@
+// stft.hip -- fused STFT front-end / ISTFT back-end for gfx950.
+//
+// Forward (vfx_stft_mel): one 256-thread workgroup per frame:
+//   reflect-padded frame load (coalesced, 8 B per lane) x periodic Hann  ->  1024-point complex
+//   radix-4 Stockham FFT in LDS (5 passes, one butterfly per thread per pass)  ->  real-FFT
+//   untangle to 1025 bins  ->  mag = sqrt(max(re^2+im^2, 1e-8)), cos = re/mag, sin = im/mag
+//   (FDomainHelper.spectrogram_phase, tools/pytorch/modules/fDomainHelper.py:60-65)  ->  banded
+//   sparse mel projection from LDS (MelScale.forward, tools/pytorch/mel_scale.py:52-64; the
+//   filterbank has 2018 non-zeros, 1..55 per band)  ->  optional log10(max(.,1e-8))
+//   (to_log, tools/pytorch/pytorch_util.py:157-159).
+//   The reference does the DFT as two conv1d(1->1025, k=2048) = 4.2 MMAC/frame; the FFT needs
+//   ~0.06 MFLOP/frame, which makes the stage HBM/latency bound: 441 new samples in, 128 mel
+//   out per frame (2276 B/frame algorithmic) when sp/cos/sin are not requested.
+//
+// Inverse (vfx_istft): one workgroup per frame: Hermitian spectrum -> packed 1024-point complex
+//   inverse FFT -> x synthesis window -> frame buffer; a second kernel gathers the <=5
+//   overlapping frames per output sample, divides by the window sum-of-squares envelope and
+//   strips the centre padding (torchlibrosa ISTFT semantics, see oracle/dsp.py).
+#include "vfx_internal.h"
+
+namespace vfx {
+
+constexpr int NFFT = 2048;
+constexpr int NC = NFFT / 2;     // complex FFT length
+constexpr int NBINS = NC + 1;    // 1025
+constexpr int NMEL = 128;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// In-place (register) radix-4 butterfly.  SIGN = -1: forward (e^{-i}), +1: inverse.
+template <int SIGN>
+__device__ __forceinline__ void fft4(float2& v0, float2& v1, float2& v2, float2& v3) {
+  const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+  const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+  const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+  const float2 d = make_float2(v1.x - v3.x, v1.y - v3.y);
+  // forward: d * (-i) = (d.y, -d.x);  inverse: d * (+i) = (-d.y, d.x)
+  const float2 a3 = SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
+  v0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+  v1 = make_float2(a1.x + a3.x, a1.y + a3.y);
+  v2 = make_float2(a0.x - a2.x, a0.y - a2.y);
+  v3 = make_float2(a1.x - a3.x, a1.y - a3.y);
+}
+
+// 1024-point Stockham FFT, 256 threads, data in `z` (LDS, natural order in and out).
+// `v` holds this thread's four inputs of the FIRST pass (z[j + r*256]); tw = e^{-2 pi i m / 1024}.
+template <int SIGN>
+__device__ __forceinline__ void fft1024(float2* z, float2 v[4], const float2* __restrict__ tw, int j) {
+#pragma unroll
+  for (int pass = 0; pass < 5; ++pass) {
+    const int Ns = 1 << (2 * pass);
+    const int k = j & (Ns - 1);
+    if (pass > 0) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = z[j + r * (NC / 4)];
+      const int tstep = NC / (4 * Ns);  // table stride of this pass
+#pragma unroll
+      for (int r = 1; r < 4; ++r) {
+        float2 w = tw[k * r * tstep];
+        if (SIGN > 0) w.y = -w.y;
+        v[r] = cmul(v[r], w);
+      }
+      __syncthreads();
+    }
+    fft4<SIGN>(v[0], v[1], v[2], v[3]);
+    const int j0 = ((j - k) << 2) + k;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[j0 + r * Ns] = v[r];
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int reflect_index(int i, int L) {
+  i = i < 0 ? -i : i;
+  return i >= L ? 2 * (L - 1) - i : i;
+}
+
+__global__ __launch_bounds__(256) void k_stft_mel(const float* __restrict__ wav, int L, int T,
+                                                   const float* __restrict__ window,
+                                                   const float2* __restrict__ tw,
+                                                   const float2* __restrict__ rtw,
+                                                   const float* __restrict__ fb_val,
+                                                   const int* __restrict__ fb_start,
+                                                   const int* __restrict__ fb_off, float* __restrict__ mel,
+                                                   float* __restrict__ sp, float* __restrict__ cosp,
+                                                   float* __restrict__ sinp, int log10_mel, int hop) {
+  __shared__ float2 z[NC];
+  __shared__ float mag_s[NBINS + 3];
+  const int frame = blockIdx.x;       // b * T + t
+  const int b = frame / T, t = frame - b * T;
+  const int j = threadIdx.x;
+  const float* x = wav + (int64_t)b * L;
+  const int base = t * hop - NFFT / 2;
+
+  float2 v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = 2 * (j + r * (NC / 4));
+    const int g = base + n;
+    float x0, x1;
+    if (g >= 0 && g + 1 < L) {
+      x0 = x[g];
+      x1 = x[g + 1];
+    } else {
+      x0 = x[reflect_index(g, L)];
+      x1 = x[reflect_index(g + 1, L)];
+    }
+    const float2 w = *reinterpret_cast<const float2*>(window + n);
+    v[r] = make_float2(x0 * w.x, x1 * w.y);
+  }
+  fft1024<-1>(z, v, tw, j);
+
+  // real-FFT untangle: X[k] = E[k] + W^k O[k], E = (Z[k] + conj Z[N-k]) / 2, O = (Z[k] - conj Z[N-k]) / (2i)
+  const int64_t row = (int64_t)frame * NBINS;
+  for (int k = j; k < NBINS; k += 256) {
+    const float2 zk = z[k & (NC - 1)];
+    const float2 zn = z[(NC - k) & (NC - 1)];
+    const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    const float2 wo = cmul(rtw[k], o);
+    const float re = e.x + wo.x, im = e.y + wo.y;
+    const float mag = sqrtf(fmaxf(re * re + im * im, 1e-8f));
+    mag_s[k] = mag;
+    if (sp) sp[row + k] = mag;
+    if (cosp) cosp[row + k] = re / mag;
+    if (sinp) sinp[row + k] = im / mag;
+  }
+  __syncthreads();
+  if (mel && j < NMEL) {
+    const int f0 = fb_start[j], o0 = fb_off[j], n = fb_off[j + 1] - o0;
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc = fmaf(mag_s[f0 + i], fb_val[o0 + i], acc);
+    mel[(int64_t)frame * NMEL + j] = log10_mel ? log10f(fmaxf(acc, 1e-8f)) : acc;
+  }
+}
+
+__global__ __launch_bounds__(128) void k_mel_project(const float* __restrict__ sp, int64_t rows,
+                                                      const float* __restrict__ fb_val,
+                                                      const int* __restrict__ fb_start,
+                                                      const int* __restrict__ fb_off, float* __restrict__ mel) {
+  __shared__ float s[NBINS + 3];
+  const int64_t row = blockIdx.x;
+  for (int k = threadIdx.x; k < NBINS; k += 128) s[k] = sp[row * NBINS + k];
+  __syncthreads();
+  const int j = threadIdx.x;
+  const int f0 = fb_start[j], o0 = fb_off[j], n = fb_off[j + 1] - o0;
+  float acc = 0.f;
+  for (int i = 0; i < n; ++i) acc = fmaf(s[f0 + i], fb_val[o0 + i], acc);
+  mel[row * NMEL + j] = acc;
+}
+
+// Inverse: per frame, x[n] (n < 2048) = irfft(X)[n] * window[n], written to frames[(frame)*2048 + n].
+//   Pack Z[k] = E[k] + i O[k] with E = (X[k] + conj X[N-k]) / 2, O = conj(W^k) (X[k] - conj X[N-k]) / 2;
+//   z = IFFT1024(Z) / 1024;  x[2n] = Re z[n], x[2n+1] = Im z[n].
+__global__ __launch_bounds__(256) void k_istft_frames(const float* __restrict__ re, const float* __restrict__ im,
+                                                       const float* __restrict__ window,
+                                                       const float2* __restrict__ tw,
+                                                       const float2* __restrict__ rtw, float* __restrict__ frames) {
+  __shared__ float2 z[NC];
+  const int64_t frame = blockIdx.x;
+  const int j = threadIdx.x;
+  const float* R = re + frame * NBINS;
+  const float* I = im + frame * NBINS;
+  float2 v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = j + r * (NC / 4);
+    const float2 xk = make_float2(R[k], I[k]);
+    const float2 xn = make_float2(R[NC - k], I[NC - k]);
+    const float2 e = make_float2(0.5f * (xk.x + xn.x), 0.5f * (xk.y - xn.y));
+    const float2 d = make_float2(0.5f * (xk.x - xn.x), 0.5f * (xk.y + xn.y));
+    float2 w = rtw[k];
+    w.y = -w.y;  // conj(W^k) = e^{+2 pi i k / 2048}
+    const float2 o = cmul(w, d);
+    // Z = E + i O
+    v[r] = make_float2(e.x - o.y, e.y + o.x);
+  }
+  fft1024<1>(z, v, tw, j);
+  const float sc = 1.0f / NC;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = j + r * (NC / 4);
+    const float2 zz = z[n];
+    const float2 w = *reinterpret_cast<const float2*>(window + 2 * n);
+    *reinterpret_cast<float2*>(frames + frame * NFFT + 2 * n) = make_float2(zz.x * sc * w.x, zz.y * sc * w.y);
+  }
+}
+
+// Overlap-add gather: wav[b, n] = (sum_t frames[b, t, n + 1024 - t*hop]) * inv_env[n + 1024], n < min(L, (T-1)*hop); 0 beyond.
+__global__ __launch_bounds__(256) void k_istft_ola(const float* __restrict__ frames, const float* __restrict__ inv_env,
+                                                    int T, int L, int hop, float* __restrict__ wav) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= L) return;
+  const int p = n + NFFT / 2;                // position in the un-trimmed OLA buffer
+  float acc = 0.f;
+  if (n < (T - 1) * hop) {
+    int t_hi = p / hop;                      // last frame starting at or before p
+    if (t_hi > T - 1) t_hi = T - 1;
+    int t_lo = (p - NFFT + hop) / hop;       // first frame with t*hop + 2048 > p
+    if (t_lo < 0) t_lo = 0;
+    const float* fr = frames + (int64_t)b * T * NFFT;
+    for (int t = t_lo; t <= t_hi; ++t) {
+      const int o = p - t * hop;
+      if (o >= 0 && o < NFFT) acc += fr[(int64_t)t * NFFT + o];
+    }
+    acc *= inv_env[p];
+  }
+  wav[(int64_t)b * L + n] = acc;
+}
+
+void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, int T, float* mel, float* sp,
+                     float* cosp, float* sinp, int log10_mel, int hop, hipStream_t stream) {
+  hipLaunchKernelGGL(k_stft_mel, dim3(B * T), dim3(256), 0, stream, wav, L, T, t.window,
+                     reinterpret_cast<const float2*>(t.twiddle), reinterpret_cast<const float2*>(t.rtwiddle),
+                     t.fb_val, t.fb_start, t.fb_off, mel, sp, cosp, sinp, log10_mel, hop);
+  VFX_HIP(hipGetLastError());
+}
+
+void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, float* mel, hipStream_t stream) {
+  hipLaunchKernelGGL(k_mel_project, dim3((unsigned)rows), dim3(128), 0, stream, sp, rows, t.fb_val, t.fb_start,
+                     t.fb_off, mel);
+  VFX_HIP(hipGetLastError());
+}
+
+void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop,
+                  const float* inv_env, float* frames_ws, float* wav, hipStream_t stream) {
+  hipLaunchKernelGGL(k_istft_frames, dim3(B * T), dim3(256), 0, stream, re, im, t.window,
+                     reinterpret_cast<const float2*>(t.twiddle), reinterpret_cast<const float2*>(t.rtwiddle),
+                     frames_ws);
+  hipLaunchKernelGGL(k_istft_ola, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames_ws, inv_env, T, L, hop, wav);
+  VFX_HIP(hipGetLastError());
+}
+
+}  // namespace vfx

@@ -1,0 +1,275 @@
+// Internal declarations shared by the libvfx.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "vfx.h"
+
+namespace vfx {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+struct Error {};  // thrown after set_error(); caught at the C boundary
+
+#define VFX_HIP(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      ::vfx::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      throw ::vfx::Error();                                                                  \
+    }                                                                                        \
+  } while (0)
+
+#define VFX_CHECK(cond, ...)         \
+  do {                               \
+    if (!(cond)) {                   \
+      ::vfx::set_error(__VA_ARGS__); \
+      throw ::vfx::Error();          \
+    }                                \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// generic tap-convolution (implicit GEMM on the fp32 MFMA) -- see tapconv.hip
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxTaps = 9;
+constexpr int kMaxSegs = 3;
+constexpr int kKC = 32;  // input channels per K step
+
+enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_ELU = 2 };
+
+// One K-range of the implicit GEMM: a source tensor (channels-last), its prologue
+// (per-channel affine + activation, applied while the tile is staged into LDS; positions
+// outside the tensor are 0 AFTER the prologue) and a tap list with K-chunked weights.
+struct TapSeg {
+  const float* src;    // (B, Hi, Wi, C)
+  const float* scale;  // [C] or nullptr (=1)
+  const float* shift;  // [C] or nullptr (=0)
+  const float* wt;     // packed [C/32][ntaps][Cout][32]
+  int C;
+  int ntaps;
+  int act;
+  float slope;
+  int dh[kMaxTaps];
+  int dw[kMaxTaps];
+};
+
+struct TapConvParams {
+  TapSeg seg[kMaxSegs];
+  int nseg;
+  int total_steps;       // sum over segs of ntaps * C/32
+  int B, Hi, Wi;         // input spatial extent (shared by all segments)
+  int Hg, Wg;            // logical grid: one GEMM row per (b, i < Hg, j < Wg)
+  int Ho, Wo, Cout;      // output tensor (B, Ho, Wo, Cout)
+  int sh, sw, oh0, ow0;  // grid (i, j) -> output pixel (i*sh + oh0, j*sw + ow0), masked to Ho x Wo
+  int reflect_w;         // reflect addressing along W (ReflectionPad1d) instead of zero padding
+  int M;                 // B * Hg * Wg
+  const float* bias;     // [Cout] or nullptr
+  const float* residual; // (B, Ho, Wo, Cout) or nullptr, added in the epilogue
+  float* out;
+};
+
+void finish_params(TapConvParams& p);  // fills total_steps and M, validates
+void launch_tapconv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
+double tapconv_flops(const TapConvParams& hp);
+
+// ---------------------------------------------------------------------------------------------
+// front-end tables + small kernels -- see stft.hip / small_ops.hip
+// ---------------------------------------------------------------------------------------------
+struct FrontEndTables {
+  float* window = nullptr;    // [2048] periodic Hann
+  float* twiddle = nullptr;   // [1024] float2 e^{-2 pi i m / 1024}
+  float* rtwiddle = nullptr;  // [1025] float2 e^{-2 pi i k / 2048}
+  float* fb_val = nullptr;    // packed non-zeros of the mel filterbank, band-major
+  int* fb_start = nullptr;    // [128] first frequency bin of band m
+  int* fb_off = nullptr;      // [129] offsets into fb_val
+  float* inv_env = nullptr;   // ISTFT 1/window-sumsquare envelope for inv_env_T frames
+  int inv_env_T = 0;
+  float* voc_inv_weight = nullptr;  // [128] 1 / mel band weight
+};
+
+void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, int T, float* mel, float* sp,
+                     float* cosp, float* sinp, int log10_mel, int hop, hipStream_t stream);
+void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, float* mel, hipStream_t stream);
+void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop,
+                  const float* inv_env, float* frames_ws, float* wav, hipStream_t stream);
+
+void launch_prep_logmel(const float* mel_linear, int B, int T, int Tpad, float* x, int* flags, hipStream_t s);
+void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s);
+void launch_conv_c1(const float* x, int B, int H, int W, const float* w9x32, float scale, float shift, float slope,
+                    const float* wsc32, const float* bsc32, float* h, float* sc, hipStream_t s);
+void launch_avgpool2(const float* x, int B, int H, int W, int C, float* y, hipStream_t s);
+void launch_final_1x1(const float* y, int B, int Tpad, int W, const float* w32, float bias, int mode, int T,
+                      const float* aux0, const float* aux1, float* out0, float* out1, hipStream_t s);
+void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_weight, float amp_floor, float min_db,
+                     float range, float* cond, hipStream_t s);
+void launch_voc_final(const float* x, int B, int T, int C, const float* w, float bias, float slope, float* wav,
+                      hipStream_t s);
+void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int unify, float* sums, float* mel_out,
+                     hipStream_t s);
+void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, float* out, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// handle-side data structures
+// ---------------------------------------------------------------------------------------------
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+// Long-lived device allocations (tables, weights, plan parameter blocks).
+struct DeviceBlob {
+  std::vector<void*> allocs;
+  void* alloc(size_t bytes);
+  float* upload(const float* p, size_t n);
+  float* upload(const std::vector<float>& v) { return upload(v.data(), v.size()); }
+  int* upload_i(const std::vector<int>& v);
+  void release();
+  ~DeviceBlob() { release(); }
+};
+
+// Offsets into the workspace arena, assigned at plan-build time by a first-fit free list.
+struct ArenaPlanner {
+  struct Block { size_t off, size; bool free; };
+  std::vector<Block> blocks;
+  size_t high = 0;
+  size_t alloc(size_t bytes);
+  void free(size_t off);
+};
+
+// A buffer is either a slice of the arena (resolved when the plan is bound to an arena base)
+// or one of the caller's tensors (resolved per call).
+struct RunCtx {
+  hipStream_t stream;
+  float* ext[8];
+  int* flags;
+};
+
+struct Plan {
+  std::vector<std::function<void(const RunCtx&)>> ops;
+  std::vector<TapConvParams> host_params;  // arena-relative until bind()
+  TapConvParams* dev_params = nullptr;
+  DeviceBlob blob;
+  size_t arena_bytes = 0;
+  char* bound_base = nullptr;
+  double conv_flops = 0;
+  int n_conv = 0;
+  std::map<std::string, size_t> named;  // named arena offsets (bytes) of stage-level buffers
+  void run(const RunCtx& ctx) {
+    for (auto& f : ops) f(ctx);
+  }
+};
+
+// Arena-relative pointer encoding used inside TapConvParams until bind_plan(): offset + 1
+// (so that offset 0 is distinguishable from nullptr).
+inline const float* rel_ptr(size_t off) { return reinterpret_cast<const float*>(off + 1); }
+
+struct PlanBuilder {
+  vfx_handle* h;
+  Plan* plan;
+  ArenaPlanner arena;
+  // returns arena offset in BYTES
+  size_t alloc_f(int64_t nfloat) { return arena.alloc((size_t)nfloat * sizeof(float)); }
+  void free(size_t off) { arena.free(off); }
+  // Adds a tap-convolution whose src/residual/out pointers are arena offsets encoded as
+  // (const float*)offset; they are rebased in Plan::bind.
+  void add_conv(TapConvParams p);
+};
+
+struct ConvBlockW {
+  int cin = 0, cout = 0, nsrc = 1;  // nsrc = 2: the input is cat(src0, src1), cin/2 channels each
+  float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
+  float* w1[2] = {nullptr, nullptr};   // conv1 packed per source
+  float* w2 = nullptr;                 // conv2 packed
+  float* wsc[2] = {nullptr, nullptr};  // 1x1 shortcut packed per source (cin != cout)
+  float* bsc = nullptr;
+  bool shortcut = false;
+};
+
+struct DecoderW {
+  int cin = 0, cout = 0;
+  float *bn_scale = nullptr, *bn_shift = nullptr;
+  float* wT[4] = {nullptr, nullptr, nullptr, nullptr};  // packed per output parity class (a*2+b)
+  ConvBlockW blocks[4];
+};
+
+struct UNetWeights {
+  float c1_scale = 1.f, c1_shift = 0.f;
+  float *c1_w = nullptr, *c1_wsc = nullptr, *c1_bsc = nullptr;
+  ConvBlockW enc[6][4];
+  ConvBlockW bott;
+  DecoderW dec[6];
+  ConvBlockW after;
+  float* final_w = nullptr;
+  float final_b = 0.f;
+};
+
+struct VocConvW {
+  float* w = nullptr;     // packed (per phase for transposed convs: w_phase[r])
+  float* bias = nullptr;
+  std::vector<float*> w_phase;
+  int cin = 0, cout = 0;
+};
+
+struct VocoderWeights {
+  std::vector<VocConvW> cond;   // k3 convs
+  VocConvW pre;                 // k7 reflect
+  std::vector<VocConvW> up;     // transposed convs
+  std::vector<std::vector<std::pair<VocConvW, VocConvW>>> res;
+  float* final_w = nullptr;     // [7][C]
+  float final_b = 0.f;
+  int final_c = 0;
+};
+
+std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int KW, int c_lo, int C,
+                             const std::vector<std::pair<int, int>>& taps);
+std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,
+                                        const std::vector<std::pair<int, int>>& taps);
+
+}  // namespace vfx
+
+struct vfx_handle {
+  int device = 0;
+  vfx_config cfg{};
+  std::map<std::string, vfx::HostTensor> staged[4];
+  vfx::FrontEndTables fe;
+  vfx::DeviceBlob blob;  // front-end tables + weights
+  std::shared_ptr<vfx::UNetWeights> unet[2];
+  std::shared_ptr<vfx::VocoderWeights> voc;
+  std::map<std::string, std::shared_ptr<vfx::Plan>> plans;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  int* d_flags = nullptr;
+};
+
+namespace vfx {
+void init_front_end(vfx_handle* h);
+void set_mel_filterbank(vfx_handle* h, const float* fb /*1025x128*/);
+const float* istft_envelope(vfx_handle* h, int T);
+void bind_plan(vfx_handle* h, Plan& plan);  // ensures the arena is large enough and rebases the plan on it
+std::shared_ptr<UNetWeights> build_unet_weights(vfx_handle* h, int model);
+std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h);
+
+// plan builders: append the ops of one stage to `pb`.  Buffers named *_off are arena byte
+// offsets; ext slots index RunCtx::ext.
+//   unet: input = ext[in_slot] or arena (in_off); mel model writes (B,T,128) log-mel to ext[out_slot] / arena.
+struct BufRef {
+  bool ext = false;
+  int slot = 0;
+  size_t off = 0;
+};
+void build_unet_mel(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef logmel_out);
+void build_unet_spec(PlanBuilder& pb, int B, int T, BufRef sp, BufRef cosb, BufRef sinb, BufRef re_out, BufRef im_out);
+void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_out);
+int64_t vocoder_out_len(const vfx_config& cfg, int T);
+}  // namespace vfx

@@ -1,0 +1,220 @@
+"""Thin Python wrapper over one libvfx handle: torch tensors in, torch tensors out.
+
+All compute happens in the HIP library; this file only allocates outputs with torch,
+passes raw device pointers + the current HIP stream, and raises on any failure.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MODEL_FRONTEND, MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER
+
+N_BINS = 1025
+N_MELS = 128
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev_f32(t, device):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    """One libvfx handle on one GPU (not thread-safe, like the reference's module-level model)."""
+
+    def __init__(self, device="cuda:0", config=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("voicefixer_main_amd runs on an MI355X GPU only (got device %s); "
+                               "there is no CPU path" % device)
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible to PyTorch")
+        torch.cuda.init()
+        self.cfg = _lib.VfxConfig()
+        self.lib.vfx_default_config(ctypes.byref(self.cfg))
+        if config:
+            for k, v in config.items():
+                cur = getattr(self.cfg, k)
+                if hasattr(cur, "__len__"):
+                    for i, x in enumerate(v):
+                        cur[i] = x
+                else:
+                    setattr(self.cfg, k, v)
+        h = ctypes.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.lib.vfx_create(idx, ctypes.byref(self.cfg), ctypes.byref(h)), "vfx_create")
+        self.h = h
+        self.loaded = set()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vfx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def hop(self):
+        return self.cfg.hop
+
+    def frames(self, L):
+        return L // self.cfg.hop + 1
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, model, state_dict, prefix=""):
+        """Upload a (reference-keyed) state_dict for `model` and finalize it."""
+        n = 0
+        for k, v in state_dict.items():
+            if prefix:
+                if not k.startswith(prefix):
+                    continue
+                k = k[len(prefix):]
+            if k.endswith("num_batches_tracked"):
+                continue
+            a = np.ascontiguousarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v),
+                                     dtype=np.float32)
+            shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+            _lib.check(self.lib.vfx_load_tensor(self.h, model, k.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim),
+                       "vfx_load_tensor(%s)" % k)
+            n += 1
+        if n == 0:
+            raise RuntimeError("no tensors with prefix %r in the state_dict" % prefix)
+        _lib.check(self.lib.vfx_finalize_weights(self.h, model), "vfx_finalize_weights")
+        self.loaded.add(model)
+
+    def set_mel_filterbank(self, fb):
+        self.load_state_dict(MODEL_FRONTEND, {"mel.fb": fb})
+
+    def reserve(self, model, B, T):
+        _lib.check(self.lib.vfx_reserve(self.h, model, B, T), "vfx_reserve")
+
+    def workspace_bytes(self, model, B, T):
+        return int(self.lib.vfx_workspace_bytes(self.h, model, B, T))
+
+    def take_flags(self):
+        f = ctypes.c_int(0)
+        _lib.check(self.lib.vfx_take_flags(self.h, self._stream(), ctypes.byref(f)), "vfx_take_flags")
+        return f.value
+
+    # ------------------------------------------------------------------ stages
+    def stft(self, wav, want_mel=True, want_sp=False, want_phase=False, log10_mel=False):
+        """wav (B, L) -> dict with any of mel (B,T,128), sp / cos / sin (B,T,1025)."""
+        wav = _dev_f32(wav, self.device)
+        B, L = wav.shape
+        T = self.frames(L)
+        out = {}
+        if want_mel:
+            out["mel"] = torch.empty((B, T, N_MELS), device=self.device, dtype=torch.float32)
+        if want_sp:
+            out["sp"] = torch.empty((B, T, N_BINS), device=self.device, dtype=torch.float32)
+        if want_phase:
+            out["cos"] = torch.empty((B, T, N_BINS), device=self.device, dtype=torch.float32)
+            out["sin"] = torch.empty((B, T, N_BINS), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.vfx_stft_mel(self.h, _ptr(wav), B, L, _ptr(out.get("mel")), _ptr(out.get("sp")),
+                                         _ptr(out.get("cos")), _ptr(out.get("sin")), int(log10_mel), self._stream()),
+                   "vfx_stft_mel")
+        return out
+
+    def mel_project(self, sp):
+        """sp (..., 1025) -> (..., 128)."""
+        sp = _dev_f32(sp, self.device)
+        rows = sp.numel() // N_BINS
+        mel = torch.empty(sp.shape[:-1] + (N_MELS,), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.vfx_mel_project(self.h, _ptr(sp), rows, _ptr(mel), self._stream()), "vfx_mel_project")
+        return mel
+
+    def istft(self, re, im, length):
+        re, im = _dev_f32(re, self.device), _dev_f32(im, self.device)
+        B, T, _ = re.shape
+        wav = torch.empty((B, length), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.vfx_istft(self.h, _ptr(re), _ptr(im), B, T, length, _ptr(wav), self._stream()), "vfx_istft")
+        return wav
+
+    def resunet_mel(self, mel_linear):
+        """Generator.forward: linear mel (B,T,128) -> log10 mel (B,T,128)."""
+        mel = _dev_f32(mel_linear, self.device)
+        B, T, _ = mel.shape
+        out = torch.empty_like(mel)
+        _lib.check(self.lib.vfx_resunet_mel(self.h, _ptr(mel), B, T, _ptr(out), self._stream()), "vfx_resunet_mel")
+        return out
+
+    def resunet_spec(self, sp, wav):
+        sp, wav = _dev_f32(sp, self.device), _dev_f32(wav, self.device)
+        B, T, _ = sp.shape
+        L = wav.shape[-1]
+        out = torch.empty((B, L), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.vfx_resunet_spec(self.h, _ptr(sp), _ptr(wav), B, T, L, _ptr(out), self._stream()),
+                   "vfx_resunet_spec")
+        return out
+
+    def vocoder_out_len(self, T):
+        return int(self.lib.vfx_vocoder_out_len(self.h, T))
+
+    def vocoder(self, mel_linear):
+        mel = _dev_f32(mel_linear, self.device)
+        B, T, _ = mel.shape
+        out = torch.empty((B, self.vocoder_out_len(T)), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.vfx_vocoder(self.h, _ptr(mel), B, T, _ptr(out), self._stream()), "vfx_vocoder")
+        return out
+
+    def restore_gsr(self, wav, unify_energy=False, want_logmel=False, out=None):
+        """Whole handler() segment body for a batch: wav (B, L) -> restored (B, L)."""
+        wav = _dev_f32(wav, self.device)
+        B, L = wav.shape
+        if out is None:
+            out = torch.empty_like(wav)
+        logmel = torch.empty((B, self.frames(L), N_MELS), device=self.device, dtype=torch.float32) if want_logmel else None
+        _lib.check(self.lib.vfx_restore_gsr(self.h, _ptr(wav), B, L, _ptr(out), _ptr(logmel), int(bool(unify_energy)),
+                                            self._stream()), "vfx_restore_gsr")
+        return (out, logmel) if want_logmel else out
+
+    # ------------------------------------------------------------------ kernel-level ops (tests)
+    def op_conv(self, x, weight, scale=None, shift=None, act=0, slope=0.0, bias=None, residual=None, dil_w=1,
+                reflect_w=False):
+        """x (B,H,W,Cin) channels-last; weight (Cout,Cin,kh,kw) torch layout (host)."""
+        x = _dev_f32(x, self.device)
+        B, H, W, Cin = x.shape
+        w = np.ascontiguousarray(np.asarray(weight, dtype=np.float32))
+        Cout, _, kh, kw = w.shape
+        y = torch.empty((B, H, W, Cout), device=self.device, dtype=torch.float32)
+        hp = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        scale, shift, bias = hp(scale), hp(shift), hp(bias)
+        cp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+        res = None if residual is None else _dev_f32(residual, self.device)
+        _lib.check(self.lib.vfx_op_conv(self.h, _ptr(x), B, H, W, Cin, cp(w), Cout, kh, kw, dil_w, int(reflect_w), cp(scale),
+                                        cp(shift), act, float(slope), cp(bias), _ptr(res), _ptr(y), self._stream()),
+                   "vfx_op_conv")
+        return y
+
+    def op_conv_transpose(self, x, weight, stride, prune_w=False, scale=None, shift=None, act=0, slope=0.0, bias=None):
+        x = _dev_f32(x, self.device)
+        B, H, W, Cin = x.shape
+        w = np.ascontiguousarray(np.asarray(weight, dtype=np.float32))
+        _, Cout, kh, kw = w.shape
+        if kh == 3:
+            shape = (B, 2 * H, 2 * W if prune_w else 2 * W + 1, Cout)
+        else:
+            shape = (B, 1, W * stride, Cout)
+        y = torch.empty(shape, device=self.device, dtype=torch.float32)
+        hp = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        scale, shift, bias = hp(scale), hp(shift), hp(bias)
+        cp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(self.lib.vfx_op_conv_transpose(self.h, _ptr(x), B, H, W, Cin, cp(w), Cout, kh, kw, stride, int(prune_w),
+                                                  cp(scale), cp(shift), act, float(slope), cp(bias), _ptr(y), self._stream()),
+                   "vfx_op_conv_transpose")
+        return y
