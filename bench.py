@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- VoiceFixer 44.1 kHz restoration throughput on MI355X.
+
+Metric (BASELINE.json): restored-audio seconds per wall-second (RTF^-1).  A "step" is one
+pass of the whole `gsr_voicefixer` hot path (STFT -> mel -> ResUNet -> from_log -> TFGAN
+vocoder -> peak normalise -> trim; eval_gsr_voicefixer.py:47-74) over one batch of
+16 x 10 s synthetic clips per GPU (BASELINE.json configs[1]), inputs resident in HBM.
+Weak scaling: every rank restores its own shard, no collective on the data path.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live: HIP events around every launch of
+the dominant kernel (k_tapconv, the fp32-MFMA tap-convolution) on its own stream over K steps
+of the same workload; `cpu_baseline` times the CPU oracle (oracle/, a port of the reference
+algorithm) on a bounded sample of the same clips on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clips", type=int, default=16, help="clips per GPU per step")
+    ap.add_argument("--seconds", type=float, default=10.0, help="clip length")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=2.0, help="length of the CPU-oracle sample clip (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(clips, sample_seconds):
+    """Time the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
+    from oracle import pipeline
+    from voicefixer_main_amd import synth
+    n = int(round(sample_seconds * 44100))
+    wav = clips[:1, :, :n]
+    unet_sd = synth.make_resunet_state_dict(0)
+    voc_sd = synth.make_vocoder_state_dict(1)
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    pipeline.restore_gsr(unet_sd, voc_sd, wav)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_seconds / dt, 4), "unit": "audio-s/s", "cores": torch.get_num_threads(),
+            "kind": "port", "seconds": round(dt, 2),
+            "sample": "oracle.pipeline.restore_gsr (torch-CPU fp32 + numpy) on 1 clip x %.1f s of the same synthetic "
+                      "clips, same seeded weights, one run" % sample_seconds}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_VOCODER
+
+    eng = Engine(device)
+    eng.load_state_dict(MODEL_UNET_MEL, synth.make_resunet_state_dict(0))
+    eng.load_state_dict(MODEL_VOCODER, synth.make_vocoder_state_dict(1))
+
+    clips = synth.make_clips(args.clips, args.seconds, seed=1234 + 1000 * rank)      # (B, 1, L) float32, host
+    wav = torch.from_numpy(clips[:, 0]).to(device)                                   # resident in HBM
+    out = torch.empty_like(wav)
+    B, L = wav.shape
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    if world > 1:
+        # Exercise the shard scatter / gather over RCCL once, outside the timed region.
+        try:
+            from voicefixer_main_amd import dist as vdist
+            vdist.selfcheck(device)
+        except Exception as e:  # never fatal for the throughput measurement
+            print("[bench] scatter/gather self-check failed on rank %d: %r" % (rank, e), file=sys.stderr)
+
+    for _ in range(args.warmup):
+        eng.restore_gsr(wav, out=out)
+    torch.cuda.synchronize(device)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.restore_gsr(wav, out=out)
+    torch.cuda.synchronize(device)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    flags = eng.take_flags()
+    finite = bool(torch.isfinite(out).all().item())
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        eng.profile_begin()
+        for _ in range(args.steps):
+            eng.restore_gsr(wav, out=out)
+        n, ms, fl = eng.profile_end()
+        tflops = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "k_tapconv (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv)",
+                    "achieved": round(tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": n // max(args.steps, 1),
+                    "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
+                    "kernel_ms_per_step": round(ms / max(args.steps, 1), 3),
+                    "algorithmic_gflop_per_step": round(fl / max(args.steps, 1) / 1e9, 1)}
+
+    if rank == 0:
+        audio_s = world * B * args.seconds * args.steps
+        res = {
+            "metric": "restored-audio sec/s (RTF^-1), VoiceFixer 44.1 kHz",
+            "value": round(audio_s / dt, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "gsr_voicefixer ResUNet+vocoder restore, batch=%dx%.0f s @44.1 kHz per GPU "
+                                   "(BASELINE.json configs[1]); fp32 operands on the fp32 MFMA (bf16 operands miss the "
+                                   "log-mel L1<=1e-3 parity bar by 19x)" % (B, args.seconds),
+                       "clips_per_gpu": B, "clip_seconds": args.seconds, "parallelism": "dp%d" % world,
+                       "weights": "seeded random (no checkpoint available offline)"},
+            "outputs_finite": finite, "negative_input_flag": flags,
+        }
+        if roofline:
+            res["roofline"] = roofline
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            try:
+                res["cpu_baseline"] = cpu_baseline(clips, args.cpu_baseline_seconds)
+            except Exception as e:
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,15 @@ int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_ou
 int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out);
 
 /*
+ * Live kernel timing for the roofline report: between vfx_profile_begin and vfx_profile_end
+ * every tap-convolution launch is bracketed by HIP events on its own stream.
+ * vfx_profile_end synchronises and returns the number of launches, the sum of their
+ * durations (ms) and of their algorithmic FLOPs (2*M*Cout*K); out pointers may be NULL.
+ */
+int vfx_profile_begin(vfx_handle* h);
+int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* total_flops);
+
+/*
  * Kernel-level entry points (used by the parity tests to check each kernel against the
  * oracle in isolation; not part of the reference surface).
  * vfx_op_conv: generic tap-convolution on channels-last activations.

@@ -1,6 +1,7 @@
 // api.cpp -- handle, weight staging, arena and the extern "C" entry points of libvfx.so.
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 #include "vfx_internal.h"
 
@@ -154,7 +155,22 @@ void PlanBuilder::add_conv(TapConvParams p) {
   plan->conv_flops += tapconv_flops(p);
   plan->n_conv += 1;
   Plan* pl = plan;
-  plan->ops.push_back([pl, idx](const RunCtx& c) { launch_tapconv(pl->host_params[idx], pl->dev_params + idx, c.stream); });
+  plan->ops.push_back([pl, idx](const RunCtx& c) {
+    if (c.prof && c.prof->enabled) {
+      hipEvent_t a, b;
+      VFX_HIP(hipEventCreate(&a));
+      VFX_HIP(hipEventCreate(&b));
+      VFX_HIP(hipEventRecord(a, c.stream));
+      launch_tapconv(pl->host_params[idx], pl->dev_params + idx, c.stream);
+      VFX_HIP(hipEventRecord(b, c.stream));
+      c.prof->events.push_back({a, b});
+      c.prof->flops.push_back(tapconv_flops(pl->host_params[idx]));
+      c.prof->bn.push_back(pl->host_params[idx].Cout);
+      c.prof->desc.push_back(pl->host_params[idx]);
+    } else {
+      launch_tapconv(pl->host_params[idx], pl->dev_params + idx, c.stream);
+    }
+  });
 }
 
 static char* ensure_arena(vfx_handle* h, size_t bytes) {
@@ -181,7 +197,14 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     return reinterpret_cast<const float*>(base + reinterpret_cast<size_t>(rel) - 1);
   };
   for (auto& p : abs) {
-    for (int s = 0; s < p.nseg; ++s) p.seg[s].src = rebase(p.seg[s].src);
+    for (int s = 0; s < p.nseg; ++s) {
+      p.seg[s].src = rebase(p.seg[s].src);
+      if (!p.seg[s].scale) {  // the kernel always loads the affine pair
+        VFX_CHECK(p.seg[s].C <= kIdentityLen, "segment too wide for the identity tables");
+        p.seg[s].scale = h->d_ones;
+        p.seg[s].shift = h->d_zeros;
+      }
+    }
     if (p.residual) p.residual = rebase(p.residual);
     p.out = const_cast<float*>(rebase(p.out));
   }
@@ -341,6 +364,11 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
   VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
   init_front_end(h.get());
+  {
+    std::vector<float> ones(kIdentityLen, 1.f), zeros(kIdentityLen, 0.f);
+    h->d_ones = h->blob.upload(ones);
+    h->d_zeros = h->blob.upload(zeros);
+  }
   h->d_flags = static_cast<int*>(h->blob.alloc(sizeof(int)));
   VFX_HIP(hipMemset(h->d_flags, 0, sizeof(int)));
   *out = h.release();
@@ -518,7 +546,7 @@ int vfx_resunet_mel(vfx_handle* h, const float* mel_linear, int B, int T, float*
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL], "vfx_resunet_mel: weights of the mel ResUNet are not finalized");
   auto plan = get_plan(h, key_of("unet_mel", B, T),
                        [&](PlanBuilder& pb) { build_unet_mel(pb, B, T, ext(0), ext(1)); });
-  RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), logmel_out}, h->d_flags};
+  RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
 }
@@ -548,7 +576,7 @@ int vfx_resunet_spec(vfx_handle* h, const float* sp, const float* wav, int B, in
   float* sinb = reinterpret_cast<float*>(base + off_sin);
   // second STFT of the same audio for the phase (unet_v2.py:96)
   launch_stft_mel(h->fe, wav, B, L, T, nullptr, nullptr, cosb, sinb, 0, h->cfg.hop, s);
-  RunCtx ctx{s, {const_cast<float*>(sp)}, h->d_flags};
+  RunCtx ctx{s, {const_cast<float*>(sp)}, h->d_flags, &h->prof};
   plan->run(ctx);
   launch_istft(h->fe, reinterpret_cast<float*>(base + off_re), reinterpret_cast<float*>(base + off_im), B, T, L,
                h->cfg.hop, env, reinterpret_cast<float*>(base + off_frames), wav_out, s);
@@ -562,7 +590,7 @@ int vfx_vocoder(vfx_handle* h, const float* mel_linear, int B, int T, float* wav
   VFX_CHECK(h && mel_linear && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->voc, "vfx_vocoder: vocoder weights are not finalized");
   auto plan = get_plan(h, key_of("vocoder", B, T), [&](PlanBuilder& pb) { build_vocoder(pb, B, T, ext(0), ext(1)); });
-  RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), wav_out}, h->d_flags};
+  RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), wav_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
 }
@@ -601,8 +629,59 @@ int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_ou
                        reinterpret_cast<float*>(pl->bound_base + o_ws), c.ext[1], c.stream);
     });
   });
-  RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags};
+  RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
+  VFX_API_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// live kernel timing (bench.py roofline): HIP events around every tap-convolution launch, on the
+// stream the kernels are launched on.
+// ---------------------------------------------------------------------------------------------
+int vfx_profile_begin(vfx_handle* h) {
+  VFX_API_BEGIN
+  VFX_CHECK(h, "NULL handle");
+  h->prof.enabled = true;
+  h->prof.events.clear();
+  h->prof.flops.clear();
+  h->prof.bn.clear();
+  VFX_API_END
+}
+
+// Synchronises, then returns: number of launches, sum of their durations (ms) and of their
+// algorithmic FLOPs (2 * M * Cout * K).  Any out pointer may be NULL.
+int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* total_flops) {
+  VFX_API_BEGIN
+  VFX_CHECK(h, "NULL handle");
+  VFX_HIP(hipDeviceSynchronize());
+  double ms = 0, fl = 0;
+  FILE* dump = nullptr;
+  if (const char* path = getenv("VFX_PROFILE_DUMP")) dump = fopen(path, "w");
+  if (dump) fprintf(dump, "idx,M,Cout,K,nseg,ntaps0,C0,Wi,sw,ms,tflops\n");
+  for (size_t i = 0; i < h->prof.events.size(); ++i) {
+    float t = 0.f;
+    VFX_HIP(hipEventElapsedTime(&t, h->prof.events[i].first, h->prof.events[i].second));
+    if (dump) {
+      const TapConvParams& d = h->prof.desc[i];
+      int K = 0;
+      for (int s2 = 0; s2 < d.nseg; ++s2) K += d.seg[s2].ntaps * d.seg[s2].C;
+      fprintf(dump, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C, d.Wi,
+              d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12);
+    }
+    ms += t;
+    fl += h->prof.flops[i];
+    (void)hipEventDestroy(h->prof.events[i].first);
+    (void)hipEventDestroy(h->prof.events[i].second);
+  }
+  if (dump) fclose(dump);
+  h->prof.desc.clear();
+  if (launches) *launches = (int64_t)h->prof.events.size();
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  h->prof.events.clear();
+  h->prof.flops.clear();
+  h->prof.bn.clear();
+  h->prof.enabled = false;
   VFX_API_END
 }
 

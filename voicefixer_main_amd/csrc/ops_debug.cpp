@@ -13,12 +13,9 @@ void fill_seg(TapSeg& S, const float* x, int Cin, const float* scale, const floa
               DeviceBlob& blob) {
   S.src = x;
   S.C = Cin;
-  S.scale = scale ? blob.upload(scale, Cin) : nullptr;
-  S.shift = shift ? blob.upload(shift, Cin) : nullptr;
-  if (scale && !shift) {
-    std::vector<float> z(Cin, 0.f);
-    S.shift = blob.upload(z);
-  }
+  std::vector<float> one(Cin, 1.f), zero(Cin, 0.f);
+  S.scale = blob.upload(scale ? scale : one.data(), Cin);
+  S.shift = blob.upload(shift ? shift : zero.data(), Cin);
   S.act = act;
   S.slope = slope;
 }

@@ -37,13 +37,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128;
 constexpr int LDK = kKC + 4;  // padded LDS row length in floats
 
-__device__ __forceinline__ float apply_act(float v, int act, float slope) {
-  if (act == ACT_LEAKY) return v >= 0.f ? v : v * slope;
-  if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
-  return v;
-}
+// Pointers read out of the parameter block are generic to the compiler (-> flat_load, which
+// also ticks the LDS counter); every tensor here lives in global memory, so say so.
+#define VFX_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const VFX_GLOBAL f32x4*)p; }
+__device__ __forceinline__ void stg4(float* p, f32x4 v) { *(VFX_GLOBAL f32x4*)p = v; }
 
-template <int BN>
+template <int BN, bool ELU>
 __global__ __launch_bounds__(256, 2) void k_tapconv(const TapConvParams* __restrict__ pp) {
   constexpr int WAVES_N = BN >= 64 ? 2 : 1;
   constexpr int WAVES_M = 4 / WAVES_N;
@@ -59,7 +59,15 @@ __global__ __launch_bounds__(256, 2) void k_tapconv(const TapConvParams* __restr
   const TapConvParams& p = *pp;
   const int tid = threadIdx.x;
   const int n_tiles = p.Cout / BN;
-  const int tile = blockIdx.x;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only), so
+  // give every XCD a contiguous range of tiles -- neighbouring tiles share halo rows and the
+  // N-tiles of one M-tile share the whole activation tile through that XCD's L2.
+  int tile;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
   const int m0 = (tile / n_tiles) * BM;
   const int n0 = (tile % n_tiles) * BN;
 
@@ -109,64 +117,85 @@ __global__ __launch_bounds__(256, 2) void k_tapconv(const TapConvParams* __restr
   const int l31 = lane & 31, lh = lane >> 5;
 
   // ---- K-loop state (uniform) ------------------------------------------------------------------
-  int s_seg = 0, s_chunk = 0, s_tap = 0;
-  f32x4 ra[4], rb[BP], rsc, rsh;
-  unsigned okmask = 0;
-  int cur_act = 0;
-  float cur_slope = 0.f;
+  // Two register stages: the loads of step s+2 are issued while step s is computed, so every
+  // global load has two full K steps (plus the co-resident block's) to land.
+  struct Stage {
+    f32x4 ra[4];
+    f32x4 rb[BP];
+    f32x4 sc, sh;
+    unsigned ok;
+    float slope;
+  };
+  Stage st0, st1;
+  int s_seg = 0, s_chunk = 0, s_tap = 0;  // next step to ISSUE
 
-  auto issue_loads = [&](int sg, int ch, int tp) {
-    const TapSeg& S = p.seg[sg];
+  // Branch-free by construction (fixed number of loads per call) so that the compiler can keep
+  // counted s_waitcnt vmcnt(N) waits across the loop back-edge: out-of-range rows read pixel 0
+  // and are zeroed when staged; scale/shift are always loaded (identity tables when the segment
+  // has no affine prologue); past the last K step the last step is re-read with ok = 0, which
+  // stages an all-zero A tile.
+  int steps_left = p.total_steps;
+  auto issue_loads = [&](Stage& R) {
+    const TapSeg& S = p.seg[s_seg];
     const int C = S.C;
-    const int dh = S.dh[tp], dw = S.dw[tp];
-    const int c0 = ch * kKC + 4 * cg;
-    okmask = 0;
+    const int dh = S.dh[s_tap], dw = S.dw[s_tap];
+    const int c0 = s_chunk * kKC + 4 * cg;
+    const unsigned live = steps_left > 0 ? ~0u : 0u;
+    unsigned ok_bits = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      int ii = a_i[q] + dh, jj = a_j[q] + dw;
-      if (p.reflect_w) {
-        jj = jj < 0 ? -jj : jj;
-        jj = jj >= Wi ? 2 * (Wi - 1) - jj : jj;
-      }
-      const bool ok = (a_b[q] >= 0) && (ii >= 0) && (ii < Hi) && (jj >= 0) && (jj < Wi);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const int64_t pix = (int64_t)(a_b[q] * Hi + ii) * Wi + jj;
-        v = *reinterpret_cast<const f32x4*>(S.src + pix * C + c0);
-        okmask |= 1u << q;
-      }
-      ra[q] = v;
+      const int ii = a_i[q] + dh;
+      int jj = a_j[q] + dw;
+      int rj = jj < 0 ? -jj : jj;
+      rj = rj >= Wi ? 2 * (Wi - 1) - rj : rj;
+      jj = p.reflect_w ? rj : jj;
+      const bool ok = (a_b[q] >= 0) & ((unsigned)ii < (unsigned)Hi) & ((unsigned)jj < (unsigned)Wi);
+      const int pix = ok ? (a_b[q] * Hi + ii) * Wi + jj : 0;
+      R.ra[q] = ldg4(S.src + (int64_t)pix * C + c0);
+      ok_bits |= ok ? (1u << q) : 0u;
     }
-    const float* wb = S.wt + ((int64_t)(ch * S.ntaps + tp) * p.Cout + n0) * kKC;
+    R.ok = ok_bits & live;
+    const float* wb = S.wt + ((int64_t)(s_chunk * S.ntaps + s_tap) * p.Cout + n0) * kKC;
 #pragma unroll
-    for (int q = 0; q < BP; ++q)
-      rb[q] = *reinterpret_cast<const f32x4*>(wb + (lr + 32 * q) * kKC + 4 * cg);
-    if (S.scale) {
-      rsc = *reinterpret_cast<const f32x4*>(S.scale + c0);
-      rsh = *reinterpret_cast<const f32x4*>(S.shift + c0);
-    } else {
-      rsc = f32x4{1.f, 1.f, 1.f, 1.f};
-      rsh = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < BP; ++q) R.rb[q] = ldg4(wb + (lr + 32 * q) * kKC + 4 * cg);
+    R.sc = ldg4(S.scale + c0);
+    R.sh = ldg4(S.shift + c0);
+    R.slope = S.act == ACT_NONE ? 1.f : S.slope;  // identity == leaky with slope 1
+    // advance (seg, chunk, tap), saturating at the last step: tap innermost so that consecutive
+    // steps re-touch the same activation lines (shifted by one pixel) while they are in L1/L2.
+    --steps_left;
+    if (steps_left > 0) {
+      ++s_tap;
+      if (s_tap == S.ntaps) {
+        s_tap = 0;
+        ++s_chunk;
+        if (s_chunk * kKC == C) {
+          s_chunk = 0;
+          ++s_seg;
+        }
+      }
     }
-    cur_act = S.act;
-    cur_slope = S.slope;
   };
 
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int buf, const Stage& R) {
     float* Ab = As + buf * BM * LDK;
     float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 v = ra[q];
-      if (okmask & (1u << q)) {
+      f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * rsc[e] + rsh[e], cur_act, cur_slope);
+      for (int e = 0; e < 4; ++e) {
+        const float t = R.ra[q][e] * R.sc[e] + R.sh[e];
+        float u;
+        if constexpr (ELU) u = t > 0.f ? t : expm1f(t);  // only the vocoder's condnet instantiates this
+        else u = t >= 0.f ? t : t * R.slope;
+        v[e] = (R.ok & (1u << q)) ? u : 0.f;
       }
       *reinterpret_cast<f32x4*>(Ab + (lr + 32 * q) * LDK + 4 * cg) = v;
     }
 #pragma unroll
     for (int q = 0; q < BP; ++q)
-      *reinterpret_cast<f32x4*>(Bb + (lr + 32 * q) * LDK + 4 * cg) = rb[q];
+      *reinterpret_cast<f32x4*>(Bb + (lr + 32 * q) * LDK + 4 * cg) = R.rb[q];
   };
 
   auto compute = [&](int buf) {
@@ -189,49 +218,62 @@ __global__ __launch_bounds__(256, 2) void k_tapconv(const TapConvParams* __restr
     }
   };
 
-  // ---- main loop -------------------------------------------------------------------------------
-  const int total = p.total_steps;
-  issue_loads(0, 0, 0);
-  for (int step = 0; step < total; ++step) {
-    const int buf = step & 1;
-    store_lds(buf);
+  // ---- main loop (unrolled by two so that the register stages are statically named) ----------
+  const int n_iter = (p.total_steps + 1) >> 1;
+  issue_loads(st0);
+  issue_loads(st1);
+  for (int it = 0; it < n_iter; ++it) {
+    store_lds(0, st0);
     __syncthreads();
-    // advance (seg, chunk, tap): tap innermost so that consecutive steps re-touch the same
-    // activation lines (shifted by one pixel) while they are still in L1/L2.
-    ++s_tap;
-    if (s_tap == p.seg[s_seg].ntaps) {
-      s_tap = 0;
-      ++s_chunk;
-      if (s_chunk * kKC == p.seg[s_seg].C) {
-        s_chunk = 0;
-        ++s_seg;
-      }
-    }
-    if (step + 1 < total) issue_loads(s_seg, s_chunk, s_tap);
-    compute(buf);
+    issue_loads(st0);
+    compute(0);
+    store_lds(1, st1);
+    __syncthreads();
+    issue_loads(st1);
+    compute(1);
   }
 
-  // ---- epilogue: bias + residual, channels-last store ---------------------------------------------
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // The accumulator fragments go through LDS (re-using the staging buffers) so that the
+  // residual read and the output write are 16-byte-per-lane, row-contiguous accesses and all
+  // residual loads of a thread are in flight together.
   // C/D layout of the 32x32 MFMA: col = lane & 31 (-> cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  const int Cout = p.Cout;
+  constexpr int LDO = BN + 4;  // staged row length (floats), keeps 16-byte alignment
+  __syncthreads();             // every wave is done reading the last K step
+  float* stage = smem;         // [BM][LDO] <= the A/B buffers
 #pragma unroll
-  for (int b = 0; b < WN; ++b) {
-    const int n = n0 + (wn * WN + b) * 32 + l31;
-    const float bv = p.bias ? p.bias[n] : 0.f;
+  for (int a = 0; a < WM; ++a)
 #pragma unroll
-    for (int a = 0; a < WM; ++a) {
+    for (int b = 0; b < WN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int opix = otab[row];
-        if (opix >= 0) {
-          const int64_t o = (int64_t)opix * Cout + n;
-          float v = acc[a][b][r] + bv;
-          if (p.residual) v += p.residual[o];
-          p.out[o] = v;
-        }
+        stage[row * LDO + (wn * WN + b) * 32 + l31] = acc[a][b][r];
       }
-    }
+  __syncthreads();
+  constexpr int V = BN / 4;         // float4 per output row
+  constexpr int RPP = 256 / V;      // rows per pass
+  constexpr int NPASS = BM / RPP;   // = BN / 8
+  const int c4 = tid % V, r0 = tid / V;
+  const int Cout = p.Cout;
+  const int ncol = n0 + 4 * c4;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bv = ldg4(p.bias + ncol);
+  int opix[NPASS];
+#pragma unroll
+  for (int q = 0; q < NPASS; ++q) opix[q] = otab[r0 + q * RPP];
+  f32x4 res[NPASS];
+  if (p.residual) {
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) res[q] = ldg4(p.residual + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * Cout + ncol);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) res[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int q = 0; q < NPASS; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (r0 + q * RPP) * LDO + 4 * c4) + bv + res[q];
+    if (opix[q] >= 0) stg4(p.out + (int64_t)opix[q] * Cout + ncol, v);
   }
 }
 
@@ -243,27 +285,44 @@ static int pick_bn(int Cout) {
   return 32;
 }
 
+template <int BN, bool ELU>
+static void launch_one(int grid, size_t lds, hipStream_t stream, const TapConvParams* dparams) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tapconv<BN, ELU>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_tapconv<BN, ELU>), dim3(grid), dim3(256), lds, stream, dparams);
+}
+
 void launch_tapconv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream) {
   VFX_CHECK(hp.Cout % 32 == 0, "tapconv: Cout=%d is not a multiple of 32", hp.Cout);
-  for (int s = 0; s < hp.nseg; ++s)
+  bool elu = false;
+  for (int s = 0; s < hp.nseg; ++s) {
     VFX_CHECK(hp.seg[s].C % kKC == 0, "tapconv: segment %d has C=%d, not a multiple of %d", s, hp.seg[s].C, kKC);
+    elu = elu || hp.seg[s].act == ACT_ELU;
+  }
+  if (elu)
+    for (int s = 0; s < hp.nseg; ++s)
+      VFX_CHECK(hp.seg[s].act == ACT_ELU, "tapconv: ELU cannot be mixed with other prologues in one launch");
   VFX_CHECK(hp.M > 0 && hp.total_steps > 0, "tapconv: empty problem");
   const int BN = pick_bn(hp.Cout);
   const int m_tiles = (hp.M + BM - 1) / BM;
   const int grid = m_tiles * (hp.Cout / BN);
   const size_t lds = tapconv_lds_bytes(BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tapconv<128>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapconv_lds_bytes(128)));
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tapconv<64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)tapconv_lds_bytes(64)));
-    attr_set = true;
-  }
-  switch (BN) {
-    case 128: hipLaunchKernelGGL(k_tapconv<128>, dim3(grid), dim3(256), lds, stream, dparams); break;
-    case 64: hipLaunchKernelGGL(k_tapconv<64>, dim3(grid), dim3(256), lds, stream, dparams); break;
-    default: hipLaunchKernelGGL(k_tapconv<32>, dim3(grid), dim3(256), lds, stream, dparams); break;
+  if (elu) {
+    switch (BN) {
+      case 128: launch_one<128, true>(grid, lds, stream, dparams); break;
+      case 64: launch_one<64, true>(grid, lds, stream, dparams); break;
+      default: launch_one<32, true>(grid, lds, stream, dparams); break;
+    }
+  } else {
+    switch (BN) {
+      case 128: launch_one<128, false>(grid, lds, stream, dparams); break;
+      case 64: launch_one<64, false>(grid, lds, stream, dparams); break;
+      default: launch_one<32, false>(grid, lds, stream, dparams); break;
+    }
   }
   VFX_HIP(hipGetLastError());
 }

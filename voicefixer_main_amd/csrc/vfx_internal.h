@@ -45,6 +45,7 @@ struct Error {};  // thrown after set_error(); caught at the C boundary
 constexpr int kMaxTaps = 9;
 constexpr int kMaxSegs = 3;
 constexpr int kKC = 32;  // input channels per K step
+constexpr int kIdentityLen = 4096;  // length of the identity scale/shift tables
 
 enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_ELU = 2 };
 
@@ -149,10 +150,19 @@ struct ArenaPlanner {
 
 // A buffer is either a slice of the arena (resolved when the plan is bound to an arena base)
 // or one of the caller's tensors (resolved per call).
+struct ConvProfile {  // HIP-event timing of every tap-convolution launch (vfx_profile_*)
+  bool enabled = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<double> flops;
+  std::vector<int> bn;
+  std::vector<TapConvParams> desc;
+};
+
 struct RunCtx {
   hipStream_t stream;
   float* ext[8];
   int* flags;
+  ConvProfile* prof = nullptr;
 };
 
 struct Plan {
@@ -250,6 +260,9 @@ struct vfx_handle {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   int* d_flags = nullptr;
+  float* d_ones = nullptr;   // identity prologue tables (kIdentityLen floats)
+  float* d_zeros = nullptr;
+  vfx::ConvProfile prof;
 };
 
 namespace vfx {

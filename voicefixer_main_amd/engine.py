@@ -183,6 +183,15 @@ class Engine:
                                             self._stream()), "vfx_restore_gsr")
         return (out, logmel) if want_logmel else out
 
+    def profile_begin(self):
+        _lib.check(self.lib.vfx_profile_begin(self.h), "vfx_profile_begin")
+
+    def profile_end(self):
+        """-> (launches, total_ms, total_flops) of the tap-convolution launches since profile_begin."""
+        n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        _lib.check(self.lib.vfx_profile_end(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "vfx_profile_end")
+        return n.value, ms.value, fl.value
+
     # ------------------------------------------------------------------ kernel-level ops (tests)
     def op_conv(self, x, weight, scale=None, shift=None, act=0, slope=0.0, bias=None, residual=None, dil_w=1,
                 reflect_w=False):
