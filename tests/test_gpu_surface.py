@@ -1,0 +1,114 @@
+"""GPU: the reference-surface mirror (models / handlers) and HIP-vs-REFERENCE golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def voicefixer(engine, unet_sd, voc_sd):
+    from voicefixer_main_amd.models import VoiceFixer
+    m = VoiceFixer(None, channels=2, type_target="vocals", engine=engine)
+    sd = {"generator.analysis_module." + k: v for k, v in unet_sd.items()}
+    sd.update({"vocoder.model." + k: v for k, v in voc_sd.items()})
+    m.load_state_dict(sd)
+    return m.eval().to(torch.device("cuda:0"))
+
+
+def test_hip_resunet_vs_reference_golden(engine):
+    """HIP Generator.forward against the output of the REFERENCE's own module (tests/golden/unet_mel.npz)."""
+    g = np.load(os.path.join(G, "unet_mel.npz"))
+    got = engine.resunet_mel(torch.from_numpy(g["mel_in"][:, 0])).cpu().numpy()
+    d = np.abs(got - g["logmel_out"][:, 0])
+    assert d.mean() < 1e-4 and d.max() < 2e-3, (d.mean(), d.max())       # north_star: log-mel L1 <= 1e-3
+
+
+def test_hip_mel_filterbank_vs_reference_golden(voicefixer):
+    g = np.load(os.path.join(G, "mel_fb.npz"))
+    fb = np.zeros((1025, 128), np.float32)
+    fb[g["rows"], g["cols"]] = g["vals"]
+    sp = np.abs(np.random.default_rng(1).normal(size=(1, 1, 5, 1025))).astype(np.float32)
+    got = voicefixer.mel(torch.from_numpy(sp).cuda().permute(0, 1, 3, 2)).permute(0, 1, 3, 2).cpu().numpy()
+    assert np.abs(got - sp.astype(np.float64) @ fb.astype(np.float64)).max() < 2e-5 * got.max()
+
+
+def test_voicefixer_surface_matches_oracle(voicefixer, unet_sd, voc_sd):
+    from oracle import dsp, resunet
+    from oracle import vocoder as ovoc
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.models import from_log
+    wav = synth.make_clips(1, 0.7, seed=5)
+    x = torch.from_numpy(wav).cuda()
+    sp, cos, sin = voicefixer.f_helper.wav_to_spectrogram_phase(x)
+    assert sp.shape == cos.shape == sin.shape == (1, 1, wav.shape[-1] // 441 + 1, 1025)
+    sp2, mel = voicefixer.pre(x)
+    ref_sp, ref_mel = dsp.wav_to_mel(wav.astype(np.float64))
+    assert np.abs(mel.cpu().numpy() - ref_mel).max() < 1e-5 * ref_mel.max()
+    out = voicefixer(mel)["mel"]
+    ref_log = resunet.generator_mel(unet_sd, torch.from_numpy(ref_mel.astype(np.float32))).numpy()
+    assert np.abs(out.cpu().numpy() - ref_log).mean() < 1e-4
+    wave = voicefixer.vocoder(from_log(out))
+    ref_wave = ovoc.vocoder(voc_sd, torch.from_numpy(dsp.from_log(ref_log))).numpy()
+    assert wave.shape == ref_wave.shape
+    assert np.abs(wave.cpu().numpy() - ref_wave).max() < 1e-3
+    # fused front-end == unfused
+    fused = voicefixer.f_helper.wav_to_mel(x)
+    assert np.abs(fused.cpu().numpy() - mel.cpu().numpy()).max() < 1e-6 * ref_mel.max()
+    bad = mel.clone()
+    bad[0, 0, 0, 0] = -1.0
+    with pytest.raises(AssertionError):
+        voicefixer(bad)
+
+
+def test_ssr_unet_vs_reference_golden_and_oracle(engine):
+    """Spectrogram ResUNet + phase recombination + ISTFT (unet_v2.py:86-148)."""
+    from oracle import pipeline
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.models import SSR_UNet
+    g = np.load(os.path.join(G, "unet_spec.npz"))
+    sd = synth.make_resunet_state_dict(2)
+    m = SSR_UNet(None, channels=1, engine=engine)
+    m.load_state_dict({"generator.unet." + k: v for k, v in sd.items()})
+    wav = torch.from_numpy(g["wav_in"]).cuda()
+    sp, _ = m.pre(wav)
+    out = m(sp, wav)
+    assert out["wav"].shape == wav.shape and out["clean"] is sp
+    got = out["wav"].cpu().numpy()
+    scale = max(1.0, np.abs(g["wav_out"]).max())
+    assert np.abs(got - g["wav_out"]).max() < 2e-4 * scale                    # vs the reference trunk
+    ref = pipeline.restore_ssr(sd, g["wav_in"])
+    err = got - ref["wav"]
+    sisdr = 10 * np.log10((ref["wav"] ** 2).sum() / ((err ** 2).sum() + 1e-30))
+    assert sisdr > 70.0, sisdr
+
+
+def test_handler_end_to_end(voicefixer, unet_sd, voc_sd, tmp_path):
+    from oracle import pipeline
+    from voicefixer_main_amd import handlers, synth
+    wav = synth.make_clips(1, 1.3, seed=21)
+    src, dst = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    handlers.save_wave(wav[0, 0], src)
+    handlers._state["model"] = voicefixer
+    metrics = handlers.handler(src, dst, src, ckpt=None, device=torch.device("cuda:0"), needrefresh=False,
+                               meta={"unify_energy": False})
+    assert set(metrics) == {"mel-lsd", "mel-sispec", "mel-non-log-sispec"}
+    out = handlers.load_wav(dst)
+    x = handlers.load_wav(src)
+    assert out.shape == x.shape
+    ref = pipeline.restore_gsr(unet_sd, voc_sd, x[None, None])["wav"][0, 0]
+    assert np.abs(out - ref).max() < 1e-3 + 2.0 / 32768
+
+
+def test_unify_energy_path(engine, unet_sd, voc_sd):
+    from oracle import pipeline
+    from voicefixer_main_amd import synth
+    wav = synth.make_clips(2, 0.6, seed=31, mode="lowpass")
+    ref = pipeline.restore_gsr(unet_sd, voc_sd, wav, unify_energy=True)
+    out = engine.restore_gsr(torch.from_numpy(wav[:, 0]), unify_energy=True).cpu().numpy()
+    err = out - ref["wav"][:, 0]
+    sisdr = 10 * np.log10((ref["wav"] ** 2).sum() / ((err ** 2).sum() + 1e-30))
+    assert sisdr > 50.0, sisdr

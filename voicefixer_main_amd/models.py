@@ -1,0 +1,312 @@
+"""Host-side mirror of the reference's model objects for the inference hot path.
+
+Same names, argument meaning and error behaviour as the reference surface that
+``handler()`` uses, backed by libvfx.so instead of torch.nn:
+
+    model = VoiceFixer(hp, channels=2, type_target="vocals").load_from_checkpoint(ckpt)
+    model.eval(); model = model.to(device)
+    sp, cos, sin = model.f_helper.wav_to_spectrogram_phase(wav)      # fDomainHelper.py:67-89
+    mel = model.mel(sp.permute(0,1,3,2)).permute(0,1,3,2)            # mel_scale.py:52-64
+    out = model(mel)['mel']                                          # gsr_voicefixer.py:183-193
+    wav = model.vocoder(from_log(out))                               # eval_gsr_voicefixer.py:66
+
+and for the waveform-out ResUNets (models/ssr_unet.py:145-155, models/gsr_unet.py):
+
+    out = model(sp, wav)   ->  {'wav': (B,1,L), 'clean': sp}
+
+Tensors are torch tensors on the ROCm device; the batch dimension may be > 1 (the
+reference only ever passes 1).  There is no CPU path: constructing a model on a
+non-GPU device raises.
+"""
+import math
+import pickle
+
+import numpy as np
+import torch
+
+from .engine import Engine, MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER
+
+EPS = 1e-8
+
+
+# ----------------------------------------------------------------------------------------
+# tools/pytorch/pytorch_util.py:157-163 (elementwise glue, kept in torch on the device)
+# ----------------------------------------------------------------------------------------
+def to_log(input):
+    assert torch.sum(input < 0) == 0, str(input) + " has negative values counts " + str(torch.sum(input < 0))
+    return torch.log10(torch.clip(input, min=1e-8))
+
+
+def from_log(input):
+    return 10 ** torch.clip(input, max=5)
+
+
+def tensor2numpy(tensor):
+    return tensor.detach().cpu().numpy()
+
+
+def _hp_get(hp, *keys, default=None):
+    cur = hp
+    for k in keys:
+        try:
+            cur = cur[k]
+        except Exception:
+            cur = getattr(cur, k, None)
+        if cur is None:
+            return default
+    return cur
+
+
+class MelScale:
+    """tools/pytorch/mel_scale.py:10-64 -- HTK triangular filterbank applied to (..., freq, time)."""
+
+    def __init__(self, engine, n_mels=128, sample_rate=44100, f_min=0.0, f_max=None, n_stft=1025, norm=None,
+                 mel_scale="htk"):
+        if n_mels != 128 or n_stft != 1025 or norm is not None or mel_scale != "htk" or f_min != 0.0:
+            raise ValueError("libvfx implements the reference configuration only (128 HTK bands over 1025 bins)")
+        self.engine = engine
+        self.n_mels, self.sample_rate = n_mels, sample_rate
+        self.f_max = f_max if f_max is not None else float(sample_rate // 2)
+        self.fb = self.filterbank(n_stft, n_mels, sample_rate, self.f_max)
+        engine.set_mel_filterbank(self.fb)
+
+    @staticmethod
+    def filterbank(n_freqs, n_mels, sample_rate, f_max):
+        """float32 torch-CPU evaluation of the HTK filterbank with the reference's operation
+        order (mel_scale.py:131-221), so the table is bit-identical to the reference buffer."""
+        hz = torch.linspace(0, sample_rate // 2, n_freqs)
+        to_mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+        edges_mel = torch.linspace(to_mel(0.0), to_mel(f_max), n_mels + 2)
+        edges = 700.0 * (10.0 ** (edges_mel / 2595.0) - 1.0)
+        span = edges[1:] - edges[:-1]
+        delta = edges.unsqueeze(0) - hz.unsqueeze(1)
+        lower = (-1.0 * delta[:, :-2]) / span[:-1]
+        upper = delta[:, 2:] / span[1:]
+        return torch.max(torch.zeros(1), torch.min(lower, upper))
+
+    def __call__(self, specgram):
+        x = specgram.transpose(-1, -2).contiguous()           # (..., time, freq)
+        return self.engine.mel_project(x).transpose(-1, -2)   # (..., n_mels, time)
+
+    forward = __call__
+
+
+class FDomainHelper:
+    """tools/pytorch/modules/fDomainHelper.py:11-113 for subband=None (the only configuration any
+    call site uses, fDomainHelper.py:20,25)."""
+
+    def __init__(self, engine, window_size=2048, hop_size=441, center=True, pad_mode="reflect", window="hann",
+                 freeze_parameters=True, subband=None):
+        if subband is not None:
+            raise NotImplementedError("PQMF sub-band analysis is outside the hot path (its filter files are not in the reference)")
+        if (window_size, hop_size, pad_mode, window) != (2048, 441, "reflect", "hann") or not center:
+            raise ValueError("libvfx implements the reference STFT configuration only (2048/441/hann/reflect/center)")
+        self.engine = engine
+
+    def _flat(self, input):
+        B, C, L = input.shape
+        return input.reshape(B * C, L), (B, C)
+
+    def spectrogram_phase(self, input, eps=0.0):
+        """(B, L) -> mag, cos, sin (B, 1, T, 1025); the power is clamped at 1e-8 (the only eps call sites use)."""
+        o = self.engine.stft(input, want_mel=False, want_sp=True, want_phase=True)
+        return o["sp"][:, None], o["cos"][:, None], o["sin"][:, None]
+
+    def wav_to_spectrogram_phase(self, input, eps=1e-8):
+        x, (B, C) = self._flat(input)
+        o = self.engine.stft(x, want_mel=False, want_sp=True, want_phase=True)
+        shp = (B, C) + tuple(o["sp"].shape[1:])
+        return o["sp"].reshape(shp), o["cos"].reshape(shp), o["sin"].reshape(shp)
+
+    def wav_to_spectrogram(self, input, eps=1e-8):
+        x, (B, C) = self._flat(input)
+        sp = self.engine.stft(x, want_mel=False, want_sp=True)["sp"]
+        return sp.reshape((B, C) + tuple(sp.shape[1:]))
+
+    def wav_to_mel(self, input, log10=False):
+        """Fused front-end (no (B,C,T,1025) round trip through HBM): (B,C,L) -> (B,C,T,128)."""
+        x, (B, C) = self._flat(input)
+        mel = self.engine.stft(x, want_mel=True, log10_mel=log10)["mel"]
+        return mel.reshape((B, C) + tuple(mel.shape[1:]))
+
+    def istft(self, real, imag, length):
+        """(B,1,T,1025) x2 -> (B, length)   [torchlibrosa ISTFT via fDomainHelper.py:30-32]."""
+        return self.engine.istft(real[:, 0], imag[:, 0], length)
+
+    def spectrogram_phase_to_wav(self, sps, coss, sins, length):
+        B, C = sps.shape[:2]
+        flat = lambda t: t.reshape((B * C,) + tuple(t.shape[2:]))
+        return self.engine.istft(flat(sps * coss), flat(sps * sins), length).reshape(B, C, length)
+
+
+class Vocoder:
+    """`voicefixer.Vocoder(sample_rate=44100)`: linear mel (B,1,T,128) -> wave (B,1,(T+T%2+4)*441)."""
+
+    def __init__(self, engine, sample_rate=44100):
+        assert sample_rate == 44100
+        self.engine = engine
+        self.rate = sample_rate
+
+    def load_state_dict(self, sd, prefix=""):
+        self.engine.load_state_dict(MODEL_VOCODER, fold_weight_norm(sd), prefix)
+
+    def __call__(self, mel, cuda=None):
+        assert mel.size()[-1] == 128
+        return self.engine.vocoder(mel[:, 0])[:, None]
+
+    forward = __call__
+
+
+def fold_weight_norm(sd):
+    """Replace (weight_g, weight_v) pairs by the plain weight g * v / ||v|| (norm over dims != 0)."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("weight_g"):
+            base = k[:-len("weight_g")]
+            vv = sd[base + "weight_v"].float()
+            norm = vv.reshape(vv.shape[0], -1).norm(dim=1).reshape((-1,) + (1,) * (vv.dim() - 1))
+            out[base + "weight"] = v.float() * vv / norm
+        elif k.endswith("weight_v"):
+            continue
+        else:
+            out[k] = v
+    return out
+
+
+class _Unpickler(pickle.Unpickler):
+    """Lightning checkpoints pickle `hyper_parameters` with project classes; stub what is absent."""
+
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except Exception:
+            return type(name, (dict,), {"__setstate__": lambda self, s: self.update(s if isinstance(s, dict) else {})})
+
+
+class _PickleModule:
+    Unpickler = _Unpickler
+    load = staticmethod(lambda f, **kw: _Unpickler(f, **kw).load())
+    __name__ = "pickle"
+
+
+def read_checkpoint(path):
+    """Lightning .ckpt (or a bare state_dict file) -> state_dict of CPU tensors."""
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
+    return obj["state_dict"] if isinstance(obj, dict) and "state_dict" in obj else obj
+
+
+class _Base:
+    def __init__(self, hp=None, channels=1, type_target="vocals", device="cuda:0", engine=None):
+        self.hp = hp
+        self.channels = channels
+        self.type_target = type_target
+        self.engine = engine if engine is not None else Engine(device)
+        self.device = self.engine.device
+        self.sampling_rate = _hp_get(hp, "data", "sampling_rate", default=44100)
+        self.f_helper = FDomainHelper(
+            self.engine,
+            window_size=_hp_get(hp, "model", "window_size", default=2048),
+            hop_size=_hp_get(hp, "model", "hop_size", default=441),
+            center=True,
+            pad_mode=_hp_get(hp, "model", "pad_mode", default="reflect"),
+            window=_hp_get(hp, "model", "window", default="hann"))
+        self.mel = MelScale(self.engine, n_mels=_hp_get(hp, "model", "mel_freq_bins", default=128),
+                            sample_rate=self.sampling_rate,
+                            n_stft=_hp_get(hp, "model", "window_size", default=2048) // 2 + 1)
+        self.vocoder = Vocoder(self.engine, sample_rate=44100)
+        self.training = False
+
+    # nn.Module-ish surface the handlers touch
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("this model only runs on the MI355X (requested %s)" % device)
+        return self
+
+    def get_vocoder(self):
+        return self.vocoder
+
+    def get_f_helper(self):
+        return self.f_helper
+
+    def pre(self, input):
+        sp, _, _ = self.f_helper.wav_to_spectrogram_phase(input)
+        mel_orig = self.mel(sp.permute(0, 1, 3, 2)).permute(0, 1, 3, 2)
+        return sp, mel_orig
+
+    def load_from_checkpoint(self, ckpt):
+        self.load_state_dict(read_checkpoint(ckpt))
+        return self
+
+
+class VoiceFixer(_Base):
+    """models/gsr_voicefixer.py:93-193 (inference surface): mel ResUNet + TFGAN vocoder."""
+
+    unet_prefix = "generator.analysis_module."
+
+    def load_state_dict(self, sd, strict=True):
+        keys = list(sd.keys())
+        if any(k.startswith(self.unet_prefix) for k in keys):
+            self.engine.load_state_dict(MODEL_UNET_MEL, sd, self.unet_prefix)
+        elif any(k.startswith("encoder_block1.") for k in keys):
+            self.engine.load_state_dict(MODEL_UNET_MEL, sd)
+        elif strict:
+            raise KeyError("no ResUNet weights ('%s*') in the state_dict" % self.unet_prefix)
+        for pfx in ("vocoder.model.", "vocoder."):
+            sub = {k[len(pfx):]: v for k, v in sd.items() if k.startswith(pfx)}
+            if any(k.startswith("condnet.") for k in sub):
+                self.vocoder.load_state_dict(sub)
+                break
+        if "mel.fb" in sd:
+            self.engine.set_mel_filterbank(sd["mel.fb"])
+        return self
+
+    def forward(self, mel_orig, check=True):
+        """mel_orig (B,1,T,128) linear, non-negative -> {'mel': log10 estimate}  (Generator.forward,
+        gsr_voicefixer.py:86-91).  `check` reproduces to_log's assert (one device sync)."""
+        out = self.engine.resunet_mel(mel_orig[:, 0])[:, None]
+        if check and (self.engine.take_flags() & 1):
+            raise AssertionError("to_log: input has negative values")
+        return {"mel": out}
+
+    __call__ = forward
+
+    def restore(self, wav, unify_energy=False):
+        """Fused handler() segment body: wav (B,1,L) or (B,L) -> restored wav of the same shape."""
+        squeeze = wav.dim() == 3
+        out = self.engine.restore_gsr(wav[:, 0] if squeeze else wav, unify_energy=unify_energy)
+        return out[:, None] if squeeze else out
+
+
+class SSR_UNet(_Base):
+    """models/ssr_unet.py:56-155 / models/gsr_unet.py (identical inference surface): the
+    spectrogram-domain ResUNet of models/components/unet_v2.py."""
+
+    unet_prefix = "generator.unet."
+
+    def load_state_dict(self, sd, strict=True):
+        keys = list(sd.keys())
+        if any(k.startswith(self.unet_prefix) for k in keys):
+            sub = {k: v for k, v in sd.items() if ".f_helper." not in k}
+            self.engine.load_state_dict(MODEL_UNET_SPEC, sub, self.unet_prefix)
+        elif any(k.startswith("encoder_block1.") for k in keys):
+            self.engine.load_state_dict(MODEL_UNET_SPEC, {k: v for k, v in sd.items() if not k.startswith("f_helper.")})
+        elif strict:
+            raise KeyError("no ResUNet weights ('%s*') in the state_dict" % self.unet_prefix)
+        return self
+
+    def forward(self, sp, wav):
+        """sp (B,1,T,1025) magnitude, wav (B,1,L) -> {'wav': (B,1,L), 'clean': sp}."""
+        out = self.engine.resunet_spec(sp[:, 0], wav[:, 0])
+        return {"wav": out[:, None], "clean": sp}
+
+    __call__ = forward
+
+
+GSR_UNet = SSR_UNet
