@@ -37,27 +37,37 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=16, help="clips per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0, help="clip length")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=2.0, help="length of the CPU-oracle sample clip (0 = skip)")
+    ap.add_argument("--cpu-baseline-clips", type=int, default=2, help="clips in the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(clips, sample_seconds):
-    """Time the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
+def cpu_baseline(clips, n_clips, threads):
+    """Time the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only).
+
+    The oracle's torch-CPU convolutions stop scaling (and then collapse) beyond a few dozen
+    threads at these sizes (measured on the 2 x EPYC 9575F host: 1-s clip 0.23 / 0.18 / 0.25 /
+    0.66 s at 8 / 16 / 32 / 64 threads, minutes at 256), so the baseline uses a fixed, stated
+    thread count instead of every hardware thread.
+    """
     from oracle import pipeline
     from voicefixer_main_amd import synth
-    n = int(round(sample_seconds * 44100))
-    wav = clips[:1, :, :n]
+    wav = clips[:n_clips]
     unet_sd = synth.make_resunet_state_dict(0)
     voc_sd = synth.make_vocoder_state_dict(1)
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    pipeline.restore_gsr(unet_sd, voc_sd, wav[:1, :, :44100])          # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
     pipeline.restore_gsr(unet_sd, voc_sd, wav)
     dt = time.perf_counter() - t0
-    return {"value": round(sample_seconds / dt, 4), "unit": "audio-s/s", "cores": torch.get_num_threads(),
-            "kind": "port", "seconds": round(dt, 2),
-            "sample": "oracle.pipeline.restore_gsr (torch-CPU fp32 + numpy) on 1 clip x %.1f s of the same synthetic "
-                      "clips, same seeded weights, one run" % sample_seconds}
+    seconds = wav.shape[0] * wav.shape[-1] / 44100.0
+    return {"value": round(seconds / dt, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "seconds": round(dt, 2), "host_cpus": os.cpu_count(),
+            "sample": "oracle.pipeline.restore_gsr (torch-CPU fp32 + numpy port of the reference algorithm) on "
+                      "%d clip(s) x %.0f s of the same synthetic clips as one batch, same seeded weights, after a "
+                      "1-s warm-up" % (wav.shape[0], wav.shape[-1] / 44100.0)}
 
 
 def main():
@@ -147,9 +157,9 @@ def main():
         }
         if roofline:
             res["roofline"] = roofline
-        if world == 1 and args.cpu_baseline_seconds > 0:
+        if world == 1 and args.cpu_baseline_clips > 0:
             try:
-                res["cpu_baseline"] = cpu_baseline(clips, args.cpu_baseline_seconds)
+                res["cpu_baseline"] = cpu_baseline(clips, args.cpu_baseline_clips, args.cpu_threads)
             except Exception as e:
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))
