@@ -57,6 +57,12 @@ typedef struct vfx_config {
   float voc_norm_range;               /* 4 */
   float voc_up_slope;                 /* 0.2 */
   float voc_res_slope;                /* 0.01 */
+  /* arithmetic of the GEMM-shaped layers:
+   * 1 (default) = split-bf16: every operand is hi + lo (two bf16), products hi*hi + hi*lo +
+   *     lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-16 relative operand
+   *     error; log-mel L1 vs the fp64 oracle 4e-5..8e-5, bar 1e-3);
+   * 0 = exact fp32 (v_mfma_f32_32x32x2_f32), log-mel L1 5e-6..1e-5, ~1.8x slower. */
+  int precision;
 } vfx_config;
 
 /* Fill *cfg with the reference's hyper-parameters. */

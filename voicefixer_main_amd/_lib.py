@@ -24,6 +24,7 @@ class VfxConfig(ctypes.Structure):
         ("voc_n_stages", c_int), ("voc_scales", c_int * VFX_MAX_STAGES), ("voc_depth", c_int * VFX_MAX_STAGES),
         ("voc_dilation_base", c_int), ("voc_min_db", c_float), ("voc_amp_floor", c_float),
         ("voc_norm_range", c_float), ("voc_up_slope", c_float), ("voc_res_slope", c_float),
+        ("precision", c_int),
     ]
 
 

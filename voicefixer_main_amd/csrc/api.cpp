@@ -101,8 +101,36 @@ void ArenaPlanner::free(size_t off) {
 // ---------------------------------------------------------------------------------------------
 // PyTorch Conv weight (Cout, CinTotal, KH, KW) -> [C/32][ntaps][Cout][32] for input channels
 // [c_lo, c_lo + C); taps are (kh, kw) pairs.
+static inline uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// Split-bf16 weight rows: the 32 floats of a (tap, cout) row become 32 hi bf16 followed by
+// 32 lo bf16 (same 128 bytes), w = hi + lo up to 2^-17 relative.
+void split_rows_bf16(std::vector<float>& packed) {
+  for (size_t r = 0; r + kKC <= packed.size(); r += kKC) {
+    uint16_t hi[kKC], lo[kKC];
+    for (int i = 0; i < kKC; ++i) {
+      const float v = packed[r + i];
+      hi[i] = bf16_rne(v);
+      lo[i] = bf16_rne(v - bf16_to_f32(hi[i]));
+    }
+    memcpy(reinterpret_cast<char*>(&packed[r]), hi, sizeof(hi));
+    memcpy(reinterpret_cast<char*>(&packed[r]) + sizeof(hi), lo, sizeof(lo));
+  }
+}
+
 std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int KW, int c_lo, int C,
-                             const std::vector<std::pair<int, int>>& taps) {
+                             const std::vector<std::pair<int, int>>& taps, bool split) {
   const int nt = (int)taps.size();
   std::vector<float> out((size_t)C * nt * Cout);
   for (int ch = 0; ch < C / kKC; ++ch)
@@ -113,12 +141,13 @@ std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int
           out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
               w[(((size_t)n * CinTotal + c) * KH + taps[t].first) * KW + taps[t].second];
         }
+  if (split) split_rows_bf16(out);
   return out;
 }
 
 // PyTorch ConvTranspose weight (Cin, Cout, KH, KW) -> [Cin/32][ntaps][Cout][32].
 std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,
-                                        const std::vector<std::pair<int, int>>& taps) {
+                                        const std::vector<std::pair<int, int>>& taps, bool split) {
   const int nt = (int)taps.size();
   std::vector<float> out((size_t)Cin * nt * Cout);
   for (int ch = 0; ch < Cin / kKC; ++ch)
@@ -129,6 +158,7 @@ std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int K
           out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
               w[(((size_t)c * Cout + n) * KH + taps[t].first) * KW + taps[t].second];
         }
+  if (split) split_rows_bf16(out);
   return out;
 }
 
@@ -149,6 +179,7 @@ void finish_params(TapConvParams& p) {
 // plans
 // ---------------------------------------------------------------------------------------------
 void PlanBuilder::add_conv(TapConvParams p) {
+  p.split = h->cfg.precision != 0;
   finish_params(p);
   const size_t idx = plan->host_params.size();
   plan->host_params.push_back(p);
@@ -352,6 +383,7 @@ int vfx_default_config(vfx_config* cfg) {
   cfg->voc_norm_range = 4.f;
   cfg->voc_up_slope = 0.2f;
   cfg->voc_res_slope = 0.01f;
+  cfg->precision = 1;
   return 0;
 }
 

@@ -20,7 +20,8 @@ void fill_seg(TapSeg& S, const float* x, int Cin, const float* scale, const floa
   S.slope = slope;
 }
 
-void run_one(TapConvParams& p, DeviceBlob& blob, hipStream_t s) {
+void run_one(TapConvParams& p, DeviceBlob& blob, hipStream_t s, bool split) {
+  p.split = split;
   finish_params(p);
   TapConvParams* d = static_cast<TapConvParams*>(blob.alloc(sizeof(TapConvParams)));
   VFX_HIP(hipMemcpy(d, &p, sizeof(p), hipMemcpyHostToDevice));
@@ -48,7 +49,7 @@ extern "C" int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, i
       }
     S.ntaps = (int)taps.size();
     fill_seg(S, x, Cin, scale, shift, act, slope, sc.blob);
-    S.wt = sc.blob.upload(pack_conv(weight, Cout, Cin, kh, kw, 0, Cin, taps));
+    S.wt = sc.blob.upload(pack_conv(weight, Cout, Cin, kh, kw, 0, Cin, taps, h->cfg.precision != 0));
     p.nseg = 1;
     p.B = B;
     p.Hi = p.Hg = p.Ho = H;
@@ -59,7 +60,7 @@ extern "C" int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, i
     p.bias = bias ? sc.blob.upload(bias, Cout) : nullptr;
     p.residual = residual;
     p.out = y;
-    run_one(p, sc.blob, s);
+    run_one(p, sc.blob, s, h->cfg.precision != 0);
     VFX_HIP(hipStreamSynchronize(s));
   } catch (const vfx::Error&) {
     return 1;
@@ -92,7 +93,7 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
             }
           S.ntaps = (int)taps.size();
           fill_seg(S, x, Cin, scale, shift, act, slope, sc.blob);
-          S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 3, 3, taps));
+          S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 3, 3, taps, h->cfg.precision != 0));
           p.nseg = 1;
           p.B = B;
           p.Hi = H;
@@ -107,7 +108,7 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
           p.Wg = (Wo - b + 1) / 2;
           p.bias = dbias;
           p.out = y;
-          run_one(p, sc.blob, s);
+          run_one(p, sc.blob, s, h->cfg.precision != 0);
         }
     } else {
       VFX_CHECK(kh == 1 && H == 1 && kw == 2 * stride, "vfx_op_conv_transpose: unsupported geometry");
@@ -126,7 +127,7 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
         }
         S.ntaps = (int)taps.size();
         fill_seg(S, x, Cin, scale, shift, act, slope, sc.blob);
-        S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 1, kw, taps));
+        S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 1, kw, taps, h->cfg.precision != 0));
         p.nseg = 1;
         p.B = B;
         p.Hi = p.Hg = p.Ho = 1;
@@ -138,7 +139,7 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
         p.ow0 = r;
         p.bias = dbias;
         p.out = y;
-        run_one(p, sc.blob, s);
+        run_one(p, sc.blob, s, h->cfg.precision != 0);
       }
     }
     VFX_HIP(hipStreamSynchronize(s));

@@ -61,6 +61,7 @@ void check_shape(const HostTensor& t, std::initializer_list<int64_t> shp, const 
 }
 
 ConvBlockW load_block(const Staged& st, DeviceBlob& blob, const std::string& p, int cin, int cout, int nsrc) {
+  const bool split = st.h->cfg.precision != 0;
   ConvBlockW w;
   w.cin = cin;
   w.cout = cout;
@@ -78,8 +79,8 @@ ConvBlockW load_block(const Staged& st, DeviceBlob& blob, const std::string& p, 
   check_shape(c2, {cout, cout, 3, 3}, p + ".conv2.weight");
   const int cs = cin / nsrc;
   if (cin >= kKC)
-    for (int s = 0; s < nsrc; ++s) w.w1[s] = blob.upload(pack_conv(c1.data.data(), cout, cin, 3, 3, s * cs, cs, taps3x3()));
-  w.w2 = blob.upload(pack_conv(c2.data.data(), cout, cout, 3, 3, 0, cout, taps3x3()));
+    for (int s = 0; s < nsrc; ++s) w.w1[s] = blob.upload(pack_conv(c1.data.data(), cout, cin, 3, 3, s * cs, cs, taps3x3(), split));
+  w.w2 = blob.upload(pack_conv(c2.data.data(), cout, cout, 3, 3, 0, cout, taps3x3(), split));
   w.shortcut = st.has(p + ".shortcut.weight");
   VFX_CHECK(w.shortcut == (cin != cout), "%s: shortcut presence does not match channel counts", p.c_str());
   if (w.shortcut) {
@@ -87,7 +88,7 @@ ConvBlockW load_block(const Staged& st, DeviceBlob& blob, const std::string& p, 
     check_shape(ws, {cout, cin, 1, 1}, p + ".shortcut.weight");
     if (cin >= kKC)
       for (int s = 0; s < nsrc; ++s)
-        w.wsc[s] = blob.upload(pack_conv(ws.data.data(), cout, cin, 1, 1, s * cs, cs, {{0, 0}}));
+        w.wsc[s] = blob.upload(pack_conv(ws.data.data(), cout, cin, 1, 1, s * cs, cs, {{0, 0}}, split));
     w.bsc = blob.upload(st.get(p + ".shortcut.bias").data);
   }
   return w;
@@ -143,7 +144,7 @@ std::shared_ptr<UNetWeights> build_unet_weights(vfx_handle* h, int model) {
         std::vector<std::pair<int, int>> taps;
         for (int kh = a; kh < 3; kh += 2)
           for (int kw = b; kw < 3; kw += 2) taps.push_back({kh, kw});
-        D.wT[a * 2 + b] = blob.upload(pack_conv_transposed(wt.data.data(), D.cin, D.cout, 3, 3, taps));
+        D.wT[a * 2 + b] = blob.upload(pack_conv_transposed(wt.data.data(), D.cin, D.cout, 3, 3, taps, h->cfg.precision != 0));
       }
     for (int j = 0; j < 4; ++j) {
       char q[96];

@@ -33,6 +33,9 @@ namespace vfx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128;
 constexpr int LDK = kKC + 4;  // padded LDS row length in floats
@@ -43,7 +46,7 @@ constexpr int LDK = kKC + 4;  // padded LDS row length in floats
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const VFX_GLOBAL f32x4*)p; }
 __device__ __forceinline__ void stg4(float* p, f32x4 v) { *(VFX_GLOBAL f32x4*)p = v; }
 
-template <int BN, bool ELU>
+template <int BN, bool ELU, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_tapconv(const TapConvParams* __restrict__ pp) {
   constexpr int WAVES_N = BN >= 64 ? 2 : 1;
   constexpr int WAVES_M = 4 / WAVES_N;
@@ -191,7 +194,20 @@ __global__ __launch_bounds__(256, 2) void k_tapconv(const TapConvParams* __restr
         else u = t >= 0.f ? t : t * R.slope;
         v[e] = (R.ok & (1u << q)) ? u : 0.f;
       }
-      *reinterpret_cast<f32x4*>(Ab + (lr + 32 * q) * LDK + 4 * cg) = v;
+      if constexpr (SPLIT) {
+        // v = hi + lo with hi = bf16(v), lo = bf16(v - hi); row layout [32 hi | 32 lo | pad] (144 B)
+        const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+        const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+        const f32x2 r01 = {v[0] - __builtin_bit_cast(float, h01 << 16), v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+        const f32x2 r23 = {v[2] - __builtin_bit_cast(float, h23 << 16), v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+        const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
+        const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
+        char* rowp = reinterpret_cast<char*>(Ab + (lr + 32 * q) * LDK);
+        *reinterpret_cast<uint2*>(rowp + 8 * cg) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(rowp + 64 + 8 * cg) = make_uint2(l01, l23);
+      } else {
+        *reinterpret_cast<f32x4*>(Ab + (lr + 32 * q) * LDK + 4 * cg) = v;
+      }
     }
 #pragma unroll
     for (int q = 0; q < BP; ++q)
@@ -199,22 +215,50 @@ __global__ __launch_bounds__(256, 2) void k_tapconv(const TapConvParams* __restr
   };
 
   auto compute = [&](int buf) {
-    const float* Ab = As + buf * BM * LDK + (wm * WM * 32 + l31) * LDK + 4 * lh;
-    const float* Bb = Bs + buf * BN * LDK + (wn * WN * 32 + l31) * LDK + 4 * lh;
+    if constexpr (SPLIT) {
+      // 32x32x16 bf16 MFMA: lane l supplies k = 8*(l>>5) .. +7 of each 16-wide K group.
+      const char* Ab = reinterpret_cast<const char*>(As + buf * BM * LDK + (wm * WM * 32 + l31) * LDK) + 16 * lh;
+      const char* Bb = reinterpret_cast<const char*>(Bs + buf * BN * LDK + (wn * WN * 32 + l31) * LDK) + 16 * lh;
 #pragma unroll
-    for (int k8 = 0; k8 < kKC / 8; ++k8) {
-      f32x4 fa[WM], fb[WN];
+      for (int s = 0; s < kKC / 16; ++s) {
+        bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
-      for (int a = 0; a < WM; ++a) fa[a] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDK + k8 * 8);
+        for (int a = 0; a < WM; ++a) {
+          ah[a] = *reinterpret_cast<const bf16x8*>(Ab + a * 32 * LDK * 4 + 32 * s);
+          al[a] = *reinterpret_cast<const bf16x8*>(Ab + a * 32 * LDK * 4 + 64 + 32 * s);
+        }
 #pragma unroll
-      for (int b = 0; b < WN; ++b) fb[b] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * LDK + k8 * 8);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int b = 0; b < WN; ++b) {
+          bh[b] = *reinterpret_cast<const bf16x8*>(Bb + b * 32 * LDK * 4 + 32 * s);
+          bl[b] = *reinterpret_cast<const bf16x8*>(Bb + b * 32 * LDK * 4 + 64 + 32 * s);
+        }
 #pragma unroll
         for (int a = 0; a < WM; ++a)
 #pragma unroll
-          for (int b = 0; b < WN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < WN; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+      }
+    } else {
+      const float* Ab = As + buf * BM * LDK + (wm * WM * 32 + l31) * LDK + 4 * lh;
+      const float* Bb = Bs + buf * BN * LDK + (wn * WN * 32 + l31) * LDK + 4 * lh;
+#pragma unroll
+      for (int k8 = 0; k8 < kKC / 8; ++k8) {
+        f32x4 fa[WM], fb[WN];
+#pragma unroll
+        for (int a = 0; a < WM; ++a) fa[a] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDK + k8 * 8);
+#pragma unroll
+        for (int b = 0; b < WN; ++b) fb[b] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * LDK + k8 * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+      }
     }
   };
 
@@ -285,15 +329,24 @@ static int pick_bn(int Cout) {
   return 32;
 }
 
-template <int BN, bool ELU>
+template <int BN, bool ELU, bool SPLIT>
 static void launch_one(int grid, size_t lds, hipStream_t stream, const TapConvParams* dparams) {
   static bool attr_set = false;
   if (!attr_set) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tapconv<BN, ELU>),
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tapconv<BN, ELU, SPLIT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_tapconv<BN, ELU>), dim3(grid), dim3(256), lds, stream, dparams);
+  hipLaunchKernelGGL((k_tapconv<BN, ELU, SPLIT>), dim3(grid), dim3(256), lds, stream, dparams);
+}
+
+template <bool ELU, bool SPLIT>
+static void launch_bn(int BN, int grid, size_t lds, hipStream_t stream, const TapConvParams* dparams) {
+  switch (BN) {
+    case 128: launch_one<128, ELU, SPLIT>(grid, lds, stream, dparams); break;
+    case 64: launch_one<64, ELU, SPLIT>(grid, lds, stream, dparams); break;
+    default: launch_one<32, ELU, SPLIT>(grid, lds, stream, dparams); break;
+  }
 }
 
 void launch_tapconv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream) {
@@ -311,18 +364,12 @@ void launch_tapconv(const TapConvParams& hp, const TapConvParams* dparams, hipSt
   const int m_tiles = (hp.M + BM - 1) / BM;
   const int grid = m_tiles * (hp.Cout / BN);
   const size_t lds = tapconv_lds_bytes(BN);
-  if (elu) {
-    switch (BN) {
-      case 128: launch_one<128, true>(grid, lds, stream, dparams); break;
-      case 64: launch_one<64, true>(grid, lds, stream, dparams); break;
-      default: launch_one<32, true>(grid, lds, stream, dparams); break;
-    }
+  if (hp.split) {
+    if (elu) launch_bn<true, true>(BN, grid, lds, stream, dparams);
+    else launch_bn<false, true>(BN, grid, lds, stream, dparams);
   } else {
-    switch (BN) {
-      case 128: launch_one<128, false>(grid, lds, stream, dparams); break;
-      case 64: launch_one<64, false>(grid, lds, stream, dparams); break;
-      default: launch_one<32, false>(grid, lds, stream, dparams); break;
-    }
+    if (elu) launch_bn<true, false>(BN, grid, lds, stream, dparams);
+    else launch_bn<false, false>(BN, grid, lds, stream, dparams);
   }
   VFX_HIP(hipGetLastError());
 }

@@ -75,6 +75,7 @@ struct TapConvParams {
   int sh, sw, oh0, ow0;  // grid (i, j) -> output pixel (i*sh + oh0, j*sw + ow0), masked to Ho x Wo
   int reflect_w;         // reflect addressing along W (ReflectionPad1d) instead of zero padding
   int M;                 // B * Hg * Wg
+  int split;             // host-side: 1 = split-bf16 operand mode (weights packed hi|lo)
   const float* bias;     // [Cout] or nullptr
   const float* residual; // (B, Ho, Wo, Cout) or nullptr, added in the epilogue
   float* out;
@@ -242,9 +243,10 @@ struct VocoderWeights {
 };
 
 std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int KW, int c_lo, int C,
-                             const std::vector<std::pair<int, int>>& taps);
+                             const std::vector<std::pair<int, int>>& taps, bool split);
 std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,
-                                        const std::vector<std::pair<int, int>>& taps);
+                                        const std::vector<std::pair<int, int>>& taps, bool split);
+void split_rows_bf16(std::vector<float>& packed);  // every 32-float row -> 32 hi bf16 | 32 lo bf16
 
 }  // namespace vfx
 
