@@ -162,6 +162,44 @@ std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int K
   return out;
 }
 
+// Patch-mode eligibility and geometry.
+void plan_patch(TapConvParams& p) {
+  p.use_patch = 0;
+  if (getenv("VFX_NO_PATCH")) return;
+  int dh_lo = 1 << 30, dh_hi = -(1 << 30), dw_lo = 1 << 30, dw_hi = -(1 << 30);
+  for (int s = 0; s < p.nseg; ++s)
+    for (int t = 0; t < p.seg[s].ntaps; ++t) {
+      dh_lo = std::min(dh_lo, p.seg[s].dh[t]);
+      dh_hi = std::max(dh_hi, p.seg[s].dh[t]);
+      dw_lo = std::min(dw_lo, p.seg[s].dw[t]);
+      dw_hi = std::max(dw_hi, p.seg[s].dw[t]);
+    }
+  int tw_shift;
+  if (p.Hg == 1) tw_shift = 7;
+  else if (p.Wg >= 12) tw_shift = 4;
+  else if (p.Wg >= 6) tw_shift = 3;
+  else if (p.Wg >= 3) tw_shift = 2;
+  else if (p.Wg == 2) tw_shift = 1;
+  else tw_shift = 0;
+  const int TW = 1 << tw_shift, TH = 128 / TW;
+  const int64_t PH = TH + (dh_hi - dh_lo), PW = TW + (int64_t)(dw_hi - dw_lo);
+  if (PH * PW > kPatchMaxRows) return;
+  p.use_patch = 1;
+  p.TH = TH;
+  p.TW = TW;
+  p.tw_shift = tw_shift;
+  p.tiles_h = (p.Hg + TH - 1) / TH;
+  p.tiles_w = (p.Wg + TW - 1) / TW;
+  p.dh_min = dh_lo;
+  p.dw_min = dw_lo;
+  p.PH = (int)PH;
+  p.PW = (int)PW;
+  p.P = (int)(PH * PW);
+  for (int s = 0; s < p.nseg; ++s)
+    for (int t = 0; t < p.seg[s].ntaps; ++t)
+      p.seg[s].poff[t] = (p.seg[s].dh[t] - dh_lo) * p.PW + (p.seg[s].dw[t] - dw_lo);
+}
+
 void finish_params(TapConvParams& p) {
   p.total_steps = 0;
   for (int s = 0; s < p.nseg; ++s) {
@@ -173,6 +211,7 @@ void finish_params(TapConvParams& p) {
   VFX_CHECK((int64_t)p.B * p.Hg * p.Wg < (int64_t)1 << 31, "tapconv: too many output pixels");
   VFX_CHECK((int64_t)p.B * p.Ho * p.Wo < (int64_t)1 << 31, "tapconv: too many output pixels");
   VFX_CHECK((int64_t)p.B * p.Hi * p.Wi < (int64_t)1 << 31, "tapconv: too many input pixels");
+  plan_patch(p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -187,19 +226,20 @@ void PlanBuilder::add_conv(TapConvParams p) {
   plan->n_conv += 1;
   Plan* pl = plan;
   plan->ops.push_back([pl, idx](const RunCtx& c) {
+    auto launch = pl->host_params[idx].use_patch ? launch_patchconv : launch_tapconv;
     if (c.prof && c.prof->enabled) {
       hipEvent_t a, b;
       VFX_HIP(hipEventCreate(&a));
       VFX_HIP(hipEventCreate(&b));
       VFX_HIP(hipEventRecord(a, c.stream));
-      launch_tapconv(pl->host_params[idx], pl->dev_params + idx, c.stream);
+      launch(pl->host_params[idx], pl->dev_params + idx, c.stream);
       VFX_HIP(hipEventRecord(b, c.stream));
       c.prof->events.push_back({a, b});
       c.prof->flops.push_back(tapconv_flops(pl->host_params[idx]));
       c.prof->bn.push_back(pl->host_params[idx].Cout);
       c.prof->desc.push_back(pl->host_params[idx]);
     } else {
-      launch_tapconv(pl->host_params[idx], pl->dev_params + idx, c.stream);
+      launch(pl->host_params[idx], pl->dev_params + idx, c.stream);
     }
   });
 }

@@ -25,7 +25,7 @@ void run_one(TapConvParams& p, DeviceBlob& blob, hipStream_t s, bool split) {
   finish_params(p);
   TapConvParams* d = static_cast<TapConvParams*>(blob.alloc(sizeof(TapConvParams)));
   VFX_HIP(hipMemcpy(d, &p, sizeof(p), hipMemcpyHostToDevice));
-  launch_tapconv(p, d, s);
+  (p.use_patch ? launch_patchconv : launch_tapconv)(p, d, s);
 }
 }  // namespace
 

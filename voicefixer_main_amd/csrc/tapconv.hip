@@ -27,6 +27,7 @@
 //   at channel offset 4*(l>>5) and feeds its 4 components to 4 consecutive MFMAs, i.e. the 8
 //   channels of a k8 group are consumed in the order (0,4),(1,5),(2,6),(3,7) -- any order is
 //   valid as long as A and B agree -- so every LDS read is a 16-byte read.
+#include "conv_epilogue.h"
 #include "vfx_internal.h"
 
 namespace vfx {
@@ -277,48 +278,8 @@ __global__ __launch_bounds__(256, 2) void k_tapconv(const TapConvParams* __restr
     compute(1);
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------
-  // The accumulator fragments go through LDS (re-using the staging buffers) so that the
-  // residual read and the output write are 16-byte-per-lane, row-contiguous accesses and all
-  // residual loads of a thread are in flight together.
-  // C/D layout of the 32x32 MFMA: col = lane & 31 (-> cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  constexpr int LDO = BN + 4;  // staged row length (floats), keeps 16-byte alignment
-  __syncthreads();             // every wave is done reading the last K step
-  float* stage = smem;         // [BM][LDO] <= the A/B buffers
-#pragma unroll
-  for (int a = 0; a < WM; ++a)
-#pragma unroll
-    for (int b = 0; b < WN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        stage[row * LDO + (wn * WN + b) * 32 + l31] = acc[a][b][r];
-      }
-  __syncthreads();
-  constexpr int V = BN / 4;         // float4 per output row
-  constexpr int RPP = 256 / V;      // rows per pass
-  constexpr int NPASS = BM / RPP;   // = BN / 8
-  const int c4 = tid % V, r0 = tid / V;
-  const int Cout = p.Cout;
-  const int ncol = n0 + 4 * c4;
-  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) bv = ldg4(p.bias + ncol);
-  int opix[NPASS];
-#pragma unroll
-  for (int q = 0; q < NPASS; ++q) opix[q] = otab[r0 + q * RPP];
-  f32x4 res[NPASS];
-  if (p.residual) {
-#pragma unroll
-    for (int q = 0; q < NPASS; ++q) res[q] = ldg4(p.residual + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * Cout + ncol);
-  } else {
-#pragma unroll
-    for (int q = 0; q < NPASS; ++q) res[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int q = 0; q < NPASS; ++q) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (r0 + q * RPP) * LDO + 4 * c4) + bv + res[q];
-    if (opix[q] >= 0) stg4(p.out + (int64_t)opix[q] * Cout + ncol, v);
-  }
+  // ---- epilogue: bias + residual, channels-last 16-byte stores (conv_epilogue.h) -----------------
+  conv_epilogue<BN, WM, WN, WAVES_N>(p, smem, otab, acc, n0);
 }
 
 static size_t tapconv_lds_bytes(int BN) { return (size_t)(2 * BM * LDK + 2 * BN * LDK) * 4 + BM * 4; }

@@ -45,7 +45,8 @@ struct Error {};  // thrown after set_error(); caught at the C boundary
 constexpr int kMaxTaps = 9;
 constexpr int kMaxSegs = 3;
 constexpr int kKC = 32;  // input channels per K step
-constexpr int kIdentityLen = 4096;  // length of the identity scale/shift tables
+constexpr int kIdentityLen = 4096;
+constexpr int kPatchMaxRows = 224;  // 7 row groups of 32  // length of the identity scale/shift tables
 
 enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_ELU = 2 };
 
@@ -63,6 +64,7 @@ struct TapSeg {
   float slope;
   int dh[kMaxTaps];
   int dw[kMaxTaps];
+  int poff[kMaxTaps];  // patch mode: row offset of the tap inside the staged patch
 };
 
 struct TapConvParams {
@@ -76,6 +78,13 @@ struct TapConvParams {
   int reflect_w;         // reflect addressing along W (ReflectionPad1d) instead of zero padding
   int M;                 // B * Hg * Wg
   int split;             // host-side: 1 = split-bf16 operand mode (weights packed hi|lo)
+  // patch mode (k_patchconv): the M tile is a TH x TW block of the logical grid and the input
+  // patch (tile + halo of all taps) is staged ONCE per 32-channel chunk.
+  int use_patch;
+  int TH, TW, tw_shift;   // TH * TW = 128, TW = 1 << tw_shift
+  int tiles_h, tiles_w;   // tiles per image
+  int dh_min, dw_min;     // smallest tap offsets over all segments
+  int PH, PW, P;          // patch extent (rows x cols) and P = PH * PW <= kPatchMaxRows
   const float* bias;     // [Cout] or nullptr
   const float* residual; // (B, Ho, Wo, Cout) or nullptr, added in the epilogue
   float* out;
@@ -83,6 +92,8 @@ struct TapConvParams {
 
 void finish_params(TapConvParams& p);  // fills total_steps and M, validates
 void launch_tapconv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
+void launch_patchconv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
+void plan_patch(TapConvParams& p);  // decides use_patch and fills the tile / patch geometry
 double tapconv_flops(const TapConvParams& hp);
 
 // ---------------------------------------------------------------------------------------------
