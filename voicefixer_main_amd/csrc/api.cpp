@@ -114,18 +114,40 @@ static inline float bf16_to_f32(uint16_t b) {
   return f;
 }
 
-// Split-bf16 weight rows: the 32 floats of a (tap, cout) row become 32 hi bf16 followed by
-// 32 lo bf16 (same 128 bytes), w = hi + lo up to 2^-17 relative.
-void split_rows_bf16(std::vector<float>& packed) {
-  for (size_t r = 0; r + kKC <= packed.size(); r += kKC) {
-    uint16_t hi[kKC], lo[kKC];
-    for (int i = 0; i < kKC; ++i) {
-      const float v = packed[r + i];
-      hi[i] = bf16_rne(v);
-      lo[i] = bf16_rne(v - bf16_to_f32(hi[i]));
+// Rows -> MFMA fragment order.  Input: consecutive (chunk, tap) blocks of [Cout][32] floats.
+// Output per block: [Cout/32][1024 floats]; inside a 1024-float cout block
+//   split-bf16: 4 fragments (s, hl) = (k 0..15 | 16..31) x (hi | lo), each [64 lanes][8 bf16]:
+//               lane l holds W[cout = 32*nb + (l & 31)][k = 16*s + 8*(l >> 5) + 0..7], w = hi + lo up
+//               to 2^-17 relative;
+//   fp32:       4 fragments g (k8 groups), each [64 lanes][4 floats]:
+//               lane l holds W[cout = 32*nb + (l & 31)][k = 8*g + 4*(l >> 5) + 0..3].
+// A wave reads one fragment with ONE coalesced 16-byte-per-lane load (conv.hip).
+void rows_to_fragments(std::vector<float>& packed, int Cout, bool split) {
+  const size_t blk = (size_t)Cout * kKC;
+  std::vector<float> tmp(blk);
+  for (size_t o = 0; o + blk <= packed.size(); o += blk) {
+    const float* in = &packed[o];
+    for (int nb = 0; nb < Cout / 32; ++nb) {
+      float* out = &tmp[(size_t)nb * 1024];
+      for (int f = 0; f < 4; ++f)
+        for (int l = 0; l < 64; ++l) {
+          const float* row = in + (size_t)(nb * 32 + (l & 31)) * kKC;
+          float* dst = out + (f * 64 + l) * 4;
+          if (split) {
+            const int s2 = f >> 1, lo = f & 1;
+            uint16_t q[8];
+            for (int j = 0; j < 8; ++j) {
+              const float v = row[16 * s2 + 8 * (l >> 5) + j];
+              const uint16_t hi = bf16_rne(v);
+              q[j] = lo ? bf16_rne(v - bf16_to_f32(hi)) : hi;
+            }
+            memcpy(dst, q, sizeof(q));
+          } else {
+            for (int e = 0; e < 4; ++e) dst[e] = row[8 * f + 4 * (l >> 5) + e];
+          }
+        }
     }
-    memcpy(reinterpret_cast<char*>(&packed[r]), hi, sizeof(hi));
-    memcpy(reinterpret_cast<char*>(&packed[r]) + sizeof(hi), lo, sizeof(lo));
+    memcpy(&packed[o], tmp.data(), blk * sizeof(float));
   }
 }
 
@@ -141,7 +163,7 @@ std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int
           out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
               w[(((size_t)n * CinTotal + c) * KH + taps[t].first) * KW + taps[t].second];
         }
-  if (split) split_rows_bf16(out);
+  rows_to_fragments(out, Cout, split);
   return out;
 }
 
@@ -158,14 +180,15 @@ std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int K
           out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
               w[(((size_t)c * Cout + n) * KH + taps[t].first) * KW + taps[t].second];
         }
-  if (split) split_rows_bf16(out);
+  rows_to_fragments(out, Cout, split);
   return out;
 }
 
-// Patch-mode eligibility and geometry.
-void plan_patch(TapConvParams& p) {
-  p.use_patch = 0;
-  if (getenv("VFX_NO_PATCH")) return;
+// Tile and patch geometry of a launch.  The tile is TH x TW <= 128 pixels of one image; if the
+// bounding box of all taps around it fits kPatchMaxRows pixels, every (segment, chunk) is ONE stage
+// reading all its taps from one patch; otherwise (Conv1d with dilation > 48) every (chunk, tap)
+// is its own stage with a tile-sized patch.
+static void plan_conv(TapConvParams& p) {
   int dh_lo = 1 << 30, dh_hi = -(1 << 30), dw_lo = 1 << 30, dw_hi = -(1 << 30);
   for (int s = 0; s < p.nseg; ++s)
     for (int t = 0; t < p.seg[s].ntaps; ++t) {
@@ -181,37 +204,87 @@ void plan_patch(TapConvParams& p) {
   else if (p.Wg >= 3) tw_shift = 2;
   else if (p.Wg == 2) tw_shift = 1;
   else tw_shift = 0;
-  const int TW = 1 << tw_shift, TH = 128 / TW;
-  const int64_t PH = TH + (dh_hi - dh_lo), PW = TW + (int64_t)(dw_hi - dw_lo);
-  if (PH * PW > kPatchMaxRows) return;
-  p.use_patch = 1;
+  const int TW = 1 << tw_shift, TH = std::min(128 / TW, p.Hg);
   p.TH = TH;
   p.TW = TW;
   p.tw_shift = tw_shift;
   p.tiles_h = (p.Hg + TH - 1) / TH;
   p.tiles_w = (p.Wg + TW - 1) / TW;
-  p.dh_min = dh_lo;
-  p.dw_min = dw_lo;
-  p.PH = (int)PH;
-  p.PW = (int)PW;
-  p.P = (int)(PH * PW);
-  for (int s = 0; s < p.nseg; ++s)
-    for (int t = 0; t < p.seg[s].ntaps; ++t)
-      p.seg[s].poff[t] = (p.seg[s].dh[t] - dh_lo) * p.PW + (p.seg[s].dw[t] - dw_lo);
+  const int64_t PH = TH + (int64_t)(dh_hi - dh_lo), PW = TW + (int64_t)(dw_hi - dw_lo);
+  bool bodies_ok = true;  // conv.hip instantiates stage bodies for these tap counts only
+  for (int s = 0; s < p.nseg; ++s) {
+    const int nt = p.seg[s].ntaps;
+    bodies_ok = bodies_ok && (nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 7 || nt == 9);
+  }
+  if (PH * PW <= kPatchMaxRows && bodies_ok) {
+    p.per_tap = 0;
+    p.PW = (int)PW;
+    p.P = (int)(PH * PW);
+    p.dh_min = dh_lo;
+    p.dw_min = dw_lo;
+  } else {
+    p.per_tap = 1;
+    p.PW = TW;
+    p.P = TH * TW;
+    p.dh_min = p.dw_min = 0;
+  }
+  VFX_CHECK(p.PW < 65536, "conv: patch too wide");
+}
+
+int count_stages(const TapConvParams& p) {
+  int n = 0;
+  for (int s = 0; s < p.nseg; ++s) n += (p.seg[s].C / kKC) * (p.per_tap ? p.seg[s].ntaps : 1);
+  return n;
+}
+
+void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out) {
+  int k = 0;
+  for (int s = 0; s < p.nseg; ++s) {
+    const TapSeg& S = p.seg[s];
+    const int64_t tstride = (int64_t)p.Cout * kKC;
+    for (int ch = 0; ch < S.C / kKC; ++ch) {
+      const int nwin = p.per_tap ? S.ntaps : 1;
+      for (int w = 0; w < nwin; ++w) {
+        ConvStage st{};
+        st.src = S.src + ch * kKC;
+        st.scale = (S.scale ? S.scale : ones) + (S.scale ? ch * kKC : 0);
+        st.shift = (S.shift ? S.shift : zeros) + (S.shift ? ch * kKC : 0);
+        st.C = S.C;
+        st.slope = S.act == ACT_NONE ? 1.f : S.slope;
+        st.tap_stride = (int)tstride;
+        if (p.per_tap) {
+          st.wt = S.wt + ((int64_t)ch * S.ntaps + w) * tstride;
+          st.ntaps = 1;
+          st.dh0 = S.dh[w];
+          st.dw0 = S.dw[w];
+          st.poff[0] = 0;
+        } else {
+          st.wt = S.wt + (int64_t)ch * S.ntaps * tstride;
+          st.ntaps = S.ntaps;
+          st.dh0 = p.dh_min;
+          st.dw0 = p.dw_min;
+          for (int t = 0; t < S.ntaps; ++t) st.poff[t] = (S.dh[t] - p.dh_min) * p.PW + (S.dw[t] - p.dw_min);
+        }
+        out[k++] = st;
+      }
+    }
+  }
 }
 
 void finish_params(TapConvParams& p) {
   p.total_steps = 0;
   for (int s = 0; s < p.nseg; ++s) {
     VFX_CHECK(p.seg[s].C % kKC == 0 && p.seg[s].ntaps >= 1 && p.seg[s].ntaps <= kMaxTaps,
-              "tapconv: bad segment %d (C=%d ntaps=%d)", s, p.seg[s].C, p.seg[s].ntaps);
+              "conv: bad segment %d (C=%d ntaps=%d)", s, p.seg[s].C, p.seg[s].ntaps);
+    VFX_CHECK(p.seg[s].C <= kIdentityLen, "conv: segment too wide for the identity tables");
     p.total_steps += p.seg[s].ntaps * (p.seg[s].C / kKC);
   }
   p.M = p.B * p.Hg * p.Wg;
-  VFX_CHECK((int64_t)p.B * p.Hg * p.Wg < (int64_t)1 << 31, "tapconv: too many output pixels");
-  VFX_CHECK((int64_t)p.B * p.Ho * p.Wo < (int64_t)1 << 31, "tapconv: too many output pixels");
-  VFX_CHECK((int64_t)p.B * p.Hi * p.Wi < (int64_t)1 << 31, "tapconv: too many input pixels");
-  plan_patch(p);
+  VFX_CHECK((int64_t)p.B * p.Hg * p.Wg < (int64_t)1 << 31, "conv: too many output pixels");
+  VFX_CHECK((int64_t)p.B * p.Ho * p.Wo < (int64_t)1 << 31, "conv: too many output pixels");
+  VFX_CHECK((int64_t)p.B * p.Hi * p.Wi < (int64_t)1 << 31, "conv: too many input pixels");
+  plan_conv(p);
+  p.nstages = count_stages(p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -222,11 +295,11 @@ void PlanBuilder::add_conv(TapConvParams p) {
   finish_params(p);
   const size_t idx = plan->host_params.size();
   plan->host_params.push_back(p);
-  plan->conv_flops += tapconv_flops(p);
+  plan->conv_flops += conv_flops(p);
   plan->n_conv += 1;
   Plan* pl = plan;
   plan->ops.push_back([pl, idx](const RunCtx& c) {
-    auto launch = pl->host_params[idx].use_patch ? launch_patchconv : launch_tapconv;
+    auto launch = launch_conv;
     if (c.prof && c.prof->enabled) {
       hipEvent_t a, b;
       VFX_HIP(hipEventCreate(&a));
@@ -235,7 +308,7 @@ void PlanBuilder::add_conv(TapConvParams p) {
       launch(pl->host_params[idx], pl->dev_params + idx, c.stream);
       VFX_HIP(hipEventRecord(b, c.stream));
       c.prof->events.push_back({a, b});
-      c.prof->flops.push_back(tapconv_flops(pl->host_params[idx]));
+      c.prof->flops.push_back(conv_flops(pl->host_params[idx]));
       c.prof->bn.push_back(pl->host_params[idx].Cout);
       c.prof->desc.push_back(pl->host_params[idx]);
     } else {
@@ -267,18 +340,22 @@ void bind_plan(vfx_handle* h, Plan& plan) {
   auto rebase = [&](const float* rel) -> const float* {
     return reinterpret_cast<const float*>(base + reinterpret_cast<size_t>(rel) - 1);
   };
+  size_t total_stages = 0;
+  for (auto& p : abs) total_stages += p.nstages;
+  if (!plan.dev_stages && total_stages)
+    plan.dev_stages = static_cast<ConvStage*>(plan.blob.alloc(total_stages * sizeof(ConvStage)));
+  std::vector<ConvStage> stages(total_stages);
+  size_t so = 0;
   for (auto& p : abs) {
-    for (int s = 0; s < p.nseg; ++s) {
-      p.seg[s].src = rebase(p.seg[s].src);
-      if (!p.seg[s].scale) {  // the kernel always loads the affine pair
-        VFX_CHECK(p.seg[s].C <= kIdentityLen, "segment too wide for the identity tables");
-        p.seg[s].scale = h->d_ones;
-        p.seg[s].shift = h->d_zeros;
-      }
-    }
+    for (int s = 0; s < p.nseg; ++s) p.seg[s].src = rebase(p.seg[s].src);
     if (p.residual) p.residual = rebase(p.residual);
     p.out = const_cast<float*>(rebase(p.out));
+    build_stages(p, h->d_ones, h->d_zeros, stages.data() + so);
+    p.stages = plan.dev_stages + so;
+    so += p.nstages;
   }
+  if (total_stages)
+    VFX_HIP(hipMemcpy(plan.dev_stages, stages.data(), total_stages * sizeof(ConvStage), hipMemcpyHostToDevice));
   if (!plan.dev_params && !abs.empty())
     plan.dev_params = static_cast<TapConvParams*>(plan.blob.alloc(abs.size() * sizeof(TapConvParams)));
   if (!abs.empty())

@@ -20,12 +20,17 @@ void fill_seg(TapSeg& S, const float* x, int Cin, const float* scale, const floa
   S.slope = slope;
 }
 
-void run_one(TapConvParams& p, DeviceBlob& blob, hipStream_t s, bool split) {
-  p.split = split;
+void run_one(vfx_handle* h, TapConvParams& p, DeviceBlob& blob, hipStream_t s) {
+  p.split = h->cfg.precision != 0;
   finish_params(p);
+  std::vector<ConvStage> st(p.nstages);
+  build_stages(p, h->d_ones, h->d_zeros, st.data());
+  ConvStage* ds = static_cast<ConvStage*>(blob.alloc(st.size() * sizeof(ConvStage)));
+  VFX_HIP(hipMemcpy(ds, st.data(), st.size() * sizeof(ConvStage), hipMemcpyHostToDevice));
+  p.stages = ds;
   TapConvParams* d = static_cast<TapConvParams*>(blob.alloc(sizeof(TapConvParams)));
   VFX_HIP(hipMemcpy(d, &p, sizeof(p), hipMemcpyHostToDevice));
-  (p.use_patch ? launch_patchconv : launch_tapconv)(p, d, s);
+  launch_conv(p, d, s);
 }
 }  // namespace
 
@@ -60,7 +65,7 @@ extern "C" int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, i
     p.bias = bias ? sc.blob.upload(bias, Cout) : nullptr;
     p.residual = residual;
     p.out = y;
-    run_one(p, sc.blob, s, h->cfg.precision != 0);
+    run_one(h, p, sc.blob, s);
     VFX_HIP(hipStreamSynchronize(s));
   } catch (const vfx::Error&) {
     return 1;
@@ -108,7 +113,7 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
           p.Wg = (Wo - b + 1) / 2;
           p.bias = dbias;
           p.out = y;
-          run_one(p, sc.blob, s, h->cfg.precision != 0);
+          run_one(h, p, sc.blob, s);
         }
     } else {
       VFX_CHECK(kh == 1 && H == 1 && kw == 2 * stride, "vfx_op_conv_transpose: unsupported geometry");
@@ -139,7 +144,7 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
         p.ow0 = r;
         p.bias = dbias;
         p.out = y;
-        run_one(p, sc.blob, s, h->cfg.precision != 0);
+        run_one(h, p, sc.blob, s);
       }
     }
     VFX_HIP(hipStreamSynchronize(s));

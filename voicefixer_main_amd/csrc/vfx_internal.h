@@ -40,32 +40,48 @@ struct Error {};  // thrown after set_error(); caught at the C boundary
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
-// generic tap-convolution (implicit GEMM on the fp32 MFMA) -- see tapconv.hip
+// stage-driven tap-convolution (implicit GEMM on the MFMA) -- see conv.hip
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxTaps = 9;
 constexpr int kMaxSegs = 3;
-constexpr int kKC = 32;  // input channels per K step
-constexpr int kIdentityLen = 4096;
-constexpr int kPatchMaxRows = 224;  // 7 row groups of 32  // length of the identity scale/shift tables
+constexpr int kKC = 32;             // input channels per K step
+constexpr int kIdentityLen = 4096;  // length of the identity scale/shift tables
+constexpr int kPatchMaxRows = 224;  // patch pixels per stage (7 row groups of 32)
 
 enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_ELU = 2 };
 
 // One K-range of the implicit GEMM: a source tensor (channels-last), its prologue
-// (per-channel affine + activation, applied while the tile is staged into LDS; positions
+// (per-channel affine + activation, applied while the patch is staged into LDS; positions
 // outside the tensor are 0 AFTER the prologue) and a tap list with K-chunked weights.
 struct TapSeg {
   const float* src;    // (B, Hi, Wi, C)
   const float* scale;  // [C] or nullptr (=1)
   const float* shift;  // [C] or nullptr (=0)
-  const float* wt;     // packed [C/32][ntaps][Cout][32]
+  const float* wt;     // fragment-packed [C/32][ntaps][Cout/32][1024] (pack_conv)
   int C;
   int ntaps;
   int act;
   float slope;
   int dh[kMaxTaps];
   int dw[kMaxTaps];
-  int poff[kMaxTaps];  // patch mode: row offset of the tap inside the staged patch
 };
+
+// One stage of a launch: a 32-channel chunk of one source and the taps that read it through one
+// staged patch.  Read by the kernel with scalar loads; built by build_stages() at bind time.
+struct ConvStage {
+  const float* src;    // source tensor + channel offset of the chunk
+  const float* scale;  // prologue affine of the chunk's 32 channels
+  const float* shift;
+  const float* wt;     // weights of the stage's first tap, cout block 0
+  int C;               // pixel stride of src in floats
+  int dh0, dw0;        // patch origin relative to the tile origin
+  int ntaps;
+  float slope;         // LeakyReLU slope of the prologue (1 = identity, 0 = ReLU)
+  int tap_stride;      // floats between the weights of consecutive taps (Cout * 32)
+  int pad_[2];
+  int poff[16];        // patch row offset of every tap (kMaxTaps used)
+};
+static_assert(sizeof(ConvStage) == 128, "ConvStage is read as a 128-byte record");
 
 struct TapConvParams {
   TapSeg seg[kMaxSegs];
@@ -77,24 +93,27 @@ struct TapConvParams {
   int sh, sw, oh0, ow0;  // grid (i, j) -> output pixel (i*sh + oh0, j*sw + ow0), masked to Ho x Wo
   int reflect_w;         // reflect addressing along W (ReflectionPad1d) instead of zero padding
   int M;                 // B * Hg * Wg
-  int split;             // host-side: 1 = split-bf16 operand mode (weights packed hi|lo)
-  // patch mode (k_patchconv): the M tile is a TH x TW block of the logical grid and the input
-  // patch (tile + halo of all taps) is staged ONCE per 32-channel chunk.
-  int use_patch;
-  int TH, TW, tw_shift;   // TH * TW = 128, TW = 1 << tw_shift
+  int split;             // 1 = split-bf16 operand mode, 0 = exact fp32
+  // tile / patch geometry (plan_conv): the M tile is a TH x TW block of the logical grid of one image,
+  // every stage stages a PH x PW patch (P = PH * PW <= kPatchMaxRows pixels).
+  int TH, TW, tw_shift;   // TH * TW <= 128, TW = 1 << tw_shift
   int tiles_h, tiles_w;   // tiles per image
-  int dh_min, dw_min;     // smallest tap offsets over all segments
-  int PH, PW, P;          // patch extent (rows x cols) and P = PH * PW <= kPatchMaxRows
+  int PW, P;
+  int per_tap;            // 1: the taps are too far apart for one patch -> one stage per (chunk, tap)
+  int dh_min, dw_min;     // patch origin of the all-taps window
+  int nstages;
+  const ConvStage* stages;  // device table (bind time)
   const float* bias;     // [Cout] or nullptr
   const float* residual; // (B, Ho, Wo, Cout) or nullptr, added in the epilogue
   float* out;
 };
 
-void finish_params(TapConvParams& p);  // fills total_steps and M, validates
-void launch_tapconv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
-void launch_patchconv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
-void plan_patch(TapConvParams& p);  // decides use_patch and fills the tile / patch geometry
-double tapconv_flops(const TapConvParams& hp);
+void finish_params(TapConvParams& p);  // fills total_steps, M and the tile / patch geometry, validates
+int count_stages(const TapConvParams& p);
+void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out);  // p: absolute pointers
+void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
+int conv_block_n(int Cout);
+double conv_flops(const TapConvParams& hp);
 
 // ---------------------------------------------------------------------------------------------
 // front-end tables + small kernels -- see stft.hip / small_ops.hip
@@ -181,6 +200,7 @@ struct Plan {
   std::vector<std::function<void(const RunCtx&)>> ops;
   std::vector<TapConvParams> host_params;  // arena-relative until bind()
   TapConvParams* dev_params = nullptr;
+  ConvStage* dev_stages = nullptr;
   DeviceBlob blob;
   size_t arena_bytes = 0;
   char* bound_base = nullptr;
@@ -253,11 +273,13 @@ struct VocoderWeights {
   int final_c = 0;
 };
 
+// Conv weights -> MFMA fragment order [C/32][ntaps][Cout/32][1024 floats] (conv.hip); `split`
+// selects the split-bf16 (hi | lo) or the fp32 fragment layout.
 std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int KW, int c_lo, int C,
                              const std::vector<std::pair<int, int>>& taps, bool split);
 std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,
                                         const std::vector<std::pair<int, int>>& taps, bool split);
-void split_rows_bf16(std::vector<float>& packed);  // every 32-float row -> 32 hi bf16 | 32 lo bf16
+void rows_to_fragments(std::vector<float>& packed, int Cout, bool split);  // [..][Cout][32] rows -> fragment order
 
 }  // namespace vfx
 
