@@ -197,26 +197,54 @@ static void plan_conv(TapConvParams& p) {
       dw_lo = std::min(dw_lo, p.seg[s].dw[t]);
       dw_hi = std::max(dw_hi, p.seg[s].dw[t]);
     }
-  int tw_shift;
-  if (p.Hg == 1) tw_shift = 7;
-  else if (p.Wg >= 12) tw_shift = 4;
-  else if (p.Wg >= 6) tw_shift = 3;
-  else if (p.Wg >= 3) tw_shift = 2;
-  else if (p.Wg == 2) tw_shift = 1;
-  else tw_shift = 0;
+  bool bodies_ok = true;  // conv.hip instantiates stage bodies for these tap counts only
+  for (int s = 0; s < p.nseg; ++s) {
+    const int nt = p.seg[s].ntaps;
+    bodies_ok = bodies_ok && (nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 7 || nt == 9);
+  }
+  // Tile shape: TW = 2^k columns x TH = min(128 / TW, Hg) rows.  Among the shapes whose all-taps window
+  // fits kPatchMaxRows pixels take the one that wastes the fewest tile pixels on the image borders
+  // (ties: the smaller window); if none fits, fall back to one stage per (chunk, tap) with a tile-sized patch.
+  int best_shift = -1;
+  double best_util = -1.0;
+  int64_t best_P = 0;
+  const int sft0 = p.Hg == 1 ? 7 : 0;
+  for (int sft = sft0; sft <= 7; ++sft) {
+    const int TW = 1 << sft, TH = std::min(128 / TW, p.Hg);
+    if (TW > 2 * p.Wg && sft > sft0) break;
+    const int64_t PH = TH + (int64_t)(dh_hi - dh_lo), PW = TW + (int64_t)(dw_hi - dw_lo);
+    if (PH * PW > kPatchMaxRows || PW >= 65536) continue;
+    const double covered = (double)((p.Hg + TH - 1) / TH) * ((p.Wg + TW - 1) / TW) * 128.0;
+    const double util = (double)p.Hg * p.Wg / covered;
+    if (util > best_util * 1.02 || (util > best_util * 0.98 && PH * PW < best_P)) {
+      best_util = util;
+      best_shift = sft;
+      best_P = PH * PW;
+    }
+  }
+  const bool window = best_shift >= 0 && bodies_ok;
+  int tw_shift = best_shift;
+  if (!window) {  // per-tap stages: any shape works, take the least wasteful one
+    best_util = -1.0;
+    for (int sft = sft0; sft <= 7; ++sft) {
+      const int TW = 1 << sft, TH = std::min(128 / TW, p.Hg);
+      if (TW > 2 * p.Wg && sft > sft0) break;
+      const double covered = (double)((p.Hg + TH - 1) / TH) * ((p.Wg + TW - 1) / TW) * 128.0;
+      const double util = (double)p.Hg * p.Wg / covered;
+      if (util > best_util) {
+        best_util = util;
+        tw_shift = sft;
+      }
+    }
+  }
   const int TW = 1 << tw_shift, TH = std::min(128 / TW, p.Hg);
   p.TH = TH;
   p.TW = TW;
   p.tw_shift = tw_shift;
   p.tiles_h = (p.Hg + TH - 1) / TH;
   p.tiles_w = (p.Wg + TW - 1) / TW;
-  const int64_t PH = TH + (int64_t)(dh_hi - dh_lo), PW = TW + (int64_t)(dw_hi - dw_lo);
-  bool bodies_ok = true;  // conv.hip instantiates stage bodies for these tap counts only
-  for (int s = 0; s < p.nseg; ++s) {
-    const int nt = p.seg[s].ntaps;
-    bodies_ok = bodies_ok && (nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 7 || nt == 9);
-  }
-  if (PH * PW <= kPatchMaxRows && bodies_ok) {
+  if (window) {
+    const int64_t PH = TH + (int64_t)(dh_hi - dh_lo), PW = TW + (int64_t)(dw_hi - dw_lo);
     p.per_tap = 0;
     p.PW = (int)PW;
     p.P = (int)(PH * PW);
@@ -228,7 +256,6 @@ static void plan_conv(TapConvParams& p) {
     p.P = TH * TW;
     p.dh_min = p.dw_min = 0;
   }
-  VFX_CHECK(p.PW < 65536, "conv: patch too wide");
 }
 
 int count_stages(const TapConvParams& p) {
@@ -239,17 +266,25 @@ int count_stages(const TapConvParams& p) {
 
 void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out) {
   int k = 0;
+  const int64_t tstride = (int64_t)p.Cout * kKC;
   for (int s = 0; s < p.nseg; ++s) {
     const TapSeg& S = p.seg[s];
-    const int64_t tstride = (int64_t)p.Cout * kKC;
-    for (int ch = 0; ch < S.C / kKC; ++ch) {
-      const int nwin = p.per_tap ? S.ntaps : 1;
-      for (int w = 0; w < nwin; ++w) {
+    // per-tap launches run tap-major: the patch origin (and with it the kernel's cached pixel offsets)
+    // then changes ntaps times per block instead of once per stage
+    const int nwin = p.per_tap ? S.ntaps : 1;
+    for (int w = 0; w < nwin; ++w)
+      for (int ch = 0; ch < S.C / kKC; ++ch) {
         ConvStage st{};
         st.src = S.src + ch * kKC;
         st.scale = (S.scale ? S.scale : ones) + (S.scale ? ch * kKC : 0);
         st.shift = (S.shift ? S.shift : zeros) + (S.shift ? ch * kKC : 0);
         st.C = S.C;
+        st.nbytes = (unsigned)((int64_t)p.B * p.in_img_stride * S.C * 4 - (int64_t)ch * kKC * 4);
+        st.flags = S.src_act ? 1 : 0;
+        if (S.src_act) {
+          st.scale = ones;
+          st.shift = zeros;
+        }
         st.slope = S.act == ACT_NONE ? 1.f : S.slope;
         st.tap_stride = (int)tstride;
         if (p.per_tap) {
@@ -267,7 +302,6 @@ void build_stages(const TapConvParams& p, const float* ones, const float* zeros,
         }
         out[k++] = st;
       }
-    }
   }
 }
 
@@ -279,10 +313,21 @@ void finish_params(TapConvParams& p) {
     VFX_CHECK(p.seg[s].C <= kIdentityLen, "conv: segment too wide for the identity tables");
     p.total_steps += p.seg[s].ntaps * (p.seg[s].C / kKC);
   }
-  p.M = p.B * p.Hg * p.Wg;
+  VFX_CHECK((int64_t)p.Hi * p.Wi < (int64_t)1 << 31 && (int64_t)p.Ho * p.Wo < (int64_t)1 << 31, "conv: image too large");
+  if (p.in_img_stride == 0) p.in_img_stride = p.in_limit = p.Hi * p.Wi;
+  if (p.out_img_stride == 0) {
+    p.out_img_stride = p.out_limit = p.Ho * p.Wo;
+    p.M = p.B * p.Hg * p.Wg;
+  } else {
+    p.M = p.B * p.out_limit;  // folded 1-D launch: grid == output
+  }
   VFX_CHECK((int64_t)p.B * p.Hg * p.Wg < (int64_t)1 << 31, "conv: too many output pixels");
-  VFX_CHECK((int64_t)p.B * p.Ho * p.Wo < (int64_t)1 << 31, "conv: too many output pixels");
-  VFX_CHECK((int64_t)p.B * p.Hi * p.Wi < (int64_t)1 << 31, "conv: too many input pixels");
+  VFX_CHECK((int64_t)p.B * p.out_img_stride < (int64_t)1 << 31, "conv: too many output pixels");
+  VFX_CHECK((int64_t)p.B * p.in_img_stride < (int64_t)1 << 31, "conv: too many input pixels");
+  for (int s = 0; s < p.nseg; ++s)  // the kernel addresses a source with 32-bit byte offsets
+    VFX_CHECK((int64_t)p.B * p.in_img_stride * p.seg[s].C * 4 < ((int64_t)1 << 32) - 4096,
+              "conv: source tensor of segment %d exceeds 4 GiB", s);
+  VFX_CHECK(p.out || p.out_act, "conv: no output");
   plan_conv(p);
   p.nstages = count_stages(p);
 }
@@ -349,7 +394,8 @@ void bind_plan(vfx_handle* h, Plan& plan) {
   for (auto& p : abs) {
     for (int s = 0; s < p.nseg; ++s) p.seg[s].src = rebase(p.seg[s].src);
     if (p.residual) p.residual = rebase(p.residual);
-    p.out = const_cast<float*>(rebase(p.out));
+    if (p.out) p.out = const_cast<float*>(rebase(p.out));
+    if (p.out_act) p.out_act = const_cast<float*>(rebase(p.out_act));
     build_stages(p, h->d_ones, h->d_zeros, stages.data() + so);
     p.stages = plan.dev_stages + so;
     so += p.nstages;

@@ -10,28 +10,33 @@
 //     upsamplers as `scale` output-phase launches (H = 1).
 //
 // GEMM view:  out[m, n] = sum_seg sum_tap sum_c  P(src_seg[pix(m) + off(tap), c]) * W_seg[tap][c][n]
-//   M = output pixels, N = Cout, K = sum ntaps*C.  Activations are channels-last fp32, so a K
-//   step (one tap, 32 channels) is a 128-byte row per pixel.
+//   M = output pixels, N = Cout, K = sum ntaps*C.  Activations are channels-last, 4 bytes per
+//   element, so a K step (one tap, 32 channels) is a 128-byte row per pixel.
 //
 // Work decomposition
 //   block   = 4 waves, tile = TH x TW (<= 128) pixels of ONE image x BN in {128, 64, 32} couts;
-//   wave    = (128 / WAVES_M) pixels x 32 couts, WAVES_N = BN / 32 (so a wave owns ONE 32-cout
-//             column block and BN/32 row blocks);
+//   wave    = (128 / WAVES_M) pixels x 32 couts, WAVES_N = BN / 32;
 //   stage   = one 32-channel chunk of one source tensor and the taps that read it.  The host
 //             flattens every launch into a table of stages (ConvStage, vfx_internal.h).
 //
 // Operand paths
 //   A (activations): per stage the input PATCH (tile + halo of the stage's taps, <= 224 pixels x
-//     32 channels) is loaded from global ONCE, run through the prologue (per-channel affine =
-//     folded eval-mode BatchNorm, LeakyReLU / ReLU / ELU, zero halo AFTER the activation,
-//     reflect addressing) and, in split-bf16 mode, through the hi/lo split ONCE, then written
-//     to one of two LDS patch buffers; every tap reads its shifted window of that buffer.  The
-//     patch of stage s+1 is fetched into registers at the start of stage s and written to the
-//     other buffer at its end: ONE barrier per stage, none per K step.
-//   B (weights): never touch LDS.  They are packed on the host in MFMA fragment order
-//     ([chunk][tap][cout/32][fragment][lane] -> one coalesced 1 KB load per fragment per wave) and
-//     go global -> VGPR -> MFMA.  The loads of a group of <= 3 taps are issued before the
-//     patch loads of the stage (vmcnt is in-order: a later weight wait must not drain the patch).
+//     128 bytes) goes into one of two LDS patch buffers; every tap reads its shifted window of it.
+//     - ACTIVATED sources (the producer's epilogue already applied this layer's prologue and
+//       stored the MFMA operand form, TapConvParams::out_act) are copied global -> LDS by the
+//       LDS-DMA engine (buffer_load ... lds): no VGPRs, no VALU, no ds_write; pixels outside the
+//       image read past the buffer bound and arrive as zeros.
+//     - RAW fp32 sources arrive the same way and are then transformed IN PLACE by the threads that
+//       fetched them: per-channel affine (folded eval-mode BatchNorm), LeakyReLU / ReLU / ELU, zero
+//       halo AFTER the activation, hi/lo split.
+//     The patch of stage s+1 is requested while stage s computes; ONE barrier per stage.
+//     LDS rows are unpadded 128-byte rows (the DMA writes lane-linear); the 16-byte piece p of row r
+//     sits at slot p ^ ((r >> 1) & 7), applied on the DMA's SOURCE address and on every read, which
+//     makes the 16-lane groups of the ds_read_b128 fragment reads conflict-free.
+//   B (weights): never touch LDS.  Packed on the host in MFMA fragment order, they go
+//     global -> VGPR -> MFMA through a ring of three (two for BN = 128) register groups.  The loads
+//     are inline asm with hand-counted s_waitcnt vmcnt(N): beside an LDS-DMA the compiler would
+//     wait vmcnt(0) for every ordinary load and drain the patch prefetch at each tap.
 //
 // Arithmetic (vfx_config.precision)
 //   1: split-bf16 -- every operand is hi + lo (two bf16), products hi*hi + hi*lo + lo*hi on
@@ -46,32 +51,60 @@ namespace vfx {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int CBM = 128;                // pixels per tile
-constexpr int CLDK = kKC + 4;           // LDS row length in floats (144 bytes): conflict-free 16-byte row reads
-constexpr int CNQ = kPatchMaxRows / 32; // patch row groups per thread
+constexpr int CBM = 128;                     // pixels per tile
+constexpr int CROW = 128;                    // bytes per patch row (32 channels)
+constexpr int CNQ = kPatchMaxRows / 32;      // patch row groups (one DMA instruction / register group each)
+constexpr int CPATCH = kPatchMaxRows * CROW; // bytes per patch buffer
 
-// Pointers read out of the parameter block are generic to the compiler (-> flat_load, which also
-// ticks the LDS counter); every tensor here lives in global memory, so say so.
 #define VFX_GLOBAL __attribute__((address_space(1)))
-__device__ __forceinline__ f32x4 c_ldg4(const float* p) { return *(const VFX_GLOBAL f32x4*)p; }
+#define VFX_LDS __attribute__((address_space(3)))
+#define VFX_CONST __attribute__((address_space(4)))
 
-template <int BN, bool ELU, bool SPLIT>
+// One weight fragment group = the four 16-byte-per-lane fragments of a (tap, 32-channel chunk, 32 couts).
+struct BFrag {
+  f32x4 f[4];  // split: (hi, lo) of k 0..15, (hi, lo) of k 16..31; fp32: the four k8 groups
+};
+
+// Hidden from the compiler's s_waitcnt bookkeeping on purpose (see the file header): the destination
+// registers are only valid after wait_b<N>() with N = number of VMEM operations issued after this load.
+__device__ __forceinline__ void load_b_asm(BFrag& R, const float* wtap, unsigned voff) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "global_load_dwordx4 %0, %4, %5\n\t"
+      "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+      "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+      "global_load_dwordx4 %3, %4, %5 offset:3072"
+      : "=&v"(R.f[0]), "=&v"(R.f[1]), "=&v"(R.f[2]), "=&v"(R.f[3])
+      : "v"(voff), "s"(wtap)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_b(BFrag& R) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R.f[0]), "+v"(R.f[1]), "+v"(R.f[2]), "+v"(R.f[3]) : "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);  // nothing that reads R may be scheduled above the wait
+}
+
+// ABL != 0: timing-only ablation builds (-DVFX_ABLATION_BUILD + VFX_ABLATE, wrong results), in the stage loop:
+// bit 0 no patch request, 1 no weight loads, 2 no barrier, 3 constant fragment addresses, 4 no fragment reads,
+// 5 no epilogue.
+template <int BN, bool ELU, bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict__ pp) {
   constexpr int WAVES_N = BN / 32;
   constexpr int WM = BN / 32;  // 32-row blocks per wave (= 4 / WAVES_M)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kMainFloats = (2 * kPatchMaxRows * CLDK > CBM * (BN + 4)) ? 2 * kPatchMaxRows * CLDK : CBM * (BN + 4);
-  int* otab = reinterpret_cast<int*>(smem + kMainFloats);  // [128] output pixel index or -1
+  constexpr int kMainBytes = (2 * CPATCH > CBM * (BN + 4) * 4) ? 2 * CPATCH : CBM * (BN + 4) * 4;
+  char* const lds = reinterpret_cast<char*>(smem);
+  int* otab = reinterpret_cast<int*>(lds + kMainBytes);  // [128] output pixel index or -1
 
   const TapConvParams& p = *pp;
   // The stage table is read-only for the whole launch: address it in the constant address space so
-  // that every descriptor field is a scalar load (a generic pointer would be read with per-lane
-  // flat loads and make the whole stage loop look divergent to the compiler).
-  typedef const ConvStage __attribute__((address_space(4))) * StageTab;
+  // that every descriptor field is a scalar load.
+  typedef const ConvStage VFX_CONST* StageTab;
   const StageTab stages = (StageTab)(uintptr_t)p.stages;
   const int nstages = p.nstages;
   const int tid = threadIdx.x;
@@ -93,27 +126,25 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
   const int img = mt / p.tiles_h;
   const int i0 = ti * p.TH, j0 = tj * p.TW;
   const int Hi = p.Hi, Wi = p.Wi, PW = p.PW, P = p.P;
+  const int in_img_stride = p.in_img_stride, in_limit = p.in_limit;
   const int nq = (P + 31) >> 5;  // patch row groups in use (uniform)
 
   // ---- per-thread roles ---------------------------------------------------------------------------
-  // Every stage of a launch stages the same PH x PW window around the tile (patch pixel -> (row, col)
-  // through the pij table); only its origin (dh0, dw0) varies between stages.
+  // Every stage of a launch stages the same PH x PW window around the tile; only its origin (dh0, dw0)
+  // varies between stages.
   const int lr = tid >> 3, cg = tid & 7;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tw_shift = p.tw_shift, TWm1 = p.TW - 1, TH = p.TH;
-  int pij[CNQ];  // (patch row << 16 | patch col) of patch pixel lr + 32q; pixels past P never pass the bounds test
-#pragma unroll
-  for (int q = 0; q < CNQ; ++q) {
-    const int prow = lr + 32 * q;
-    const int pi = prow / PW, pj = prow - pi * PW;
-    pij[q] = prow < P ? ((pi << 16) | pj) : 0x7fff0000;
-  }
+  const int key_l = (lr >> 1) & 7;                         // swizzle key of this thread's patch rows (lr + 32q)
+  const unsigned dma_piece = (unsigned)(cg ^ key_l) << 4;  // the DMA lane fetches the piece that belongs in slot cg
   if (tid < CBM) {
     const int li = tid >> tw_shift, lj = tid & TWm1;
     const int i = i0 + li, j = j0 + lj;
     int idx = -1;
     if (li < TH && i < p.Hg && j < p.Wg) {
       const int oh = i * p.sh + p.oh0, ow = j * p.sw + p.ow0;
-      if (oh < p.Ho && ow < p.Wo) idx = (img * p.Ho + oh) * p.Wo + ow;
+      const int o = oh * p.Wo + ow;
+      if (oh < p.Ho && ow < p.Wo && o < p.out_limit) idx = img * p.out_img_stride + o;
     }
     otab[tid] = idx;
   }
@@ -124,93 +155,119 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
 
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lane = tid & 63;
+  const int wm = wave_u / WAVES_N, wn = wave_u % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
-  int aoff[WM];  // byte offset of this lane's pixel of M block a inside a patch buffer (tap offset added per step)
+  int arow[WM];  // patch row of this lane's pixel of M block a (tap offset added per step)
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
     const int ml = (wm * WM + a) * 32 + l31;
     const int li = ml >> tw_shift;
-    aoff[a] = (li < TH ? li * PW + (ml & TWm1) : 0) * (CLDK * 4) + 16 * lh;
+    arow[a] = li < TH ? li * PW + (ml & TWm1) : 0;
   }
-  const int nb_off = ((n0 >> 5) + wn) * 1024 + lane * 4;  // this lane's slot in a weight fragment block
+  const unsigned nb_off = (unsigned)(((n0 >> 5) + wn) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block
 
   // ---- patch (A) staging ------------------------------------------------------------------------
-  // Loads are unconditional (pixels outside the image or the patch read pixel 0 and are zeroed when
-  // staged) so that every stage body is straight-line code with a fixed number of loads: the compiler
-  // then keeps counted s_waitcnt vmcnt(N) waits, i.e. the prefetches really stay in flight.
-  f32x4 pa[CNQ], psc, psh;
-  float pslope = 1.f;
+  // The byte offset of every patch pixel is kept in registers and only recomputed when the patch
+  // origin or the pixel stride changes (per-tap and mixed-width launches only).
+  unsigned voff[CNQ];  // pixel byte offset inside the source tensor (chunk 0), valid when the okmask bit is set
   unsigned okmask = 0;
-
-  auto issue_patch = [&](const __attribute__((address_space(4))) ConvStage& S) {
-    const float* src = S.src;
-    const int C = S.C;
-    const int dh0 = i0 + S.dh0, dw0 = j0 + S.dw0;
+  int o_dh = 0x7fffffff, o_dw = 0, o_C = 0;  // origin / stride the offsets were computed for
+  bool praw = false;   // the patch in flight is a raw fp32 one: transformed in place once it has landed
+  auto set_origin = [&](int dh, int dw, int C) __attribute__((always_inline)) {
+    o_dh = dh;
+    o_dw = dw;
+    o_C = C;
     okmask = 0;
 #pragma unroll
     for (int q = 0; q < CNQ; ++q) {
-      const int si = dh0 + (pij[q] >> 16);
-      int sj = dw0 + (pij[q] & 0xffff);
+      const int prow = lr + 32 * q;  // patch pixel -> (row, col) of the PH x PW window
+      const int pi = prow / PW, pj = prow - pi * PW;
+      const int si = prow < P ? i0 + dh + pi : -1;
+      int sj = j0 + dw + pj;
       int rj = sj < 0 ? -sj : sj;
       rj = rj >= Wi ? 2 * (Wi - 1) - rj : rj;
       sj = p.reflect_w ? rj : sj;
-      const bool ok = ((unsigned)si < (unsigned)Hi) & ((unsigned)sj < (unsigned)Wi);
-      const int pix = ok ? (img * Hi + si) * Wi + sj : 0;
-      pa[q] = c_ldg4(src + (int64_t)pix * C + 4 * cg);
+      const int o = si * Wi + sj;
+      const bool ok = ((unsigned)si < (unsigned)Hi) & ((unsigned)sj < (unsigned)Wi) & (o < in_limit);
+      voff[q] = (unsigned)(img * in_img_stride + o) * (unsigned)(C * 4);
       okmask |= ok ? (1u << q) : 0u;
     }
-    psc = c_ldg4(S.scale + 4 * cg);
-    psh = c_ldg4(S.shift + 4 * cg);
-    pslope = S.slope;
   };
 
-  auto store_group = [&](float* Ap, int q, f32x4 raw) {
-    f32x4 v;
+  // Request the patch of stage S into the LDS buffer at byte offset `dst`: CNQ LDS-DMA instructions (the
+  // hand-counted weight waits rely on that number).  Offsets of pixels outside the image / patch are
+  // replaced by one past the buffer bound: the hardware returns zeros.  A thread's lane always lands in
+  // slot cg of patch row lr + 32q; an activated source is fetched pre-swizzled (piece cg ^ key), a raw one
+  // straight (piece cg) -- the same thread re-reads and rewrites it in transform_patch().
+  auto issue_patch = [&](const ConvStage VFX_CONST& S, int dst) __attribute__((always_inline)) {
+    const int dh = S.dh0, dw = S.dw0, C = S.C;
+    if (dh != o_dh || dw != o_dw || C != o_C) set_origin(dh, dw, C);  // uniform; VALU only
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((const float*)S.src), 0, (int)S.nbytes, 0x00020000);
+    praw = (S.flags & 1) == 0;
+    const unsigned piece = praw ? 16u * cg : dma_piece;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float t = raw[e] * psc[e] + psh[e];
-      float u;
-      if constexpr (ELU) u = t > 0.f ? t : expm1f(t);  // only the vocoder's condnet instantiates this
-      else u = fmaxf(t, t * pslope);                    // LeakyReLU, slope in [0, 1]: 1 = identity, 0 = ReLU
-      v[e] = (okmask & (1u << q)) ? u : 0.f;
-    }
-    float* rowf = Ap + (lr + 32 * q) * CLDK;
-    if constexpr (SPLIT) {
-      // v = hi + lo with hi = bf16(v), lo = bf16(v - hi); row layout [32 hi | 32 lo | pad] (144 B)
-      const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
-      const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
-      const f32x2 r01 = {v[0] - __builtin_bit_cast(float, h01 << 16), v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
-      const f32x2 r23 = {v[2] - __builtin_bit_cast(float, h23 << 16), v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
-      const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
-      const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
-      char* rowp = reinterpret_cast<char*>(rowf);
-      *reinterpret_cast<uint2*>(rowp + 8 * cg) = make_uint2(h01, h23);
-      *reinterpret_cast<uint2*>(rowp + 64 + 8 * cg) = make_uint2(l01, l23);
-    } else {
-      *reinterpret_cast<f32x4*>(rowf + 4 * cg) = v;
+    for (int q = 0; q < CNQ; ++q) {
+      const unsigned o = (okmask & (1u << q)) ? voff[q] + piece : 0xfffffff0u;
+      VFX_LDS void* l = (VFX_LDS void*)(lds + dst + (32 * q + 8 * wave_u) * CROW);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
     }
   };
-  // nqs = row groups to stage (uniform); the guard only skips VALU + LDS work, never a global load
-  auto store_patch = [&](float* Ap) {
+
+  // Raw source: every thread turns the 4 floats it fetched (slot cg of its rows) into operand form in
+  // place: per-channel affine (folded eval-mode BatchNorm), LeakyReLU / ReLU / ELU, zero halo AFTER the
+  // activation, hi/lo split.  All reads of a thread precede its writes and a row's 8 slots belong to 8
+  // consecutive lanes of one wave, so no barrier is needed between the two passes.
+  auto transform_patch = [&](const ConvStage VFX_CONST& S, int dst) __attribute__((always_inline)) {
+    const f32x4 psc = *(const VFX_GLOBAL f32x4*)((const float*)S.scale + 4 * cg);
+    const f32x4 psh = *(const VFX_GLOBAL f32x4*)((const float*)S.shift + 4 * cg);
+    const float pslope = S.slope;
+    char* row0 = lds + dst + lr * CROW;
+    f32x4 raw[CNQ];
 #pragma unroll
     for (int q = 0; q < CNQ; ++q)
-      if (q < 4 || q < nq) store_group(Ap, q, pa[q]);
-  };
-
-  // ---- weight (B) fragments: global -> VGPR -----------------------------------------------------
-  struct BF {
-    f32x4 f[4];  // split: (hi, lo) of k 0..15, (hi, lo) of k 16..31; fp32: the four k8 groups
-  };
-  auto load_b = [&](BF& R, const float* wtap) {
-    const float* b = wtap + nb_off;
+      if (q < 4 || q < nq) raw[q] = *reinterpret_cast<const f32x4*>(row0 + 32 * q * CROW + 16 * cg);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) R.f[i] = c_ldg4(b + i * 256);
+    for (int q = 0; q < CNQ; ++q)
+      if (q < 4 || q < nq) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = raw[q][e] * psc[e] + psh[e];
+          float u;
+          if constexpr (ELU) u = t > 0.f ? t : expm1f(t);  // only vfx_op_conv instantiates this
+          else u = fmaxf(t, t * pslope);                    // LeakyReLU, slope in [0, 1]: 1 = identity, 0 = ReLU
+          v[e] = (okmask & (1u << q)) ? u : 0.f;
+        }
+        char* rowp = row0 + 32 * q * CROW;
+        if constexpr (SPLIT) {
+          // v = hi + lo with hi = bf16(v), lo = bf16(v - hi); logical row layout [32 hi | 32 lo]
+          const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+          const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          const f32x2 r01 = {v[0] - __builtin_bit_cast(float, h01 << 16), v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+          const f32x2 r23 = {v[2] - __builtin_bit_cast(float, h23 << 16), v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+          const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
+          const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
+          // hi of channels 4cg..4cg+3: piece cg>>1, half cg&1; lo: piece 4 + (cg>>1)
+          const int half = 8 * (cg & 1);
+          *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ key_l) << 4) + half) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ key_l) << 4) + half) = make_uint2(l01, l23);
+        } else {
+          *reinterpret_cast<f32x4*>(rowp + ((cg ^ key_l) << 4)) = v;
+        }
+      }
   };
 
-  auto compute = [&](const BF& R, const float* Ap, int toff) {
-    const char* A0 = reinterpret_cast<const char*>(Ap) + toff * (CLDK * 4);
+  auto compute = [&](const BFrag& R, int src, int toff) __attribute__((always_inline)) {
+    const char* base[WM];
+    int key[WM];
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const int row = (ABL & 8) ? arow[a] : arow[a] + toff;
+      base[a] = (ABL & 8) ? lds + row * CROW : lds + src + row * CROW;
+      key[a] = (ABL & 8) ? 0 : ((row >> 1) & 7) << 4;
+    }
     if constexpr (SPLIT) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -219,9 +276,13 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
         bf16x8 ah[WM], al[WM];
 #pragma unroll
         for (int a = 0; a < WM; ++a) {
-          const char* ap = A0 + aoff[a] + 32 * s;
-          ah[a] = *reinterpret_cast<const bf16x8*>(ap);
-          al[a] = *reinterpret_cast<const bf16x8*>(ap + 64);
+          if constexpr (ABL & 16) {
+            ah[a] = __builtin_bit_cast(bf16x8, R.f[a & 3]);
+            al[a] = __builtin_bit_cast(bf16x8, R.f[(a + 1) & 3]);
+          } else {
+            ah[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
+            al[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((64 + 32 * s + 16 * lh) ^ key[a]));
+          }
         }
         // small cross terms first, the dominant hi*hi product last; consecutive MFMAs hit different accumulators
 #pragma unroll
@@ -239,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
         const f32x4 fb = R.f[g];
         f32x4 fa[WM];
 #pragma unroll
-        for (int a = 0; a < WM; ++a) fa[a] = *reinterpret_cast<const f32x4*>(A0 + aoff[a] + 32 * g);
+        for (int a = 0; a < WM; ++a) fa[a] = *reinterpret_cast<const f32x4*>(base[a] + ((32 * g + 16 * lh) ^ key[a]));
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -250,82 +311,155 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
   };
 
   // ---- stage bodies ------------------------------------------------------------------------------
-  // One straight-line body per tap count NT.  Weight fragments live in a ring of three register
-  // groups (taps t, t+1, t+2); a group is refilled (tap t+3, or tap 0 of the next stage) right after
-  // its tap has been computed.  Order of issue at the start of a stage: weights of taps 1, 2 (tap 0
-  // was fetched by the previous stage), THEN the next stage's patch -- vmcnt retires in order, so a
-  // wait for a weight fragment issued before the patch loads leaves the patch in flight.
-  BF R0, R1, R2;
-  auto body = [&](auto NTc, const __attribute__((address_space(4))) ConvStage& S,
-                  const __attribute__((address_space(4))) ConvStage& N, const float* Acur, float* Anext) {
+  // One straight-line body per tap count NT.  Weight fragments: ring of RING register groups (3, or 2 for
+  // the register-hungry BN = 128 tile), tap t in group t % RING, fetched RING-1 taps ahead (the fetches of
+  // the last taps of a stage go to the first taps of the following stage(s)).  On entry the fragments of
+  // the stage's first RING-1 taps have landed (every body ends with vmcnt(0)).  The next stage's patch is
+  // requested right after the fetch of the stage's LAST tap: every weight wait of the stage is then for a
+  // load issued before the patch request (vmcnt retires in order), so the patch prefetch stays in flight
+  // until the end-of-stage barrier.
+  // vmcnt bookkeeping at the wait for tap t >= RING-1: younger operations = 4 * (RING-1) weight loads
+  // + CNQ if the patch has been requested (t >= TP).
+  constexpr int RING = WM >= 4 ? 2 : 3;
+  constexpr int AHEAD = RING - 1;
+  BFrag R0, R1, R2;
+  auto ring = [&](int i) __attribute__((always_inline)) -> BFrag& { return i % RING == 0 ? R0 : (i % RING == 1 ? R1 : R2); };
+  auto body = [&](auto NTc, const ConvStage VFX_CONST& S, const ConvStage VFX_CONST& N, const ConvStage VFX_CONST& N2,
+                  int cur, int nxt) __attribute__((always_inline)) {
     constexpr int NT = decltype(NTc)::value;
-    const float* wt = S.wt;
+    constexpr int TP = NT > AHEAD ? NT - 1 - AHEAD : 0;  // the patch request follows the weight fetch issued in iteration TP
+    const float* wt = (const float*)S.wt;
     const int64_t ts = S.tap_stride;
     int poff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) poff[t] = S.poff[t];
-    const float* nwt = N.wt;
-    if constexpr (NT >= 2) load_b(R1, wt + ts);
-    if constexpr (NT >= 3) load_b(R2, wt + 2 * ts);
-    issue_patch(N);
-    if constexpr (NT == 1) load_b(R1, nwt);  // tap 0 of the next stage: a free ring slot, younger than the patch
-    if constexpr (NT == 2) load_b(R2, nwt);
-    // the ring slot of tap t is t % 3; `next` must end up in R0
-    auto slot = [&](int t) -> BF& { return t % 3 == 0 ? R0 : (t % 3 == 1 ? R1 : R2); };
+    // taps NT, NT+1 of the flattened tap sequence: first taps of the following stage(s)
+    const float* nw0 = (const float*)N.wt;
+    const float* nw1 = N.ntaps >= 2 ? (const float*)N.wt + N.tap_stride : (const float*)N2.wt;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      compute(slot(t), Acur, poff[t]);
+      BFrag& cur_r = ring(t);
+      const int j = t + AHEAD;  // tap fetched now
+      const float* fw = j < NT ? wt + j * ts : (j == NT ? nw0 : nw1);
+      if constexpr (!(ABL & 2)) load_b_asm(ring(j), fw, nb_off);
+      if constexpr (!(ABL & 1))
+        if (t == TP) issue_patch(N, nxt);
+      if (t >= AHEAD && !(ABL & 3)) {
+        if (t >= TP) wait_b<4 * AHEAD + CNQ>(cur_r);
+        else wait_b<4 * AHEAD>(cur_r);
+      }
+      compute(cur_r, cur, poff[t]);
       __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of tap t+1 below the MFMAs of tap t (register pressure)
-      if (t + 3 < NT) load_b(slot(t), wt + (t + 3) * ts);
-      else if (t + 3 == NT) load_b(slot(t), nwt);  // slot (NT % 3): moved to R0 below if it is not R0
     }
-    store_patch(Anext);
-    if constexpr (NT % 3 == 1) R0 = R1;
-    if constexpr (NT % 3 == 2) R0 = R2;
+    // everything in flight (next taps' weights, the patch) must have landed before the transform / the
+    // barrier / the moves below
+    if constexpr (RING == 3)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]),
+                     "+v"(R1.f[3]), "+v"(R2.f[0]), "+v"(R2.f[1]), "+v"(R2.f[2]), "+v"(R2.f[3])
+                   :
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]),
+                     "+v"(R1.f[3])
+                   :
+                   : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (praw) transform_patch(N, nxt);
+    // the next stage's first taps sit in groups NT % RING, ...: rotate them into R0 (, R1)
+    if constexpr (RING == 3) {
+      if constexpr (NT % 3 == 1) {
+        R0 = R1;
+        R1 = R2;
+      } else if constexpr (NT % 3 == 2) {
+        R1 = R0;
+        R0 = R2;
+      }
+    } else {
+      if constexpr (NT % 2 == 1) R0 = R1;
+    }
   };
 
   // ---- stage loop ----------------------------------------------------------------------------------
-  issue_patch(stages[0]);
-  load_b(R0, stages[0].wt);
-  store_patch(smem);
-
+  {
+    const ConvStage VFX_CONST& S0 = stages[0];
+    const ConvStage VFX_CONST& S1 = stages[nstages > 1 ? 1 : 0];
+    load_b_asm(R0, (const float*)S0.wt, nb_off);
+    if constexpr (RING == 3) load_b_asm(R1, S0.ntaps >= 2 ? (const float*)S0.wt + S0.tap_stride : (const float*)S1.wt, nb_off);
+    else R1 = R0;
+    issue_patch(S0, 0);
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]), "+v"(R1.f[3])
+                 :
+                 : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (praw) transform_patch(S0, 0);
+  }
+  const int last = nstages - 1;
   for (int st = 0; st < nstages; ++st) {
-    const __attribute__((address_space(4))) ConvStage& S = stages[st];
-    const __attribute__((address_space(4))) ConvStage& N = stages[st + 1 < nstages ? st + 1 : st];  // past the end: refetch (never consumed)
-    const float* Acur = smem + (st & 1) * (kPatchMaxRows * CLDK);
-    float* Anext = smem + ((st + 1) & 1) * (kPatchMaxRows * CLDK);
+    const ConvStage VFX_CONST& S = stages[st];
+    const ConvStage VFX_CONST& N = stages[st + 1 < last ? st + 1 : last];   // past the end: refetch (never consumed)
+    const ConvStage VFX_CONST& N2 = stages[st + 2 < last ? st + 2 : last];
+    const int cur = (st & 1) * CPATCH, nxt = ((st + 1) & 1) * CPATCH;
     const int ntaps = S.ntaps;
-    __syncthreads();  // patch `st` is visible; every wave is done with the buffer patch st+1 will overwrite
+    if constexpr (!(ABL & 4)) __syncthreads();  // patch `st` is visible; every wave is done with the buffer patch st+1 will overwrite
     switch (ntaps) {
-      case 1: body(std::integral_constant<int, 1>{}, S, N, Acur, Anext); break;
-      case 2: body(std::integral_constant<int, 2>{}, S, N, Acur, Anext); break;
-      case 3: body(std::integral_constant<int, 3>{}, S, N, Acur, Anext); break;
-      case 4: body(std::integral_constant<int, 4>{}, S, N, Acur, Anext); break;
-      case 7: body(std::integral_constant<int, 7>{}, S, N, Acur, Anext); break;
-      default: body(std::integral_constant<int, 9>{}, S, N, Acur, Anext); break;
+      case 1: body(std::integral_constant<int, 1>{}, S, N, N2, cur, nxt); break;
+      case 2: body(std::integral_constant<int, 2>{}, S, N, N2, cur, nxt); break;
+      case 3: body(std::integral_constant<int, 3>{}, S, N, N2, cur, nxt); break;
+      case 4: body(std::integral_constant<int, 4>{}, S, N, N2, cur, nxt); break;
+      case 7: body(std::integral_constant<int, 7>{}, S, N, N2, cur, nxt); break;
+      default: body(std::integral_constant<int, 9>{}, S, N, N2, cur, nxt); break;
     }
   }
 
-  // ---- epilogue: bias + residual, channels-last 16-byte stores (conv_epilogue.h) -----------------
-  conv_epilogue<BN, WM, 1, WAVES_N>(p, smem, otab, acc, n0);
+  // ---- epilogue: bias + residual, raw and / or activated output (conv_epilogue.h) ------------------
+  if constexpr (ABL & 32) {
+    float keep = 0.f;
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep += acc[a][0][r];
+    if (keep == 12345.678f) p.out_act[tid] = keep;  // keeps the accumulators live
+  } else {
+    conv_epilogue<BN, WM, 1, WAVES_N, SPLIT>(p, smem, otab, acc, n0);
+  }
 }
 
 static size_t conv_lds_bytes(int BN) {
-  const size_t main_floats = std::max<size_t>((size_t)2 * kPatchMaxRows * CLDK, (size_t)CBM * (BN + 4));
-  return main_floats * 4 + CBM * 4;
+  const size_t main_bytes = std::max<size_t>((size_t)2 * CPATCH, (size_t)CBM * (BN + 4) * 4);
+  return main_bytes + CBM * 4;
 }
 
-template <int BN, bool ELU, bool SPLIT>
+template <int BN, bool ELU, bool SPLIT, int ABL = 0>
 static void launch_one(int grid, hipStream_t stream, const TapConvParams* dparams) {
   const size_t lds = conv_lds_bytes(BN);
   static bool attr_set = false;
   if (!attr_set) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT>),
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT>), dim3(grid), dim3(256), lds, stream, dparams);
+  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL>), dim3(grid), dim3(256), lds, stream, dparams);
 }
+
+#ifdef VFX_ABLATION_BUILD
+static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvParams* dparams) {
+  switch (abl) {
+    case 1: launch_one<128, false, true, 1>(grid, stream, dparams); return true;
+    case 2: launch_one<128, false, true, 2>(grid, stream, dparams); return true;
+    case 4: launch_one<128, false, true, 4>(grid, stream, dparams); return true;
+    case 8: launch_one<128, false, true, 8>(grid, stream, dparams); return true;
+    case 16: launch_one<128, false, true, 16>(grid, stream, dparams); return true;
+    case 32: launch_one<128, false, true, 32>(grid, stream, dparams); return true;
+    case 7: launch_one<128, false, true, 7>(grid, stream, dparams); return true;
+    case 23: launch_one<128, false, true, 23>(grid, stream, dparams); return true;
+    case 55: launch_one<128, false, true, 55>(grid, stream, dparams); return true;
+    default: return false;
+  }
+}
+#endif
 
 template <bool ELU, bool SPLIT>
 static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams* dparams) {
@@ -349,6 +483,10 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
   const int BN = conv_block_n(hp.Cout);
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w * (hp.Cout / BN);
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "conv: bad grid");
+#ifdef VFX_ABLATION_BUILD
+  static const int abl = getenv("VFX_ABLATE") ? atoi(getenv("VFX_ABLATE")) : 0;
+  if (abl && hp.split && !elu && BN == 128 && launch_ablated(abl, (int)grid, stream, dparams)) return;
+#endif
   if (hp.split) {
     if (elu) launch_bn<true, true>(BN, (int)grid, stream, dparams);
     else launch_bn<false, true>(BN, (int)grid, stream, dparams);

@@ -1,20 +1,28 @@
-// conv_epilogue.h -- shared epilogue of k_tapconv / k_patchconv.
+// conv_epilogue.h -- epilogue of k_conv.
 //
 // The 32x32 MFMA accumulator fragments go through LDS (re-using the staging buffers) so that the
-// residual read and the output write are 16-byte-per-lane, row-contiguous accesses.  All residual
+// residual read and the output writes are 16-byte-per-lane, row-contiguous accesses.  All residual
 // loads of a thread are issued first, all results are formed in registers, and only then are the
 // stores issued back-to-back: on gfx950 vmcnt also counts stores, so a store placed between two
 // waited loads would serialise on the previous store's acknowledgement.
+//
+// Two outputs, either optional: the raw fp32 tensor, and the ACTIVATED tensor for a consumer
+// convolution (TapConvParams::out_act): y -> affine -> LeakyReLU / ELU -> (split-bf16: hi | lo).  In
+// split mode a lane pair (8 consecutive channels) swaps halves through DPP so that the even lane
+// stores the 8 hi values and the odd lane the 8 lo values, 16 bytes each.
 #pragma once
 #include "vfx_internal.h"
 
 namespace vfx {
 
 typedef float ce_f32x4 __attribute__((ext_vector_type(4)));
+typedef float ce_f32x2 __attribute__((ext_vector_type(2)));
 typedef float ce_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned ce_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 ce_bf16x2 __attribute__((ext_vector_type(2)));
 #define VFX_CE_GLOBAL __attribute__((address_space(1)))
 
-template <int BN, int WM, int WN, int WAVES_N>
+template <int BN, int WM, int WN, int WAVES_N, bool SPLIT>
 __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* smem, const int* otab,
                                               ce_f32x16 (&acc)[WM][WN], int n0) {
   constexpr int LDO = BN + 4;  // staged row length (floats), keeps 16-byte alignment
@@ -25,7 +33,7 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
-  __syncthreads();  // every wave is done reading the last K step
+  __syncthreads();  // every wave is done reading the last stage
   // C/D layout of the 32x32 MFMA: col = lane & 31 (-> cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 #pragma unroll
   for (int a = 0; a < WM; ++a)
@@ -57,9 +65,48 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) val[q] += res[q];
   }
+  if (p.out) {
 #pragma unroll
-  for (int q = 0; q < NPASS; ++q)
-    if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out + (int64_t)opix[q] * Cout + ncol) = val[q];
+    for (int q = 0; q < NPASS; ++q)
+      if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out + (int64_t)opix[q] * Cout + ncol) = val[q];
+  }
+  if (p.out_act) {
+    ce_f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+    if (p.act_scale) asc = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_scale + ncol);
+    if (p.act_shift) ash = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_shift + ncol);
+    const float slope = p.act_slope;
+    const bool elu = p.act_elu != 0;
+    const bool even = (tid & 1) == 0;
+    // split: the pair's 8 channels live in chunk ncol/32; hi block at +0, lo block at +16 floats, 8 channels = 4 floats
+    const int aoff = SPLIT ? (ncol & ~31) + ((ncol & 31) >> 3) * 4 + (even ? 0 : 16) : ncol;
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      ce_f32x4 u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = val[q][e] * asc[e] + ash[e];
+        u[e] = elu ? (t > 0.f ? t : expm1f(t)) : fmaxf(t, t * slope);
+      }
+      ce_f32x4 o;
+      if constexpr (SPLIT) {
+        const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[0], u[1]}, ce_bf16x2));
+        const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[2], u[3]}, ce_bf16x2));
+        const ce_f32x2 r01 = {u[0] - __builtin_bit_cast(float, h01 << 16), u[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+        const ce_f32x2 r23 = {u[2] - __builtin_bit_cast(float, h23 << 16), u[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+        const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, ce_bf16x2));
+        const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, ce_bf16x2));
+        // quad_perm [1,0,3,2]: swap with the neighbouring lane (the other half of the 8-channel group)
+        const unsigned s0 = even ? l01 : h01, s1 = even ? l23 : h23;
+        const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, false);
+        const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, false);
+        const ce_u32x4 w = even ? ce_u32x4{h01, h23, g0, g1} : ce_u32x4{g0, g1, l01, l23};
+        o = __builtin_bit_cast(ce_f32x4, w);
+      } else {
+        o = u;
+      }
+      if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * Cout + aoff) = o;
+    }
+  }
 }
 
 }  // namespace vfx

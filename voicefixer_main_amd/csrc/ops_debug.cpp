@@ -65,6 +65,7 @@ extern "C" int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, i
     p.bias = bias ? sc.blob.upload(bias, Cout) : nullptr;
     p.residual = residual;
     p.out = y;
+    p.act_slope = 1.f;
     run_one(h, p, sc.blob, s);
     VFX_HIP(hipStreamSynchronize(s));
   } catch (const vfx::Error&) {

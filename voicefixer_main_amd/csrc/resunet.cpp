@@ -200,6 +200,7 @@ struct TrunkBuilder {
     p.Wi = p.Wg = p.Wo = geo.W;
     p.Cout = Cout;
     p.sh = p.sw = 1;
+    p.act_slope = 1.f;
     p.out = const_cast<float*>(rel_ptr(out_off));
     return p;
   }
@@ -229,6 +230,12 @@ struct TrunkBuilder {
         set_taps3x3(S);
         coff += srcs[s].C;
       }
+      // h feeds conv2 only: store it ACTIVATED (bn2 affine + LeakyReLU applied once per element, operand form)
+      p.out_act = p.out;
+      p.out = nullptr;
+      p.act_scale = w.bn2_scale;
+      p.act_shift = w.bn2_shift;
+      p.act_slope = kSlope;
       pb.add_conv(p);
     }
     Act4 y = make(g.H, g.W, w.cout);
@@ -236,10 +243,16 @@ struct TrunkBuilder {
     TapSeg& S0 = p.seg[0];
     S0.src = rel_ptr(hbuf.off);
     S0.C = w.cout;
-    S0.scale = w.bn2_scale;
-    S0.shift = w.bn2_shift;
-    S0.act = ACT_LEAKY;
-    S0.slope = kSlope;
+    if (pre_h) {  // h of the Cin = 1 entry block comes raw from k_conv_c1
+      S0.scale = w.bn2_scale;
+      S0.shift = w.bn2_shift;
+      S0.act = ACT_LEAKY;
+      S0.slope = kSlope;
+    } else {
+      S0.src_act = 1;
+      S0.act = ACT_NONE;
+      S0.slope = 1.f;
+    }
     S0.wt = w.w2;
     set_taps3x3(S0);
     p.nseg = 1;
@@ -299,6 +312,7 @@ struct TrunkBuilder {
         p.Hg = (y.H - a + 1) / 2;
         p.Wg = (y.W - b + 1) / 2;
         p.out = const_cast<float*>(rel_ptr(y.off));
+        p.act_slope = 1.f;
         p.nseg = 1;
         TapSeg& S = p.seg[0];
         S.src = rel_ptr(x.off);

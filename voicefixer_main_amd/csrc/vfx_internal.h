@@ -62,6 +62,7 @@ struct TapSeg {
   int ntaps;
   int act;
   float slope;
+  int src_act;         // 1: src is an ACTIVATED tensor (see TapConvParams::out_act): staged by plain copy, no prologue
   int dh[kMaxTaps];
   int dw[kMaxTaps];
 };
@@ -78,7 +79,8 @@ struct ConvStage {
   int ntaps;
   float slope;         // LeakyReLU slope of the prologue (1 = identity, 0 = ReLU)
   int tap_stride;      // floats between the weights of consecutive taps (Cout * 32)
-  int pad_[2];
+  int flags;           // bit 0: src is an activated tensor (LDS-DMA copy, no prologue)
+  unsigned nbytes;     // bytes addressable from src (buffer descriptor bound; reads past it return 0)
   int poff[16];        // patch row offset of every tap (kMaxTaps used)
 };
 static_assert(sizeof(ConvStage) == 128, "ConvStage is read as a 128-byte record");
@@ -92,7 +94,12 @@ struct TapConvParams {
   int Ho, Wo, Cout;      // output tensor (B, Ho, Wo, Cout)
   int sh, sw, oh0, ow0;  // grid (i, j) -> output pixel (i*sh + oh0, j*sw + ow0), masked to Ho x Wo
   int reflect_w;         // reflect addressing along W (ReflectionPad1d) instead of zero padding
-  int M;                 // B * Hg * Wg
+  // Folded 1-D geometry (Conv1d with dilation d viewed as a 2-D convolution with VERTICAL taps on the
+  // sequence reshaped to rows of d samples): pixel (i, j) of image b is element b * img_stride + i * W + j
+  // and exists iff i * W + j < limit.  0 = plain 2-D tensors (img_stride = limit = H * W); set by finish_params.
+  int in_img_stride, in_limit;
+  int out_img_stride, out_limit;
+  int M;                 // output pixels of the launch (B * Hg * Wg, or B * out_limit when folded)
   int split;             // 1 = split-bf16 operand mode, 0 = exact fp32
   // tile / patch geometry (plan_conv): the M tile is a TH x TW block of the logical grid of one image,
   // every stage stages a PH x PW patch (P = PH * PW <= kPatchMaxRows pixels).
@@ -105,7 +112,16 @@ struct TapConvParams {
   const ConvStage* stages;  // device table (bind time)
   const float* bias;     // [Cout] or nullptr
   const float* residual; // (B, Ho, Wo, Cout) or nullptr, added in the epilogue
-  float* out;
+  float* out;            // raw fp32 output (B, Ho, Wo, Cout) or nullptr
+  // Optional ACTIVATED output for a tensor whose only consumer is the next convolution: the epilogue
+  // applies that consumer's prologue (per-channel affine, LeakyReLU / ELU) once per element and stores
+  // the MFMA operand form, same size as fp32: per pixel and 32-channel chunk [32 hi bf16 | 32 lo bf16]
+  // in split-bf16 mode, 32 activated floats in fp32 mode.  The consumer stages it by plain copy.
+  float* out_act;
+  const float* act_scale;  // [Cout] or nullptr (=1)
+  const float* act_shift;  // [Cout] or nullptr (=0)
+  float act_slope;         // LeakyReLU slope in [0, 1] (1 = identity)
+  int act_elu;             // 1: ELU instead of LeakyReLU
 };
 
 void finish_params(TapConvParams& p);  // fills total_steps, M and the tile / patch geometry, validates

@@ -131,43 +131,64 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     });
   }
 
+  // `src_act`: src is an activated tensor (its prologue was applied by the producer's epilogue);
+  // `next_act` != ACT_NONE: the output feeds one convolution only -> store it activated with that prologue.
   auto conv1d = [&](const VocConvW& cw, size_t src, int Tlen, int K, int dil, int act, float slope, bool reflect,
-                    const size_t* residual) -> size_t {
+                    const size_t* residual, bool src_act = false, int next_act = ACT_NONE,
+                    float next_slope = 1.f) -> size_t {
     const size_t out = pb.alloc_f((int64_t)B * Tlen * cw.cout);
     TapConvParams p{};
     p.B = B;
-    p.Hi = p.Hg = p.Ho = 1;
-    p.Wi = p.Wg = p.Wo = Tlen;
+    // A dilation too wide for one patch (> 48 samples for k3) is folded: the sequence becomes an image
+    // with rows of `dil` samples and the taps become vertical neighbours (TapConvParams, folded geometry).
+    const bool fold = !reflect && (K - 1) * dil + 128 > kPatchMaxRows && dil >= 16;
+    if (fold) {
+      p.Hi = p.Hg = p.Ho = (Tlen + dil - 1) / dil;
+      p.Wi = p.Wg = p.Wo = dil;
+      p.in_img_stride = p.in_limit = p.out_img_stride = p.out_limit = Tlen;
+    } else {
+      p.Hi = p.Hg = p.Ho = 1;
+      p.Wi = p.Wg = p.Wo = Tlen;
+    }
     p.Cout = cw.cout;
     p.sh = p.sw = 1;
     p.reflect_w = reflect ? 1 : 0;
     p.bias = cw.bias;
     p.residual = residual ? rel_ptr(*residual) : nullptr;
-    p.out = const_cast<float*>(rel_ptr(out));
+    p.act_slope = 1.f;
+    if (next_act == ACT_NONE) {
+      p.out = const_cast<float*>(rel_ptr(out));
+    } else {
+      p.out_act = const_cast<float*>(rel_ptr(out));
+      p.act_slope = next_slope;
+      p.act_elu = next_act == ACT_ELU;
+    }
     p.nseg = 1;
     TapSeg& S = p.seg[0];
     S.src = rel_ptr(src);
     S.C = cw.cin;
-    S.act = act;
-    S.slope = slope;
+    S.act = src_act ? ACT_NONE : act;
+    S.slope = src_act ? 1.f : slope;
+    S.src_act = src_act ? 1 : 0;
     S.wt = cw.w;
     S.ntaps = K;
     for (int k = 0; k < K; ++k) {
-      S.dh[k] = 0;
-      S.dw[k] = (k - K / 2) * dil;
+      S.dh[k] = fold ? k - K / 2 : 0;
+      S.dw[k] = fold ? 0 : (k - K / 2) * dil;
     }
     pb.add_conv(p);
     return out;
   };
 
-  // condnet: Conv1d k3 + ELU, the ELU applied as the consumer's prologue
+  // condnet: Conv1d k3 + ELU; every output feeds exactly one convolution, so the ELU (and the
+  // LeakyReLU in front of the first upsampler) is applied by the producer's epilogue
   for (size_t i = 0; i < W->cond.size(); ++i) {
-    const size_t y = conv1d(W->cond[i], x, Tp, 3, 1, i == 0 ? ACT_NONE : ACT_ELU, 1.f, false, nullptr);
+    const size_t y = conv1d(W->cond[i], x, Tp, 3, 1, ACT_NONE, 1.f, false, nullptr, /*src_act=*/i > 0, ACT_ELU, 1.f);
     pb.free(x);
     x = y;
   }
-  {  // ReflectionPad1d(3) + Conv1d k7 on ELU(condnet output)
-    const size_t y = conv1d(W->pre, x, Tp, 7, 1, ACT_ELU, 1.f, true, nullptr);
+  {  // ReflectionPad1d(3) + Conv1d k7 on ELU(condnet output); its output is read by upsampler 0 only
+    const size_t y = conv1d(W->pre, x, Tp, 7, 1, ACT_ELU, 1.f, true, nullptr, /*src_act=*/true, ACT_LEAKY, cfg.voc_up_slope);
     pb.free(x);
     x = y;
   }
@@ -189,12 +210,14 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
       p.ow0 = r;
       p.bias = up.bias;
       p.out = const_cast<float*>(rel_ptr(y));
+      p.act_slope = 1.f;
       p.nseg = 1;
       TapSeg& S = p.seg[0];
       S.src = rel_ptr(x);
       S.C = up.cin;
-      S.act = ACT_LEAKY;
-      S.slope = cfg.voc_up_slope;
+      S.act = st == 0 ? ACT_NONE : ACT_LEAKY;  // stage 0 reads the activated output of the k7 convolution
+      S.slope = st == 0 ? 1.f : cfg.voc_up_slope;
+      S.src_act = st == 0 ? 1 : 0;
       S.wt = up.w_phase[r];
       S.ntaps = 0;
       for (auto& ek : phase_taps(s, pad, r)) {
@@ -209,8 +232,9 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     Tlen = Tout;
     int dil = 1;
     for (auto& layer : W->res[st]) {
-      const size_t hbuf = conv1d(layer.first, x, Tlen, 3, dil, ACT_LEAKY, cfg.voc_res_slope, false, nullptr);
-      const size_t y2 = conv1d(layer.second, hbuf, Tlen, 3, 1, ACT_LEAKY, cfg.voc_res_slope, false, &x);
+      const size_t hbuf = conv1d(layer.first, x, Tlen, 3, dil, ACT_LEAKY, cfg.voc_res_slope, false, nullptr,
+                                 /*src_act=*/false, ACT_LEAKY, cfg.voc_res_slope);
+      const size_t y2 = conv1d(layer.second, hbuf, Tlen, 3, 1, ACT_LEAKY, cfg.voc_res_slope, false, &x, /*src_act=*/true);
       pb.free(hbuf);
       pb.free(x);
       x = y2;
