@@ -802,7 +802,7 @@ int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_ou
   auto plan = get_plan(h, key_of("restore_gsr", B, T, unify), [&](PlanBuilder& pb) {
     const int64_t nmel = (int64_t)B * T * 128;
     const size_t o_mel = pb.alloc_f(nmel), o_log = pb.alloc_f(nmel), o_den = pb.alloc_f(nmel);
-    const size_t o_long = pb.alloc_f((int64_t)B * Llong), o_ws = pb.alloc_f(2 * B + 64);
+    const size_t o_long = pb.alloc_f((int64_t)B * Llong), o_ws = pb.alloc_f(2 * B + 64), o_pk = pb.alloc_f(B + 64);
     vfx_handle* hh = pb.h;
     Plan* pl = pb.plan;
     // pre(): STFT -> magnitude -> mel (eval_gsr_voicefixer.py:19-25)
@@ -818,10 +818,11 @@ int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_ou
                       reinterpret_cast<float*>(pl->bound_base + o_ws), reinterpret_cast<float*>(pl->bound_base + o_den),
                       c.stream);
     });
-    build_vocoder(pb, B, T, arena_buf(o_den), arena_buf(o_long));
+    const BufRef peak_buf = arena_buf(o_pk);  // per-clip peak, produced by the vocoder tail
+    build_vocoder(pb, B, T, arena_buf(o_den), arena_buf(o_long), &peak_buf);
     pl->ops.push_back([=](const RunCtx& c) {
       launch_peak_trim(reinterpret_cast<float*>(pl->bound_base + o_long), B, Llong, L,
-                       reinterpret_cast<float*>(pl->bound_base + o_ws), c.ext[1], c.stream);
+                       reinterpret_cast<float*>(pl->bound_base + o_pk), /*have_peak=*/true, c.ext[1], c.stream);
     });
   });
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags, &h->prof};

@@ -20,7 +20,7 @@
 //             flattens every launch into a table of stages (ConvStage, vfx_internal.h).
 //
 // Operand paths
-//   A (activations): per stage the input PATCH (tile + halo of the stage's taps, <= 224 pixels x
+//   A (activations): per stage the input PATCH (tile + halo of the stage's taps, <= 192 pixels x
 //     128 bytes) goes into one of two LDS patch buffers; every tap reads its shifted window of it.
 //     - ACTIVATED sources (the producer's epilogue already applied this layer's prologue and
 //       stored the MFMA operand form, TapConvParams::out_act) are copied global -> LDS by the

@@ -217,48 +217,97 @@ void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_we
 }
 
 // ---------------------------------------------------------------------------------------------
-// Vocoder tail: LeakyReLU(slope) -> ReflectionPad1d(3) -> Conv1d(C -> 1, k7) -> tanh.
-// 8 lanes per output sample, C/8 channels each, rows re-read through L1 (each row serves 7 outputs).
+// Vocoder tail: LeakyReLU(slope) -> ReflectionPad1d(3) -> Conv1d(C -> 1, k7) -> tanh, plus the per-clip
+// peak |wave| the handler's peak normalisation needs (eval_gsr_voicefixer.py:68-70), so that the
+// waveform is not read a second time.
+// HBM-bound (C * 4 bytes in, 4 bytes out per sample).  A group of 8 lanes owns 8 consecutive output
+// samples and C/8 channels per lane: the 14 input rows the 8 outputs touch are loaded once (16 bytes per
+// lane and row piece), the 7 x C/8 taps of the lane sit in registers, and the 8 partial sums are
+// completed with three DPP-sized xor shuffles each.  One atomicMax per block for the peak.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, int T, int C,
-                                                    const float* __restrict__ w /*[7][C]*/, float bias, float slope,
-                                                    int64_t total, float* __restrict__ wav) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t q = gid >> 3;
-  const int g = gid & 7;
-  const bool active = q < total;
-  float acc = 0.f;
-  if (active) {
-    const int t = q % T;
-    const float* xb = x + (q - t) * C;
-    const int cpl = C >> 3;  // channels per lane (multiple of 4)
-    for (int k = 0; k < 7; ++k) {
-      int tt = t + k - 3;
+template <int CPL>  // channels per lane = C / 8 (4, 8 or 16)
+__global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, int T, const float* __restrict__ w /*[7][C]*/,
+                                                    float bias, float slope, float* __restrict__ wav,
+                                                    unsigned* __restrict__ peak /*[B] or null*/) {
+  constexpr int C = 8 * CPL;
+  const int b = blockIdx.y;
+  const int grp = threadIdx.x >> 3, g = threadIdx.x & 7;
+  const int t0 = (blockIdx.x * 32 + grp) * 8;  // first output sample of the group
+  const float* xb = x + (int64_t)b * T * C + g * CPL;
+  float wk[7][CPL];
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int c = 0; c < CPL; c += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(w + k * C + g * CPL + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wk[k][c + e] = v[e];
+    }
+  float acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+  if (t0 < T) {
+#pragma unroll
+    for (int r = 0; r < 14; ++r) {  // input row t0 - 3 + r feeds output o with tap k = r - o
+      int tt = t0 - 3 + r;
       tt = tt < 0 ? -tt : tt;
       tt = tt >= T ? 2 * (T - 1) - tt : tt;
-      const float* row = xb + (int64_t)tt * C + g * cpl;
-      const float* wr = w + k * C + g * cpl;
-      for (int c = 0; c < cpl; c += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(row + c);
-        const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + c);
+      tt = tt < 0 ? 0 : tt;  // only rows of masked outputs (t >= T) can get here
+      float v[CPL];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = a[e] >= 0.f ? a[e] : a[e] * slope;
-          acc = fmaf(v, ww[e], acc);
+      for (int c = 0; c < CPL; c += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xb + (int64_t)tt * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c + e] = a[e] >= 0.f ? a[e] : a[e] * slope;
+      }
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const int k = r - o;
+        if (k >= 0 && k < 7) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[o] = fmaf(v[c], wk[k][c], acc[o]);
         }
       }
     }
   }
-  acc += __shfl_xor(acc, 1);
-  acc += __shfl_xor(acc, 2);
-  acc += __shfl_xor(acc, 4);
-  if (active && g == 0) wav[q] = tanhf(acc + bias);
+  float mine = 0.f;  // lane g finishes output t0 + g
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    float s = acc[o];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    mine = g == o ? s : mine;
+  }
+  const int t = t0 + g;
+  float m = 0.f;
+  if (t < T) {
+    const float y = tanhf(mine + bias);
+    wav[(int64_t)b * T + t] = y;
+    m = fabsf(y);
+  }
+  if (peak) {
+    __shared__ float wmax[4];
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      if (m > 0.f) atomicMax(peak + b, __float_as_uint(m));  // |y| >= 0: the uint order is the float order
+    }
+  }
 }
 
 void launch_voc_final(const float* x, int B, int T, int C, const float* w, float bias, float slope, float* wav,
-                      hipStream_t s) {
-  const int64_t total = (int64_t)B * T;
-  hipLaunchKernelGGL(k_voc_final, dim3(nblocks(total * 8, 256)), dim3(256), 0, s, x, T, C, w, bias, slope, total, wav);
+                      unsigned* peak, hipStream_t s) {
+  const dim3 grid((T + 255) / 256, B);
+  if (peak) VFX_HIP(hipMemsetAsync(peak, 0, sizeof(unsigned) * B, s));
+  switch (C) {
+    case 32: hipLaunchKernelGGL(k_voc_final<4>, grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+    case 64: hipLaunchKernelGGL(k_voc_final<8>, grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+    case 128: hipLaunchKernelGGL(k_voc_final<16>, grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+    default: VFX_CHECK(false, "vocoder tail: %d channels are not supported (32, 64 or 128)", C);
+  }
   VFX_HIP(hipGetLastError());
 }
 
@@ -331,10 +380,14 @@ __global__ void k_trim_scale(const float* __restrict__ x, int64_t Llong, int L, 
   out[(int64_t)b * L + n] = p > 1.0f ? v / p : v;
 }
 
-void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, float* out, hipStream_t s) {
-  VFX_HIP(hipMemsetAsync(ws, 0, sizeof(unsigned) * B, s));
-  const int gx = (int)std::min<int64_t>(1024, (Llong + 255) / 256);
-  hipLaunchKernelGGL(k_absmax, dim3(gx, B), dim3(256), 0, s, wav_long, Llong, reinterpret_cast<unsigned*>(ws));
+// `have_peak`: ws[b] already holds the peak of clip b (written by the vocoder tail).
+void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, bool have_peak, float* out,
+                      hipStream_t s) {
+  if (!have_peak) {
+    VFX_HIP(hipMemsetAsync(ws, 0, sizeof(unsigned) * B, s));
+    const int gx = (int)std::min<int64_t>(64, (Llong + 255) / 256);
+    hipLaunchKernelGGL(k_absmax, dim3(gx, B), dim3(256), 0, s, wav_long, Llong, reinterpret_cast<unsigned*>(ws));
+  }
   const int64_t diff = Llong - L;
   const int off = (int)(diff / 2);
   hipLaunchKernelGGL(k_trim_scale, dim3((L + 255) / 256, B), dim3(256), 0, s, wav_long, Llong, L, off,

@@ -46,7 +46,7 @@ constexpr int kMaxTaps = 9;
 constexpr int kMaxSegs = 3;
 constexpr int kKC = 32;             // input channels per K step
 constexpr int kIdentityLen = 4096;  // length of the identity scale/shift tables
-constexpr int kPatchMaxRows = 224;  // patch pixels per stage (7 row groups of 32)
+constexpr int kPatchMaxRows = 192;  // patch pixels per stage (6 row groups of 32)
 
 enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_ELU = 2 };
 
@@ -162,10 +162,11 @@ void launch_final_1x1(const float* y, int B, int Tpad, int W, const float* w32, 
 void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_weight, float amp_floor, float min_db,
                      float range, float* cond, hipStream_t s);
 void launch_voc_final(const float* x, int B, int T, int C, const float* w, float bias, float slope, float* wav,
-                      hipStream_t s);
+                      unsigned* peak, hipStream_t s);
 void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int unify, float* sums, float* mel_out,
                      hipStream_t s);
-void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, float* out, hipStream_t s);
+void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, bool have_peak, float* out,
+                      hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // handle-side data structures
@@ -334,6 +335,6 @@ struct BufRef {
 };
 void build_unet_mel(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef logmel_out);
 void build_unet_spec(PlanBuilder& pb, int B, int T, BufRef sp, BufRef cosb, BufRef sinb, BufRef re_out, BufRef im_out);
-void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_out);
+void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_out, const BufRef* peak = nullptr);
 int64_t vocoder_out_len(const vfx_config& cfg, int T);
 }  // namespace vfx

@@ -110,7 +110,7 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
   return W;
 }
 
-void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_out) {
+void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_out, const BufRef* peak) {
   VFX_CHECK(pb.h->voc, "vocoder weights are not finalized");
   const vfx_config cfg = pb.h->cfg;
   const VocoderWeights* W = pb.h->voc.get();
@@ -244,9 +244,12 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
   {
     const size_t xo = x;
     const int Tl = Tlen;
+    const bool want_peak = peak != nullptr;
+    const BufRef pk = peak ? *peak : BufRef{};
     pl->ops.push_back([=](const RunCtx& c) {
       launch_voc_final(reinterpret_cast<const float*>(pl->bound_base + xo), B, Tl, W->final_c, W->final_w, W->final_b,
-                       cfg.voc_up_slope, resolve(c, wav_out), c.stream);
+                       cfg.voc_up_slope, resolve(c, wav_out), want_peak ? reinterpret_cast<unsigned*>(resolve(c, pk)) : nullptr,
+                       c.stream);
     });
   }
   pb.free(x);
