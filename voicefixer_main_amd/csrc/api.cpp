@@ -362,6 +362,38 @@ void PlanBuilder::add_conv(TapConvParams p) {
   });
 }
 
+void PlanBuilder::add_resblock(ResBlockParams p) {
+  plan_resblock(p);
+  const size_t idx = plan->host_rb.size();
+  plan->host_rb.push_back(p);
+  plan->conv_flops += resblock_flops(p);
+  plan->n_conv += 1;
+  Plan* pl = plan;
+  plan->ops.push_back([pl, idx](const RunCtx& c) {
+    const ResBlockParams& hp = pl->host_rb[idx];
+    if (c.prof && c.prof->enabled) {
+      hipEvent_t a, b;
+      VFX_HIP(hipEventCreate(&a));
+      VFX_HIP(hipEventCreate(&b));
+      VFX_HIP(hipEventRecord(a, c.stream));
+      launch_resblock(hp, pl->dev_rb + idx, c.stream);
+      VFX_HIP(hipEventRecord(b, c.stream));
+      c.prof->events.push_back({a, b});
+      c.prof->flops.push_back(resblock_flops(hp));
+      c.prof->bn.push_back(hp.C);
+      TapConvParams d{};
+      d.M = hp.B * hp.T;
+      d.Cout = hp.C;
+      d.Wi = hp.dil;
+      d.seg[0].C = hp.C;
+      d.seg[0].ntaps = 6;
+      c.prof->desc.push_back(d);
+    } else {
+      launch_resblock(hp, pl->dev_rb + idx, c.stream);
+    }
+  });
+}
+
 static char* ensure_arena(vfx_handle* h, size_t bytes) {
   if (bytes <= h->arena_bytes) return h->arena;
   VFX_HIP(hipDeviceSynchronize());
@@ -380,7 +412,7 @@ static char* ensure_arena(vfx_handle* h, size_t bytes) {
 // the parameter blocks.
 void bind_plan(vfx_handle* h, Plan& plan) {
   char* base = ensure_arena(h, plan.arena_bytes);
-  if (plan.bound_base == base && plan.dev_params) return;
+  if (plan.bound_base == base && (plan.dev_params || plan.dev_rb || (plan.host_params.empty() && plan.host_rb.empty()))) return;
   std::vector<TapConvParams> abs = plan.host_params;
   auto rebase = [&](const float* rel) -> const float* {
     return reinterpret_cast<const float*>(base + reinterpret_cast<size_t>(rel) - 1);
@@ -406,6 +438,15 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     plan.dev_params = static_cast<TapConvParams*>(plan.blob.alloc(abs.size() * sizeof(TapConvParams)));
   if (!abs.empty())
     VFX_HIP(hipMemcpy(plan.dev_params, abs.data(), abs.size() * sizeof(TapConvParams), hipMemcpyHostToDevice));
+  if (!plan.host_rb.empty()) {
+    std::vector<ResBlockParams> rb = plan.host_rb;
+    for (auto& q : rb) {
+      q.x = rebase(q.x);
+      q.y = const_cast<float*>(rebase(q.y));
+    }
+    if (!plan.dev_rb) plan.dev_rb = static_cast<ResBlockParams*>(plan.blob.alloc(rb.size() * sizeof(ResBlockParams)));
+    VFX_HIP(hipMemcpy(plan.dev_rb, rb.data(), rb.size() * sizeof(ResBlockParams), hipMemcpyHostToDevice));
+  }
   plan.bound_base = base;
 }
 

@@ -43,50 +43,11 @@
 //      v_mfma_f32_32x32x16_bf16, fp32 accumulate (~2^-16 relative operand error);
 //   0: exact fp32 on v_mfma_f32_32x32x2_f32.
 //   Plain bf16 / fp16 operands miss the "log-mel L1 <= 1e-3" bar of the reference.
+#include "conv_common.h"
 #include "conv_epilogue.h"
 #include "vfx_internal.h"
 
 namespace vfx {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int CBM = 128;                     // pixels per tile
-constexpr int CROW = 128;                    // bytes per patch row (32 channels)
-constexpr int CNQ = kPatchMaxRows / 32;      // patch row groups (one DMA instruction / register group each)
-constexpr int CPATCH = kPatchMaxRows * CROW; // bytes per patch buffer
-
-#define VFX_GLOBAL __attribute__((address_space(1)))
-#define VFX_LDS __attribute__((address_space(3)))
-#define VFX_CONST __attribute__((address_space(4)))
-
-// One weight fragment group = the four 16-byte-per-lane fragments of a (tap, 32-channel chunk, 32 couts).
-struct BFrag {
-  f32x4 f[4];  // split: (hi, lo) of k 0..15, (hi, lo) of k 16..31; fp32: the four k8 groups
-};
-
-// Hidden from the compiler's s_waitcnt bookkeeping on purpose (see the file header): the destination
-// registers are only valid after wait_b<N>() with N = number of VMEM operations issued after this load.
-__device__ __forceinline__ void load_b_asm(BFrag& R, const float* wtap, unsigned voff) {
-  asm volatile(
-      "s_nop 4\n\t"
-      "global_load_dwordx4 %0, %4, %5\n\t"
-      "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
-      "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
-      "global_load_dwordx4 %3, %4, %5 offset:3072"
-      : "=&v"(R.f[0]), "=&v"(R.f[1]), "=&v"(R.f[2]), "=&v"(R.f[3])
-      : "v"(voff), "s"(wtap)
-      : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_b(BFrag& R) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R.f[0]), "+v"(R.f[1]), "+v"(R.f[2]), "+v"(R.f[3]) : "n"(N) : "memory");
-  __builtin_amdgcn_sched_barrier(0);  // nothing that reads R may be scheduled above the wait
-}
 
 // ABL != 0: timing-only ablation builds (-DVFX_ABLATION_BUILD + VFX_ABLATE, wrong results), in the stage loop:
 // bit 0 no patch request, 1 no weight loads, 2 no barrier, 3 constant fragment addresses, 4 no fragment reads,

@@ -1,0 +1,390 @@
+// resblock.hip -- one fused TFGAN ResStack layer (oracle/vocoder.py, layer table in vfx_config):
+//
+//     y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2      conv1: k3, dilation d;  conv2: k3, dilation 1
+//
+// for the channel counts whose unfused form is HBM-bound (C = 64, 128; 44.1 kHz and 14.7 kHz stacks).
+// The two convolutions of a layer move 20 bytes per element through HBM as separate launches (x, h
+// written and re-read, the residual); fused, h never leaves the CU: 8 bytes per element.
+//
+// Tile = up to 128 positions of h (= conv1 output incl. the +-1 halo conv2 needs) of ONE clip:
+//   * d <= 32: 128 consecutive positions, 126 outputs; x patch = 128 + 2d consecutive positions;
+//   * d  > 32: "folded" -- the sequence is viewed as rows of d samples, conv1's taps become vertical
+//     neighbours: h tile = TH x (TW + 2) positions (7 x 18), outputs TH x TW, x patch (TH+2) x (TW+2).
+//     A position is just row*d + col, so a column index of -1 or d is simply the neighbouring row.
+// Phases (one block = 4 waves, wave = (128 / WAVES_M) h rows x 32 channels, all C output channels per block):
+//   1. conv1: per 32-channel chunk the raw x patch arrives by LDS-DMA (zero fill by the buffer bound),
+//      is turned into MFMA operand form in place (LeakyReLU, hi/lo split, swizzled slots) and read by the
+//      three taps -- same machinery as k_conv (conv.hip), statically scheduled here;
+//   2. h = LeakyReLU(acc + b1), zero outside the sequence, written to LDS in operand form;
+//   3. conv2: A fragments straight from the LDS-resident h, no staging, no barriers;
+//   4. epilogue: + b2 + x (residual, L2-hot), fp32 rows of 16 bytes per lane.
+// Weights as in k_conv: fragment order, global -> VGPR ring, inline-asm loads with hand-counted vmcnt.
+// Arithmetic: split-bf16 only (precision 1); the fp32 mode keeps the two-launch plan.
+#include "conv_common.h"
+#include "vfx_internal.h"
+
+namespace vfx {
+
+// n is a compile-time constant after unrolling; only these counts occur
+__device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
+  switch (n) {
+    case 4: wait_b<4>(R); break;
+    case 8: wait_b<8>(R); break;
+    case 4 + CNQ: wait_b<4 + CNQ>(R); break;
+    case 8 + CNQ: wait_b<8 + CNQ>(R); break;
+    default: wait_b<0>(R); break;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256, C == 64 ? 2 : 1) void k_resblock(const ResBlockParams* __restrict__ pp) {
+  constexpr int NCH = C / 32;  // 32-channel chunks = waves along N
+  constexpr int WAVES_N = NCH, WAVES_M = 4 / WAVES_N, WM = 4 / WAVES_M;  // C = 64: 2, 2, 2;  C = 128: 4, 1, 4
+  constexpr int RING = WM >= 4 ? 2 : 3, AHEAD = RING - 1;
+  constexpr int HROW = C * 4;         // bytes per h row
+  constexpr int H_OFF = 2 * CPATCH;   // h buffer behind the two patch buffers
+  constexpr int NT1 = 3 * NCH;        // taps of conv1 (chunk-major); conv2 has as many
+  constexpr int LDO = C + 4;          // staged output row (floats)
+  constexpr int OTAB_OFF = CBM * LDO * 4;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds = reinterpret_cast<char*>(smem);
+
+  const ResBlockParams& p = *pp;
+  const int tid = threadIdx.x;
+  int tile;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tj = tile % p.tiles_w;
+  const int ti = (tile / p.tiles_w) % p.tiles_h;
+  const int img = tile / (p.tiles_w * p.tiles_h);
+  const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
+  const int rowstride = p.fold ? d : 0;
+  const int j0 = tj * p.TWo;  // first output column (folded) / position (1-D) of the tile
+  const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
+  const int base_x = base_h - d;                                // position of x patch pixel (0, 0)
+  const float slope = p.slope;
+
+  const int lr = tid >> 3, cg = tid & 7;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int wm = wave_u / WAVES_N, wn = wave_u % WAVES_N;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int key_l = (lr >> 1) & 7;
+
+  // ---- per-thread tables ------------------------------------------------------------------------------
+  // x patch pixel lr + 32q -> byte offset in x (chunk 0) / validity
+  unsigned voff[CNQ];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int q = 0; q < CNQ; ++q) {
+    const int prow = lr + 32 * q;
+    const int pi = prow / PW, pj = prow - pi * PW;
+    const int pos = base_x + pi * rowstride + pj;
+    const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
+    voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 4);
+    okmask |= ok ? (1u << q) : 0u;
+  }
+  // h pixel m -> inside the tile's h grid and inside the sequence (temporary table in the h region)
+  if (tid < CBM) {
+    const int li = tid / W1, lj = tid - li * W1;
+    const int pos = base_h + li * rowstride + lj;
+    reinterpret_cast<int*>(lds + H_OFF)[tid] = (li < TH) & ((unsigned)pos < (unsigned)T);
+  }
+  __syncthreads();
+  int arow1[WM], arow2[WM];  // A row of this lane's h pixel: in the x patch (tap offset added) / in the h buffer
+  unsigned long long hbits = 0;  // bit a*16 + r: h pixel of accumulator element (a, r) is valid
+#pragma unroll
+  for (int a = 0; a < WM; ++a) {
+    const int ml = (wm * WM + a) * 32 + l31;
+    const int li = ml / W1;
+    arow1[a] = li < TH ? li * PW + (ml - li * W1) : 0;
+    arow2[a] = ml;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (reinterpret_cast<const int*>(lds + H_OFF)[m]) hbits |= 1ull << (a * 16 + r);
+    }
+  }
+  const unsigned nb_off = (unsigned)(wn * 1024 + lane * 4) * 4u;
+  const int64_t ts = (int64_t)C * kKC;  // floats per tap of a weight tensor
+  const float b1v = p.b1[wn * 32 + l31];
+
+  f32x16 acc[WM];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  // ---- x patch: LDS-DMA request and in-place transform (cf. conv.hip) -------------------------------------
+  auto issue_patch = [&](int c, int dst) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + c * kKC), 0, (int)(unsigned)((int64_t)p.B * T * C * 4 - (int64_t)c * kKC * 4), 0x00020000);
+#pragma unroll
+    for (int q = 0; q < CNQ; ++q) {
+      const unsigned o = (okmask & (1u << q)) ? voff[q] + 16u * cg : 0xfffffff0u;
+      VFX_LDS void* l = (VFX_LDS void*)(lds + dst + (32 * q + 8 * wave_u) * CROW);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
+    }
+  };
+  const int nq = (P + 31) >> 5;
+  auto transform_patch = [&](int dst) __attribute__((always_inline)) {
+    char* row0 = lds + dst + lr * CROW;
+    f32x4 raw[CNQ];
+#pragma unroll
+    for (int q = 0; q < CNQ; ++q)
+      if (q < 4 || q < nq) raw[q] = *reinterpret_cast<const f32x4*>(row0 + 32 * q * CROW + 16 * cg);
+#pragma unroll
+    for (int q = 0; q < CNQ; ++q)
+      if (q < 4 || q < nq) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[q][e], raw[q][e] * slope);  // LeakyReLU(0) = 0: DMA zero fill stays zero
+        const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+        const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+        const f32x2 r01 = {v[0] - __builtin_bit_cast(float, h01 << 16), v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+        const f32x2 r23 = {v[2] - __builtin_bit_cast(float, h23 << 16), v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+        const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
+        const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
+        char* rowp = row0 + 32 * q * CROW;
+        const int half = 8 * (cg & 1);
+        *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ key_l) << 4) + half) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ key_l) << 4) + half) = make_uint2(l01, l23);
+      }
+  };
+
+  // ---- MFMA step: 32 channels of one tap; A rows `row[a]` of an LDS image with `stride` bytes per row ------
+  auto mma = [&](const BFrag& R, const char* img_base, int stride, const int (&row)[WM]) __attribute__((always_inline)) {
+    const char* base[WM];
+    int key[WM];
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      base[a] = img_base + row[a] * stride;
+      key[a] = swz_key(row[a]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, R.f[2 * s]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, R.f[2 * s + 1]);
+      bf16x8 ah[WM], al[WM];
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        ah[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
+        al[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((64 + 32 * s + 16 * lh) ^ key[a]));
+      }
+#pragma unroll
+      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a], 0, 0, 0);
+    }
+  };
+
+  // ---- weight ring: global tap g (conv1: 0 .. NT1-1, conv2: NT1 .. 2*NT1-1) in register group g % RING ------
+  BFrag R0, R1, R2;
+  auto ring = [&](int g) __attribute__((always_inline)) -> BFrag& { return g % RING == 0 ? R0 : (g % RING == 1 ? R1 : R2); };
+  auto fetch = [&](int g) __attribute__((always_inline)) {
+    const float* w = g < NT1 ? p.w1 + g * ts : (g < 2 * NT1 ? p.w2 + (g - NT1) * ts : p.w2 + (NT1 - 1) * ts);
+    load_b_asm(ring(g), w, nb_off);
+  };
+  auto drain = [&]() __attribute__((always_inline)) {
+    if constexpr (RING == 3)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]),
+                     "+v"(R1.f[3]), "+v"(R2.f[0]), "+v"(R2.f[1]), "+v"(R2.f[2]), "+v"(R2.f[3])
+                   :
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]),
+                     "+v"(R1.f[3])
+                   :
+                   : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- phase 1: conv1 ------------------------------------------------------------------------------------
+  // Per chunk: taps 3c .. 3c+2.  Iteration g: fetch tap g + AHEAD; in iteration 3c + 2 - AHEAD (right after the
+  // fetch of the chunk's last tap) request the next chunk's patch; wait for tap g; MFMAs.  Every chunk ends
+  // with vmcnt(0), so only fetches issued inside the chunk need a counted wait: they all precede the patch
+  // request, which is therefore never drained early.
+#pragma unroll
+  for (int g = 0; g < AHEAD; ++g) fetch(g);
+  issue_patch(0, 0);
+  drain();
+  transform_patch(0);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const bool has_dma = c + 1 < NCH;
+    __syncthreads();  // patch c is visible; the other buffer is free
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int g = 3 * c + k;
+      fetch(g + AHEAD);
+      if (k == 2 - AHEAD && has_dma) issue_patch(c + 1, ((c + 1) & 1) * CPATCH);
+      if (k >= AHEAD) wait_b_dyn(ring(g), 4 * AHEAD + (has_dma ? CNQ : 0));
+      int rows[WM];
+#pragma unroll
+      for (int a = 0; a < WM; ++a) rows[a] = arow1[a] + p.poff[k];
+      mma(ring(g), lds + (c & 1) * CPATCH, CROW, rows);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    drain();
+    if (has_dma) transform_patch(((c + 1) & 1) * CPATCH);
+  }
+
+  // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------
+  // Accumulator element (a, r) of lane (l31, lh): h row m = (wm*WM + a)*32 + (r&3) + 8*(r>>2) + 4*lh, channel
+  // wn*32 + l31.  Rows m and m+1 (r even / odd) share a cvt_pk; 2-byte stores into the swizzled row.
+  {
+    char* hcol = lds + H_OFF + wn * CROW + (l31 & 7) * 2;
+    const int piece = l31 >> 3;
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int m = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float u0 = acc[a][r] + b1v, u1 = acc[a][r + 1] + b1v;
+        u0 = fmaxf(u0, u0 * slope);
+        u1 = fmaxf(u1, u1 * slope);
+        u0 = ((hbits >> (a * 16 + r)) & 1) ? u0 : 0.f;
+        u1 = ((hbits >> (a * 16 + r + 1)) & 1) ? u1 : 0.f;
+        const unsigned hh = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u0, u1}, bf16x2));
+        const f32x2 rr = {u0 - __builtin_bit_cast(float, hh << 16), u1 - __builtin_bit_cast(float, hh & 0xffff0000u)};
+        const unsigned ll = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+        const int k0 = ((m >> 1) & 7), k1 = (((m + 1) >> 1) & 7);
+        char* row0 = hcol + m * HROW;
+        char* row1 = row0 + HROW;
+        *reinterpret_cast<unsigned short*>(row0 + ((piece ^ k0) << 4)) = (unsigned short)(hh & 0xffffu);
+        *reinterpret_cast<unsigned short*>(row1 + ((piece ^ k1) << 4)) = (unsigned short)(hh >> 16);
+        *reinterpret_cast<unsigned short*>(row0 + (((piece + 4) ^ k0) << 4)) = (unsigned short)(ll & 0xffffu);
+        *reinterpret_cast<unsigned short*>(row1 + (((piece + 4) ^ k1) << 4)) = (unsigned short)(ll >> 16);
+        acc[a][r] = 0.f;
+        acc[a][r + 1] = 0.f;
+      }
+  }
+  __syncthreads();  // h is complete
+
+  // ---- phase 3: conv2 from the resident h ------------------------------------------------------------------
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int g = NT1 + 3 * c + k;
+      fetch(g + AHEAD);
+      if (g >= NT1 + AHEAD) wait_b_dyn(ring(g), 4 * AHEAD);  // the first AHEAD taps landed with the last drain
+      int rows[WM];
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const int r = arow2[a] + k - 1;
+        rows[a] = r < 0 ? 0 : (r > CBM - 1 ? CBM - 1 : r);  // clamped rows only feed outputs that are masked anyway
+      }
+      mma(ring(g), lds + H_OFF + c * CROW, HROW, rows);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  drain();
+  __syncthreads();  // every wave is done with h and the patch buffers
+
+  // ---- phase 4: y = conv2 + b2 + x --------------------------------------------------------------------------
+  int* otab = reinterpret_cast<int*>(lds + OTAB_OFF);
+  if (tid < CBM) {
+    const int li = tid / W1, lj = tid - li * W1;
+    const int pos = base_h + li * rowstride + lj;
+    const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) &
+                    (!p.fold | (j0 + lj - 1 < d));
+    otab[tid] = ok ? img * T + pos : -1;
+  }
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      smem[row * LDO + wn * 32 + l31] = acc[a][r];
+    }
+  __syncthreads();
+  {
+    constexpr int V = C / 4, RPP = 256 / V, NPASS = CBM / RPP;
+    const int c4 = tid % V, r0 = tid / V;
+    const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
+    int opix[NPASS];
+    f32x4 val[NPASS], res[NPASS];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      opix[q] = otab[r0 + q * RPP];
+      val[q] = *reinterpret_cast<const f32x4*>(smem + (r0 + q * RPP) * LDO + 4 * c4) + bv;
+    }
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q)
+      res[q] = *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * C + 4 * c4);
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q)
+      if (opix[q] >= 0) *(VFX_GLOBAL f32x4*)(p.y + (int64_t)opix[q] * C + 4 * c4) = val[q] + res[q];
+  }
+}
+
+static size_t resblock_lds_bytes(int C) {
+  const size_t h_end = (size_t)2 * CPATCH + (size_t)CBM * C * 4;
+  const size_t epi_end = (size_t)CBM * (C + 4) * 4 + CBM * 4;
+  return std::max(h_end, epi_end);
+}
+
+template <int C>
+static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
+  const size_t lds = resblock_lds_bytes(C);
+  static bool attr_set = false;
+  if (!attr_set) {
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_resblock<C>), dim3(grid), dim3(256), lds, stream, dparams);
+}
+
+bool resblock_supported(int C) { return C == 64 || C == 128; }
+
+// Fills the tile geometry of a fused ResStack layer (B, T, C, dil must be set).
+void plan_resblock(ResBlockParams& p) {
+  VFX_CHECK(resblock_supported(p.C), "resblock: C=%d is not supported", p.C);
+  const int d = p.dil;
+  if (128 + 2 * d <= kPatchMaxRows) {
+    p.fold = 0;
+    p.TH = 1;
+    p.W1 = 128;
+    p.TWo = 126;
+    p.tiles_h = 1;
+    p.tiles_w = (p.T + p.TWo - 1) / p.TWo;
+    p.PW = 128 + 2 * d;
+    p.P = p.PW;
+    for (int k = 0; k < 3; ++k) p.poff[k] = k * d;
+  } else {
+    // rows of d samples; h tile TH x (TW + 2) <= 128 pixels, x patch (TH + 2) x (TW + 2) <= kPatchMaxRows
+    p.fold = 1;
+    const int TW = d >= 16 ? 16 : d;
+    p.W1 = TW + 2;
+    p.TH = std::min(128 / p.W1, kPatchMaxRows / p.W1 - 2);
+    p.TWo = TW;
+    const int rows = (p.T + d - 1) / d;
+    p.tiles_h = (rows + p.TH - 1) / p.TH;
+    p.tiles_w = (d + TW - 1) / TW;
+    p.PW = p.W1;
+    p.P = (p.TH + 2) * p.W1;
+    for (int k = 0; k < 3; ++k) p.poff[k] = k * p.W1;
+  }
+  VFX_CHECK(p.P <= kPatchMaxRows && p.TH * p.W1 <= CBM && p.TH >= 1, "resblock: bad tile geometry (dil=%d)", d);
+  VFX_CHECK((int64_t)p.B * p.T * p.C * 4 < ((int64_t)1 << 32) - 4096, "resblock: tensor exceeds 4 GiB");
+}
+
+void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
+  const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
+  VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock: bad grid");
+  if (hp.C == 64) launch_rb<64>((int)grid, stream, dparams);
+  else launch_rb<128>((int)grid, stream, dparams);
+  VFX_HIP(hipGetLastError());
+}
+
+double resblock_flops(const ResBlockParams& hp) { return 2.0 * 2.0 * (double)hp.B * hp.T * hp.C * (3.0 * hp.C); }
+
+}  // namespace vfx

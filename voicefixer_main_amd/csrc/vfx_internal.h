@@ -124,6 +124,28 @@ struct TapConvParams {
   int act_elu;             // 1: ELU instead of LeakyReLU
 };
 
+// One fused TFGAN ResStack layer (resblock.hip): y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2.
+struct ResBlockParams {
+  const float* x;   // (B, T, C) raw fp32 input, also the residual
+  float* y;         // (B, T, C) raw fp32 output
+  const float* w1;  // conv1 (k3, dilation dil), fragment-packed [C/32][3][C/32][1024] (pack_conv)
+  const float* w2;  // conv2 (k3, dilation 1)
+  const float* b1;  // [C]
+  const float* b2;
+  float slope;      // LeakyReLU slope of both activations
+  int B, T, C, dil;
+  // tile geometry (plan_resblock): h tile = TH x W1 positions, position(li, lj) = base + li * rowstride + lj
+  int fold;         // 1: the sequence is viewed as rows of `dil` samples (conv1's taps are vertical)
+  int TH, W1, TWo;  // TWo = outputs per tile row (W1 - 2)
+  int tiles_h, tiles_w;
+  int PW, P;        // x patch: PH x PW pixels, P <= kPatchMaxRows
+  int poff[3];      // patch row offset of conv1's taps
+};
+bool resblock_supported(int C);
+void plan_resblock(ResBlockParams& p);
+void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
+double resblock_flops(const ResBlockParams& hp);
+
 void finish_params(TapConvParams& p);  // fills total_steps, M and the tile / patch geometry, validates
 int count_stages(const TapConvParams& p);
 void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out);  // p: absolute pointers
@@ -198,12 +220,12 @@ struct ArenaPlanner {
 
 // A buffer is either a slice of the arena (resolved when the plan is bound to an arena base)
 // or one of the caller's tensors (resolved per call).
-struct ConvProfile {  // HIP-event timing of every tap-convolution launch (vfx_profile_*)
+struct ConvProfile {  // HIP-event timing of every convolution launch (vfx_profile_*)
   bool enabled = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::vector<double> flops;
   std::vector<int> bn;
-  std::vector<TapConvParams> desc;
+  std::vector<TapConvParams> desc;  // fused ResStack layers are described as M = B*T, Cout = C, nseg = 0
 };
 
 struct RunCtx {
@@ -218,6 +240,8 @@ struct Plan {
   std::vector<TapConvParams> host_params;  // arena-relative until bind()
   TapConvParams* dev_params = nullptr;
   ConvStage* dev_stages = nullptr;
+  std::vector<ResBlockParams> host_rb;     // arena-relative until bind()
+  ResBlockParams* dev_rb = nullptr;
   DeviceBlob blob;
   size_t arena_bytes = 0;
   char* bound_base = nullptr;
@@ -243,6 +267,7 @@ struct PlanBuilder {
   // Adds a tap-convolution whose src/residual/out pointers are arena offsets encoded as
   // (const float*)offset; they are rebased in Plan::bind.
   void add_conv(TapConvParams p);
+  void add_resblock(ResBlockParams p);  // x / y are arena offsets encoded with rel_ptr()
 };
 
 struct ConvBlockW {

@@ -8,6 +8,7 @@
 // biases and the ResStack residual adds are epilogues, a stride-s transposed convolution is s
 // output-phase launches with two taps each, ReflectionPad1d is an addressing mode.
 #include <cmath>
+#include <cstdlib>
 
 #include "vfx_internal.h"
 
@@ -231,7 +232,30 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     x = y;
     Tlen = Tout;
     int dil = 1;
+    // HBM-bound stacks (C = 64, 128) run each layer as ONE fused launch (resblock.hip); `VFX_NO_FUSE` keeps
+    // the two-launch form for A/B measurements.
+    const bool fuse = cfg.precision != 0 && resblock_supported(up.cout) && !getenv("VFX_NO_FUSE");
     for (auto& layer : W->res[st]) {
+      if (fuse) {
+        const size_t y2 = pb.alloc_f((int64_t)B * Tlen * up.cout);
+        ResBlockParams rp{};
+        rp.x = rel_ptr(x);
+        rp.y = const_cast<float*>(rel_ptr(y2));
+        rp.w1 = layer.first.w;
+        rp.w2 = layer.second.w;
+        rp.b1 = layer.first.bias;
+        rp.b2 = layer.second.bias;
+        rp.slope = cfg.voc_res_slope;
+        rp.B = B;
+        rp.T = Tlen;
+        rp.C = up.cout;
+        rp.dil = dil;
+        pb.add_resblock(rp);
+        pb.free(x);
+        x = y2;
+        dil *= cfg.voc_dilation_base;
+        continue;
+      }
       const size_t hbuf = conv1d(layer.first, x, Tlen, 3, dil, ACT_LEAKY, cfg.voc_res_slope, false, nullptr,
                                  /*src_act=*/false, ACT_LEAKY, cfg.voc_res_slope);
       const size_t y2 = conv1d(layer.second, hbuf, Tlen, 3, 1, ACT_LEAKY, cfg.voc_res_slope, false, &x, /*src_act=*/true);
