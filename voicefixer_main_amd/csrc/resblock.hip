@@ -11,7 +11,7 @@
 //   * d  > 32: "folded" -- the sequence is viewed as rows of d samples, conv1's taps become vertical
 //     neighbours: h tile = TH x (TW + 2) positions (7 x 18), outputs TH x TW, x patch (TH+2) x (TW+2).
 //     A position is just row*d + col, so a column index of -1 or d is simply the neighbouring row.
-// Phases (one block = 4 waves, wave = (128 / WAVES_M) h rows x 32 channels, all C output channels per block):
+// Phases (one block = 4 or 8 waves, wave = (128 / WAVES_M) h rows x 32 channels, all C output channels per block):
 //   1. conv1: per 32-channel chunk the raw x patch arrives by LDS-DMA (zero fill by the buffer bound),
 //      is turned into MFMA operand form in place (LeakyReLU, hi/lo split, swizzled slots) and read by the
 //      three taps -- same machinery as k_conv (conv.hip), statically scheduled here;
@@ -25,21 +25,28 @@
 
 namespace vfx {
 
-// n is a compile-time constant after unrolling; only these counts occur
+// n is a compile-time constant after unrolling; only these counts occur (NG = patch DMA instructions per wave)
+template <int NG>
 __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
   switch (n) {
     case 4: wait_b<4>(R); break;
     case 8: wait_b<8>(R); break;
-    case 4 + CNQ: wait_b<4 + CNQ>(R); break;
-    case 8 + CNQ: wait_b<8 + CNQ>(R); break;
+    case 4 + NG: wait_b<4 + NG>(R); break;
+    case 8 + NG: wait_b<8 + NG>(R); break;
     default: wait_b<0>(R); break;
   }
 }
 
-template <int C>
-__global__ __launch_bounds__(256, C == 64 ? 2 : 1) void k_resblock(const ResBlockParams* __restrict__ pp) {
+// NW waves per block: 4 (C = 64, two blocks per CU) or 8 (C = 128: the 112 KB of LDS allow one block per CU,
+// so the block itself brings the second wave per SIMD).
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* __restrict__ pp) {
+  constexpr int NTHR = NW * 64;
+  constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
+  constexpr int NG = kPatchMaxRows / RG;     // DMA instructions per wave and patch
+  static_assert(kPatchMaxRows % RG == 0, "patch rows must split into whole DMA groups");
   constexpr int NCH = C / 32;  // 32-channel chunks = waves along N
-  constexpr int WAVES_N = NCH, WAVES_M = 4 / WAVES_N, WM = 4 / WAVES_M;  // C = 64: 2, 2, 2;  C = 128: 4, 1, 4
+  constexpr int WAVES_N = NCH, WAVES_M = NW / WAVES_N, WM = 4 / WAVES_M;  // (C, NW) = (64, 4): 2, 2, 2;  (128, 8): 4, 2, 2
   constexpr int RING = WM >= 4 ? 2 : 3, AHEAD = RING - 1;
   constexpr int HROW = C * 4;         // bytes per h row
   constexpr int H_OFF = 2 * CPATCH;   // h buffer behind the two patch buffers
@@ -77,11 +84,11 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void k_resblock(const ResBloc
 
   // ---- per-thread tables ------------------------------------------------------------------------------
   // x patch pixel lr + 32q -> byte offset in x (chunk 0) / validity
-  unsigned voff[CNQ];
+  unsigned voff[NG];
   unsigned okmask = 0;
 #pragma unroll
-  for (int q = 0; q < CNQ; ++q) {
-    const int prow = lr + 32 * q;
+  for (int q = 0; q < NG; ++q) {
+    const int prow = lr + RG * q;
     const int pi = prow / PW, pj = prow - pi * PW;
     const int pos = base_x + pi * rowstride + pj;
     const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
@@ -124,22 +131,22 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void k_resblock(const ResBloc
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x + c * kKC), 0, (int)(unsigned)((int64_t)p.B * T * C * 4 - (int64_t)c * kKC * 4), 0x00020000);
 #pragma unroll
-    for (int q = 0; q < CNQ; ++q) {
+    for (int q = 0; q < NG; ++q) {
       const unsigned o = (okmask & (1u << q)) ? voff[q] + 16u * cg : 0xfffffff0u;
-      VFX_LDS void* l = (VFX_LDS void*)(lds + dst + (32 * q + 8 * wave_u) * CROW);
+      VFX_LDS void* l = (VFX_LDS void*)(lds + dst + (RG * q + 8 * wave_u) * CROW);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
     }
   };
-  const int nq = (P + 31) >> 5;
+  const int nq = (P + RG - 1) / RG;
   auto transform_patch = [&](int dst) __attribute__((always_inline)) {
     char* row0 = lds + dst + lr * CROW;
-    f32x4 raw[CNQ];
+    f32x4 raw[NG];
 #pragma unroll
-    for (int q = 0; q < CNQ; ++q)
-      if (q < 4 || q < nq) raw[q] = *reinterpret_cast<const f32x4*>(row0 + 32 * q * CROW + 16 * cg);
+    for (int q = 0; q < NG; ++q)
+      if (q * RG < 128 || q < nq) raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
 #pragma unroll
-    for (int q = 0; q < CNQ; ++q)
-      if (q < 4 || q < nq) {
+    for (int q = 0; q < NG; ++q)
+      if (q * RG < 128 || q < nq) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[q][e], raw[q][e] * slope);  // LeakyReLU(0) = 0: DMA zero fill stays zero
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void k_resblock(const ResBloc
         const f32x2 r23 = {v[2] - __builtin_bit_cast(float, h23 << 16), v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
         const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
         const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
-        char* rowp = row0 + 32 * q * CROW;
+        char* rowp = row0 + RG * q * CROW;
         const int half = 8 * (cg & 1);
         *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ key_l) << 4) + half) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ key_l) << 4) + half) = make_uint2(l01, l23);
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void k_resblock(const ResBloc
       const int g = 3 * c + k;
       fetch(g + AHEAD);
       if (k == 2 - AHEAD && has_dma) issue_patch(c + 1, ((c + 1) & 1) * CPATCH);
-      if (k >= AHEAD) wait_b_dyn(ring(g), 4 * AHEAD + (has_dma ? CNQ : 0));
+      if (k >= AHEAD) wait_b_dyn<NG>(ring(g), 4 * AHEAD + (has_dma ? NG : 0));
       int rows[WM];
 #pragma unroll
       for (int a = 0; a < WM; ++a) rows[a] = arow1[a] + p.poff[k];
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void k_resblock(const ResBloc
     for (int k = 0; k < 3; ++k) {
       const int g = NT1 + 3 * c + k;
       fetch(g + AHEAD);
-      if (g >= NT1 + AHEAD) wait_b_dyn(ring(g), 4 * AHEAD);  // the first AHEAD taps landed with the last drain
+      if (g >= NT1 + AHEAD) wait_b_dyn<NG>(ring(g), 4 * AHEAD);  // the first AHEAD taps landed with the last drain
       int rows[WM];
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void k_resblock(const ResBloc
     }
   __syncthreads();
   {
-    constexpr int V = C / 4, RPP = 256 / V, NPASS = CBM / RPP;
+    constexpr int V = C / 4, RPP = NTHR / V, NPASS = CBM / RPP;
     const int c4 = tid % V, r0 = tid / V;
     const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
     int opix[NPASS];
@@ -332,15 +339,16 @@ static size_t resblock_lds_bytes(int C) {
   return std::max(h_end, epi_end);
 }
 
-template <int C>
+template <int C, int NW>
 static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
   const size_t lds = resblock_lds_bytes(C);
   static bool attr_set = false;
   if (!attr_set) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_resblock<C>), dim3(grid), dim3(256), lds, stream, dparams);
+  hipLaunchKernelGGL((k_resblock<C, NW>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
 }
 
 bool resblock_supported(int C) { return C == 64 || C == 128; }
@@ -380,8 +388,8 @@ void plan_resblock(ResBlockParams& p) {
 void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock: bad grid");
-  if (hp.C == 64) launch_rb<64>((int)grid, stream, dparams);
-  else launch_rb<128>((int)grid, stream, dparams);
+  if (hp.C == 64) launch_rb<64, 4>((int)grid, stream, dparams);
+  else launch_rb<128, 8>((int)grid, stream, dparams);
   VFX_HIP(hipGetLastError());
 }
 
