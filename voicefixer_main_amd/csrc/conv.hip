@@ -245,13 +245,15 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
             al[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((64 + 32 * s + 16 * lh) ^ key[a]));
           }
         }
-        // small cross terms first, the dominant hi*hi product last; consecutive MFMAs hit different accumulators
+        // D = W (A operand: rows = couts) x patch (B operand: columns = pixels): a lane ends up with ONE pixel and
+        // four runs of 4 consecutive couts, i.e. 16-byte pieces of the pixel's row (conv_epilogue.h).  Small cross
+        // terms first, the dominant hi*hi product last; consecutive MFMAs hit different accumulators.
 #pragma unroll
-        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][0], 0, 0, 0);
+        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[a], acc[a][0], 0, 0, 0);
 #pragma unroll
-        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][0], 0, 0, 0);
+        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[a], acc[a][0], 0, 0, 0);
 #pragma unroll
-        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][0], 0, 0, 0);
+        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[a], acc[a][0], 0, 0, 0);
       }
     } else {
       // 32x32x2 fp32 MFMA: lane l supplies k = l>>5; a lane reads ONE float4 at channel 8g + 4*(l>>5)
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int a = 0; a < WM; ++a)
-            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[e], acc[a][0], 0, 0, 0);
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[e], fa[a][e], acc[a][0], 0, 0, 0);
       }
     }
   };
