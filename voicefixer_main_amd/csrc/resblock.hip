@@ -95,30 +95,22 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
     voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 4);
     okmask |= ok ? (1u << q) : 0u;
   }
-  // h pixel m -> inside the tile's h grid and inside the sequence (temporary table in the h region)
-  if (tid < CBM) {
-    const int li = tid / W1, lj = tid - li * W1;
-    const int pos = base_h + li * rowstride + lj;
-    reinterpret_cast<int*>(lds + H_OFF)[tid] = (li < TH) & ((unsigned)pos < (unsigned)T);
-  }
-  __syncthreads();
   int arow1[WM], arow2[WM];  // A row of this lane's h pixel: in the x patch (tap offset added) / in the h buffer
-  unsigned long long hbits = 0;  // bit a*16 + r: h pixel of accumulator element (a, r) is valid
+  bool hval[WM];             // that h pixel lies inside the tile's h grid and inside the sequence
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
     const int ml = (wm * WM + a) * 32 + l31;
-    const int li = ml / W1;
-    arow1[a] = li < TH ? li * PW + (ml - li * W1) : 0;
+    const int li = ml / W1, lj = ml - li * W1;
+    arow1[a] = li < TH ? li * PW + lj : 0;
     arow2[a] = ml;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (reinterpret_cast<const int*>(lds + H_OFF)[m]) hbits |= 1ull << (a * 16 + r);
-    }
+    const int pos = base_h + li * rowstride + lj;
+    hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
   }
   const unsigned nb_off = (unsigned)(wn * 1024 + lane * 4) * 4u;
   const int64_t ts = (int64_t)C * kKC;  // floats per tap of a weight tensor
-  const float b1v = p.b1[wn * 32 + l31];
+  f32x4 b1v[4];  // bias of conv1 for this lane's accumulator channels: runs wn*32 + 8j + 4lh .. +3
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b1v[j] = *(const VFX_GLOBAL f32x4*)(p.b1 + wn * 32 + 8 * j + 4 * lh);
 
   f32x16 acc[WM];
 #pragma unroll
@@ -182,12 +174,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
         ah[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
         al[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((64 + 32 * s + 16 * lh) ^ key[a]));
       }
+      // D = W (A operand: rows = couts) x image rows (B operand: columns = pixels): lane = pixel, registers =
+      // four runs of 4 consecutive couts
 #pragma unroll
-      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a], 0, 0, 0);
+      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[a], acc[a], 0, 0, 0);
 #pragma unroll
-      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a], 0, 0, 0);
+      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[a], acc[a], 0, 0, 0);
 #pragma unroll
-      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a], 0, 0, 0);
+      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[a], acc[a], 0, 0, 0);
     }
   };
 
@@ -245,34 +239,31 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
   }
 
   // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------
-  // Accumulator element (a, r) of lane (l31, lh): h row m = (wm*WM + a)*32 + (r&3) + 8*(r>>2) + 4*lh, channel
-  // wn*32 + l31.  Rows m and m+1 (r even / odd) share a cvt_pk; 2-byte stores into the swizzled row.
-  {
-    char* hcol = lds + H_OFF + wn * CROW + (l31 & 7) * 2;
-    const int piece = l31 >> 3;
+  // Lane (l31, lh) of M block a holds h pixel m = (wm*WM + a)*32 + l31 and, in registers 4j .. 4j+3, channels
+  // wn*32 + 8j + 4lh .. +3: their 4 hi bf16 are half `lh` of piece j of the pixel's chunk row, the 4 lo of piece j+4.
 #pragma unroll
-    for (int a = 0; a < WM; ++a)
+  for (int a = 0; a < WM; ++a) {
+    const int m = (wm * WM + a) * 32 + l31;
+    char* rowp = lds + H_OFF + m * HROW + wn * CROW + 8 * lh;
+    const int key = (m >> 1) & 7;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const int m = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float u0 = acc[a][r] + b1v, u1 = acc[a][r + 1] + b1v;
-        u0 = fmaxf(u0, u0 * slope);
-        u1 = fmaxf(u1, u1 * slope);
-        u0 = ((hbits >> (a * 16 + r)) & 1) ? u0 : 0.f;
-        u1 = ((hbits >> (a * 16 + r + 1)) & 1) ? u1 : 0.f;
-        const unsigned hh = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u0, u1}, bf16x2));
-        const f32x2 rr = {u0 - __builtin_bit_cast(float, hh << 16), u1 - __builtin_bit_cast(float, hh & 0xffff0000u)};
-        const unsigned ll = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
-        const int k0 = ((m >> 1) & 7), k1 = (((m + 1) >> 1) & 7);
-        char* row0 = hcol + m * HROW;
-        char* row1 = row0 + HROW;
-        *reinterpret_cast<unsigned short*>(row0 + ((piece ^ k0) << 4)) = (unsigned short)(hh & 0xffffu);
-        *reinterpret_cast<unsigned short*>(row1 + ((piece ^ k1) << 4)) = (unsigned short)(hh >> 16);
-        *reinterpret_cast<unsigned short*>(row0 + (((piece + 4) ^ k0) << 4)) = (unsigned short)(ll & 0xffffu);
-        *reinterpret_cast<unsigned short*>(row1 + (((piece + 4) ^ k1) << 4)) = (unsigned short)(ll >> 16);
-        acc[a][r] = 0.f;
-        acc[a][r + 1] = 0.f;
+    for (int j = 0; j < 4; ++j) {
+      f32x4 u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = acc[a][4 * j + e] + b1v[j][e];
+        u[e] = hval[a] ? fmaxf(t, t * slope) : 0.f;
+        acc[a][4 * j + e] = 0.f;
       }
+      const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u[0], u[1]}, bf16x2));
+      const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u[2], u[3]}, bf16x2));
+      const f32x2 r01 = {u[0] - __builtin_bit_cast(float, h01 << 16), u[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+      const f32x2 r23 = {u[2] - __builtin_bit_cast(float, h23 << 16), u[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+      const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
+      const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
+      *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(rowp + (((j + 4) ^ key) << 4)) = make_uint2(l01, l23);
+    }
   }
   __syncthreads();  // h is complete
 
@@ -308,9 +299,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
 #pragma unroll
   for (int a = 0; a < WM; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      smem[row * LDO + wn * 32 + l31] = acc[a][r];
+    for (int j = 0; j < 4; ++j) {
+      const int row = (wm * WM + a) * 32 + l31;
+      *reinterpret_cast<f32x4*>(smem + row * LDO + wn * 32 + 8 * j + 4 * lh) =
+          f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
     }
   __syncthreads();
   {
