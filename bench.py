@@ -10,9 +10,9 @@ Weak scaling: every rank restores its own shard, no collective on the data path.
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live: HIP events around every launch of
-the dominant kernel (k_tapconv, the fp32-MFMA tap-convolution) on its own stream over K steps
-of the same workload; `cpu_baseline` times the CPU oracle (oracle/, a port of the reference
+Rank 0 prints ONE JSON line.  `roofline` is measured live: HIP events around every convolution
+launch on its own stream over K more steps of the same workload, reported for the kernel with the
+largest share of GPU time (k_conv<128, false, true>, the split-bf16 MFMA tap convolution); `cpu_baseline` times the CPU oracle (oracle/, a port of the reference
 algorithm) on a bounded sample of the same clips on this box's host cores.
 """
 import argparse
@@ -70,6 +70,66 @@ def cpu_baseline(clips, n_clips, threads):
             "sample": "oracle.pipeline.restore_gsr (torch-CPU fp32 + numpy port of the reference algorithm) on "
                       "%d clip(s) x %.0f s of the same synthetic clips as one batch, same seeded weights, after a "
                       "1-s warm-up" % (wav.shape[0], wav.shape[-1] / 44100.0)}
+
+
+def measure_roofline(eng, wav, out, args):
+    """HIP events around every convolution launch (on the launch stream) over K more steps of the same
+    workload; per-kernel totals come from the per-launch table libvfx writes (VFX_PROFILE_DUMP).  The
+    roofline object describes the kernel with the largest share of GPU time; `traffic` is the HBM byte count
+    of that kernel per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes, + WRITE_SIZE), null if no such measurement exists for this workload."""
+    import csv
+    import tempfile
+    dump = tempfile.NamedTemporaryFile(prefix="vfx_convs_", suffix=".csv", delete=False).name
+    os.environ["VFX_PROFILE_DUMP"] = dump
+    eng.profile_begin()
+    for _ in range(args.steps):
+        eng.restore_gsr(wav, out=out)
+    n, ms, fl = eng.profile_end()
+    os.environ.pop("VFX_PROFILE_DUMP", None)
+    rows = list(csv.DictReader(open(dump)))
+    os.unlink(dump)
+    per = {}
+    for r in rows:
+        k = r["kernel"].replace(";", ",")
+        t = per.setdefault(k, [0, 0.0, 0.0])
+        t[0] += 1
+        t[1] += float(r["ms"])
+        t[2] += float(r["tflops"]) * float(r["ms"]) * 1e9   # flops of the launch
+    steps = max(args.steps, 1)
+    dom = max(per, key=lambda k: per[k][1])
+    cnt, kms, kfl = per[dom]
+    tflops = kfl / (kms * 1e-3) / 1e12
+    split = args.precision == 1
+    peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+    traffic = None
+    tpath = os.path.join(HERE, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath))
+            if t.get("workload") == "%dx%.0fs" % (wav.shape[0], args.seconds) and t.get("precision") == args.precision:
+                traffic = t.get("kernels", {}).get(dom)
+        except Exception:
+            traffic = None
+    return {
+        "bound": "mfma",
+        "kernel": "%s (%s)" % (dom, "3 x v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
+                               if split else "v_mfma_f32_32x32x2_f32"),
+        "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+        # achieved counts ALGORITHMIC flops (2*M*N*K once); in split-bf16 mode the kernel issues 3 bf16 MFMAs per
+        # product, so `frac` is bounded by 1/3 and mfma_issue_frac is the share of the MFMA pipe actually used
+        "mfma_issue_frac": round(tflops * (3 if split else 1) / peak, 4),
+        "traffic": traffic,
+        "launches_per_step": cnt // steps,
+        "avg_launch_us": round(kms * 1e3 / max(cnt, 1), 2),
+        "kernel_ms_per_step": round(kms / steps, 3),
+        "algorithmic_gflop_per_step": round(kfl / steps / 1e9, 1),
+        "share_of_conv_time": round(kms / max(ms, 1e-9), 4),
+        "all_conv_kernels": {k: {"launches_per_step": v[0] // steps, "ms_per_step": round(v[1] / steps, 3),
+                                 "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(per.items())},
+        "all_conv_ms_per_step": round(ms / steps, 3),
+        "all_conv_algorithmic_gflop_per_step": round(fl / steps / 1e9, 1),
+    }
 
 
 def main():
@@ -130,25 +190,7 @@ def main():
 
     roofline = None
     if not args.no_roofline and rank == 0:
-        eng.profile_begin()
-        for _ in range(args.steps):
-            eng.restore_gsr(wav, out=out)
-        n, ms, fl = eng.profile_end()
-        tflops = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        if args.precision == 1:
-            # achieved counts ALGORITHMIC flops (2*M*N*K once); the kernel issues 3 bf16 MFMAs per
-            # product, so the dense bf16 peak bounds `frac` by 1/3.
-            kern, peak = "k_tapconv<split-bf16> (3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)", PEAK_BF16_MFMA_TFLOPS
-        else:
-            kern, peak = "k_tapconv<fp32> (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
-        roofline = {"bound": "mfma", "kernel": kern,
-                    "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(tflops / peak, 4), "mfma_issue_frac": round(tflops * (3 if args.precision == 1 else 1) / peak, 4),
-                    "traffic": None,
-                    "launches_per_step": n // max(args.steps, 1),
-                    "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
-                    "kernel_ms_per_step": round(ms / max(args.steps, 1), 3),
-                    "algorithmic_gflop_per_step": round(fl / max(args.steps, 1) / 1e9, 1)}
+        roofline = measure_roofline(eng, wav, out, args)
 
     if rank == 0:
         audio_s = world * B * args.seconds * args.steps

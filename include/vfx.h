@@ -167,6 +167,13 @@ int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H, int W, in
                           const float* scale, const float* shift, int act, float slope,
                           const float* bias, float* y, void* stream);
 
+/* One TFGAN ResStack layer (vocoder layer table, oracle/vocoder.py) on channels-last (B, T, C) tensors:
+ *   y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2,  conv1: k3 with dilation `dil`, conv2: k3.
+ * w1 / w2 in PyTorch Conv1d layout (C, C, 3), b1 / b2 (C), all on the HOST.  fused != 0 runs the single-launch
+ * kernel (C = 64 or 128, precision 1); fused == 0 the two-launch form with the activated intermediate tensor. */
+int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int C, const float* w1, const float* b1,
+                    const float* w2, const float* b2, int dil, float slope, int fused, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

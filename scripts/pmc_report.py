@@ -67,8 +67,8 @@ def main():
         busy = avg("SQ_BUSY_CYCLES")
         mfma = avg("SQ_VALU_MFMA_BUSY_CYCLES")
         gui = avg("GRBM_GUI_ACTIVE")
-        # MFMA busy: cycles summed over SIMDs (1024 of them); kernel cycles ~ GRBM_GUI_ACTIVE (or us * clock)
-        cyc = gui if gui == gui else us * 2.0e3
+        # SQ_VALU_MFMA_BUSY_CYCLES sums over the 1024 SIMDs; GRBM_GUI_ACTIVE sums over the 8 XCDs
+        cyc = gui / 8.0 if gui == gui else us * 2.0e3
         mfma_pct = 100.0 * mfma / (cyc * 1024.0) if mfma == mfma else float("nan")
         rd = 2.0 * avg("FETCH_SIZE") * 1024 / 1e9  # FETCH_SIZE is in KB
         wr = avg("WRITE_SIZE") * 1024 / 1e9

@@ -56,6 +56,28 @@ def test_conv1d_dilated_and_reflect(engine):
     assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), err
 
 
+def _resblock_ref(x, w1, b1, w2, b2, d, slope):
+    h = F.conv1d(F.leaky_relu(x.double(), slope), w1.double(), b1.double(), padding=d, dilation=d)
+    return x.double() + F.conv1d(F.leaky_relu(h, slope), w2.double(), b2.double(), padding=1)
+
+
+@pytest.mark.parametrize("C,T,fused", [(64, 1000, True), (128, 777, True), (64, 90, True), (96, 500, False), (256, 333, False)])
+def test_resblock_layer(engine, C, T, fused):
+    """One ResStack layer (oracle/vocoder.py): fused k_resblock and the two-launch form with the activated
+    intermediate tensor, over the vocoder's dilations (plain tiles up to 27, folded geometry beyond, also d > T)."""
+    if fused and engine.tol['name'] != 'split-bf16':
+        pytest.skip("the fused kernel is split-bf16 only; fp32 plans use the two-launch form")
+    B = 2
+    x = _rand((B, C, T), 21)
+    w1, w2 = _rand((C, C, 3), 22, 0.08), _rand((C, C, 3), 23, 0.08)
+    b1, b2 = _rand((C,), 24, 0.1), _rand((C,), 25, 0.1)
+    for d in (1, 3, 27, 81, 729, 2187):
+        ref = _resblock_ref(x, w1, b1, w2, b2, d, 0.01)
+        y = engine.op_resblock(x.permute(0, 2, 1).contiguous(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), d, 0.01, fused)
+        err = (y.cpu().permute(0, 2, 1).double() - ref).abs().max().item()
+        assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), (d, err)
+
+
 @pytest.mark.parametrize("prune_w,H,W", [(False, 5, 1), (False, 10, 3), (True, 4, 16)])
 def test_conv_transpose2d(engine, prune_w, H, W):
     B, Cin, Cout = 2, 64, 32

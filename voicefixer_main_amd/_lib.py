@@ -53,6 +53,8 @@ SIGNATURES = {
                             c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfx_op_conv_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                       c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "vfx_op_resblock": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                c_float, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -305,6 +305,29 @@ void build_stages(const TapConvParams& p, const float* ones, const float* zeros,
   }
 }
 
+void set_conv1d_geometry(TapConvParams& p, int B, int T, int K, int dil, bool reflect) {
+  p.B = B;
+  // A dilation too wide for one patch (> 32 samples for k3) is folded: the sequence becomes an image with
+  // rows of `dil` samples and the taps become vertical neighbours (TapConvParams, folded geometry).
+  const bool fold = !reflect && (K - 1) * dil + 128 > kPatchMaxRows && dil >= 16;
+  if (fold) {
+    p.Hi = p.Hg = p.Ho = (T + dil - 1) / dil;
+    p.Wi = p.Wg = p.Wo = dil;
+    p.in_img_stride = p.in_limit = p.out_img_stride = p.out_limit = T;
+  } else {
+    p.Hi = p.Hg = p.Ho = 1;
+    p.Wi = p.Wg = p.Wo = T;
+  }
+  p.sh = p.sw = 1;
+  p.reflect_w = reflect ? 1 : 0;
+  TapSeg& S = p.seg[0];
+  S.ntaps = K;
+  for (int k = 0; k < K; ++k) {
+    S.dh[k] = fold ? k - K / 2 : 0;
+    S.dw[k] = fold ? 0 : (k - K / 2) * dil;
+  }
+}
+
 void finish_params(TapConvParams& p) {
   p.total_steps = 0;
   for (int s = 0; s < p.nseg; ++s) {
@@ -894,7 +917,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
   double ms = 0, fl = 0;
   FILE* dump = nullptr;
   if (const char* path = getenv("VFX_PROFILE_DUMP")) dump = fopen(path, "w");
-  if (dump) fprintf(dump, "idx,M,Cout,K,nseg,ntaps0,C0,Wi,sw,ms,tflops\n");
+  if (dump) fprintf(dump, "idx,kernel,M,Cout,K,nseg,ntaps0,C0,Wi,sw,ms,tflops\n");
   for (size_t i = 0; i < h->prof.events.size(); ++i) {
     float t = 0.f;
     VFX_HIP(hipEventElapsedTime(&t, h->prof.events[i].first, h->prof.events[i].second));
@@ -902,8 +925,16 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       const TapConvParams& d = h->prof.desc[i];
       int K = 0;
       for (int s2 = 0; s2 < d.nseg; ++s2) K += d.seg[s2].ntaps * d.seg[s2].C;
-      fprintf(dump, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C, d.Wi,
-              d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12);
+      char kname[64];
+      if (d.nseg == 0) {  // fused ResStack layer
+        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>", d.Cout, d.Cout == 64 ? 4 : 8);
+      } else {
+        bool elu = false;
+        for (int s2 = 0; s2 < d.nseg; ++s2) elu = elu || d.seg[s2].act == ACT_ELU;
+        snprintf(kname, sizeof(kname), "k_conv<%d; %s; %s>", conv_block_n(d.Cout), elu ? "true" : "false", d.split ? "true" : "false");
+      }
+      fprintf(dump, "%zu,%s,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i, kname, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C,
+              d.Wi, d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12);
     }
     ms += t;
     fl += h->prof.flops[i];

@@ -59,14 +59,83 @@ extern "C" int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, i
     p.B = B;
     p.Hi = p.Hg = p.Ho = H;
     p.Wi = p.Wg = p.Wo = W;
-    p.Cout = Cout;
     p.sh = p.sw = 1;
     p.reflect_w = reflect_w;
+    if (H == 1 && kh == 1 && !reflect_w) set_conv1d_geometry(p, B, W, kw, dil_w, false);  // folds wide dilations
+    p.Cout = Cout;
     p.bias = bias ? sc.blob.upload(bias, Cout) : nullptr;
     p.residual = residual;
     p.out = y;
     p.act_slope = 1.f;
     run_one(h, p, sc.blob, s);
+    VFX_HIP(hipStreamSynchronize(s));
+  } catch (const vfx::Error&) {
+    return 1;
+  }
+  return 0;
+}
+
+// One ResStack layer y = x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 on (B, T, C) tensors; weights in PyTorch
+// Conv1d layout (C, C, 3) on the HOST.  fused != 0: k_resblock (C = 64 / 128, split-bf16 mode only);
+// fused == 0: two k_conv launches with the ACTIVATED intermediate tensor (any C multiple of 32), which is what
+// the plans use for the wide stacks -- this path also exercises the folded geometry for dil > 32.
+extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int C, const float* w1, const float* b1,
+                               const float* w2, const float* b2, int dil, float slope, int fused, float* y, void* stream) {
+  try {
+    VFX_CHECK(h && x && w1 && b1 && w2 && b2 && y, "NULL argument");
+    VFX_CHECK(C % kKC == 0 && B > 0 && T > 0 && dil >= 1, "vfx_op_resblock: bad shape");
+    VFX_HIP(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scratch sc;
+    const bool split = h->cfg.precision != 0;
+    std::vector<std::pair<int, int>> taps = {{0, 0}, {0, 1}, {0, 2}};
+    float* dw1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, split));
+    float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, split));
+    float* db1 = sc.blob.upload(b1, C);
+    float* db2 = sc.blob.upload(b2, C);
+    if (fused) {
+      VFX_CHECK(split && resblock_supported(C), "vfx_op_resblock: the fused kernel needs precision 1 and C = 64 or 128");
+      ResBlockParams rp{};
+      rp.x = x;
+      rp.y = y;
+      rp.w1 = dw1;
+      rp.w2 = dw2;
+      rp.b1 = db1;
+      rp.b2 = db2;
+      rp.slope = slope;
+      rp.B = B;
+      rp.T = T;
+      rp.C = C;
+      rp.dil = dil;
+      plan_resblock(rp);
+      ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
+      VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
+      launch_resblock(rp, d, s);
+    } else {
+      float* hbuf = static_cast<float*>(sc.blob.alloc((size_t)B * T * C * sizeof(float)));
+      TapConvParams p1{};
+      set_conv1d_geometry(p1, B, T, 3, dil, false);
+      p1.Cout = C;
+      p1.nseg = 1;
+      fill_seg(p1.seg[0], x, C, nullptr, nullptr, ACT_LEAKY, slope, sc.blob);
+      p1.seg[0].wt = dw1;
+      p1.bias = db1;
+      p1.out_act = hbuf;  // activated with conv2's prologue
+      p1.act_slope = slope;
+      run_one(h, p1, sc.blob, s);
+      TapConvParams p2{};
+      set_conv1d_geometry(p2, B, T, 3, 1, false);
+      p2.Cout = C;
+      p2.nseg = 1;
+      fill_seg(p2.seg[0], hbuf, C, nullptr, nullptr, ACT_NONE, 1.f, sc.blob);
+      p2.seg[0].src_act = 1;
+      p2.seg[0].wt = dw2;
+      p2.bias = db2;
+      p2.residual = x;
+      p2.out = y;
+      p2.act_slope = 1.f;
+      run_one(h, p2, sc.blob, s);
+    }
     VFX_HIP(hipStreamSynchronize(s));
   } catch (const vfx::Error&) {
     return 1;

@@ -146,6 +146,9 @@ void plan_resblock(ResBlockParams& p);
 void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 double resblock_flops(const ResBlockParams& hp);
 
+// Geometry + taps of a Conv1d (kernel K, dilation dil, 'same' padding) over (B, T, C) tensors as seg[0] of p:
+// plain 1-D when the taps fit one patch, folded (rows of `dil` samples, vertical taps) otherwise.
+void set_conv1d_geometry(TapConvParams& p, int B, int T, int K, int dil, bool reflect);
 void finish_params(TapConvParams& p);  // fills total_steps, M and the tile / patch geometry, validates
 int count_stages(const TapConvParams& p);
 void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out);  // p: absolute pointers

@@ -139,21 +139,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
                     float next_slope = 1.f) -> size_t {
     const size_t out = pb.alloc_f((int64_t)B * Tlen * cw.cout);
     TapConvParams p{};
-    p.B = B;
-    // A dilation too wide for one patch (> 48 samples for k3) is folded: the sequence becomes an image
-    // with rows of `dil` samples and the taps become vertical neighbours (TapConvParams, folded geometry).
-    const bool fold = !reflect && (K - 1) * dil + 128 > kPatchMaxRows && dil >= 16;
-    if (fold) {
-      p.Hi = p.Hg = p.Ho = (Tlen + dil - 1) / dil;
-      p.Wi = p.Wg = p.Wo = dil;
-      p.in_img_stride = p.in_limit = p.out_img_stride = p.out_limit = Tlen;
-    } else {
-      p.Hi = p.Hg = p.Ho = 1;
-      p.Wi = p.Wg = p.Wo = Tlen;
-    }
+    set_conv1d_geometry(p, B, Tlen, K, dil, reflect);
     p.Cout = cw.cout;
-    p.sh = p.sw = 1;
-    p.reflect_w = reflect ? 1 : 0;
     p.bias = cw.bias;
     p.residual = residual ? rel_ptr(*residual) : nullptr;
     p.act_slope = 1.f;
@@ -172,11 +159,6 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     S.slope = src_act ? 1.f : slope;
     S.src_act = src_act ? 1 : 0;
     S.wt = cw.w;
-    S.ntaps = K;
-    for (int k = 0; k < K; ++k) {
-      S.dh[k] = fold ? k - K / 2 : 0;
-      S.dw[k] = fold ? 0 : (k - K / 2) * dil;
-    }
     pb.add_conv(p);
     return out;
   };

@@ -210,6 +210,18 @@ class Engine:
                    "vfx_op_conv")
         return y
 
+    def op_resblock(self, x, w1, b1, w2, b2, dil, slope=0.01, fused=True):
+        """One ResStack layer on x (B, T, C) channels-last; w1 / w2 (C, C, 3), b1 / b2 (C) torch layout (host)."""
+        x = _dev_f32(x, self.device)
+        B, T, C = x.shape
+        hp = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        w1, b1, w2, b2 = hp(w1), hp(b1), hp(w2), hp(b2)
+        cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        y = torch.empty_like(x)
+        _lib.check(self.lib.vfx_op_resblock(self.h, _ptr(x), B, T, C, cp(w1), cp(b1), cp(w2), cp(b2), int(dil), float(slope),
+                                            int(bool(fused)), _ptr(y), self._stream()), "vfx_op_resblock")
+        return y
+
     def op_conv_transpose(self, x, weight, stride, prune_w=False, scale=None, shift=None, act=0, slope=0.0, bias=None):
         x = _dev_f32(x, self.device)
         B, H, W, Cin = x.shape
