@@ -102,15 +102,16 @@ def measure_roofline(eng, wav, out, args):
     tflops = kfl / (kms * 1e-3) / 1e12
     split = args.precision == 1
     peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-    traffic = None
+    traffic, traffic_detail = None, None
     tpath = os.path.join(HERE, "profiles", "r01_traffic.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
             if t.get("workload") == "%dx%.0fs" % (wav.shape[0], args.seconds) and t.get("precision") == args.precision:
-                traffic = t.get("kernels", {}).get(dom)
+                traffic_detail = t.get("kernels", {}).get(dom)
+                traffic = traffic_detail["bytes_per_launch"] if traffic_detail else None
         except Exception:
-            traffic = None
+            traffic, traffic_detail = None, None
     return {
         "bound": "mfma",
         "kernel": "%s (%s)" % (dom, "3 x v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
@@ -119,7 +120,8 @@ def measure_roofline(eng, wav, out, args):
         # achieved counts ALGORITHMIC flops (2*M*N*K once); in split-bf16 mode the kernel issues 3 bf16 MFMAs per
         # product, so `frac` is bounded by 1/3 and mfma_issue_frac is the share of the MFMA pipe actually used
         "mfma_issue_frac": round(tflops * (3 if split else 1) / peak, 4),
-        "traffic": traffic,
+        "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC passes of profiles/r01_traffic.json)",
+        "traffic_detail": traffic_detail,
         "launches_per_step": cnt // steps,
         "avg_launch_us": round(kms * 1e3 / max(cnt, 1), 2),
         "kernel_ms_per_step": round(kms / steps, 3),

@@ -58,3 +58,19 @@ def test_restore_gsr_vs_oracle(engine, unet_sd, voc_sd):
     err = out - ref["wav"][:, 0]
     sisdr = 10 * np.log10((ref["wav"] ** 2).sum() / ((err ** 2).sum() + 1e-20))
     assert sisdr > engine.tol['sisdr'], sisdr
+
+
+def test_poisoned_arena_stays_finite(unet_sd, voc_sd, monkeypatch):
+    """A freshly grown workspace arena is filled with NaN patterns (VFX_POISON_ARENA): every stage must produce
+    finite output on its very first call, i.e. no kernel reads a workspace buffer before something wrote it."""
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER
+    monkeypatch.setenv("VFX_POISON_ARENA", "1")
+    eng = Engine("cuda:0", config={"precision": 1})
+    eng.load_state_dict(MODEL_UNET_MEL, unet_sd)
+    eng.load_state_dict(MODEL_VOCODER, voc_sd)
+    eng.load_state_dict(MODEL_UNET_SPEC, synth.make_resunet_state_dict(2))
+    wav = torch.from_numpy(synth.make_clips(2, 1.0, seed=41)[:, 0]).cuda()
+    sp = eng.stft(wav, want_mel=False, want_sp=True)["sp"]
+    for y in (eng.resunet_spec(sp, wav), eng.restore_gsr(wav), eng.vocoder(eng.stft(wav)["mel"])):
+        assert bool(torch.isfinite(y).all())

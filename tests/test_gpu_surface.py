@@ -112,3 +112,43 @@ def test_unify_energy_path(engine, unet_sd, voc_sd):
     err = out - ref["wav"][:, 0]
     sisdr = 10 * np.log10((ref["wav"] ** 2).sum() / ((err ** 2).sum() + 1e-30))
     assert sisdr > 50.0, sisdr
+
+
+def test_graph_capture_restore_and_streaming_step(engine):
+    """BASELINE configs[4]: a steady-state call enqueues kernels only (no allocation, no sync), so a whole
+    restore step -- and the gsr_unet 1-s streaming step -- can be captured into a hipGraph and replayed."""
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.engine import MODEL_UNET_SPEC
+    wav = torch.from_numpy(synth.make_clips(2, 1.0, seed=41)[:, 0]).cuda()
+    out_eager = engine.restore_gsr(wav).clone()          # warm-up: builds the plan, sizes the arena, sets kernel attributes
+    out = torch.empty_like(wav)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        engine.restore_gsr(wav, out=out)                  # second warm-up on the capture stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            engine.restore_gsr(wav, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_eager)
+    # streaming step: spectrogram ResUNet on one 1-s chunk (T = 101 -> Tpad = 128)
+    engine.load_state_dict(MODEL_UNET_SPEC, synth.make_resunet_state_dict(2))
+    chunk = wav[:1].contiguous()
+    sp = engine.stft(chunk, want_mel=False, want_sp=True)["sp"]
+    ref = engine.resunet_spec(sp, chunk).clone()
+    g2 = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())  # one handle = one stream at a time: the arena is shared state
+    with torch.cuda.stream(side):
+        y = engine.resunet_spec(sp, chunk)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g2, stream=side):
+            y = engine.resunet_spec(sp, chunk)
+    torch.cuda.current_stream().wait_stream(side)
+    y.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)

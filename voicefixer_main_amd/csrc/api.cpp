@@ -426,6 +426,9 @@ static char* ensure_arena(vfx_handle* h, size_t bytes) {
   const size_t want = bytes + (bytes >> 4);
   void* p = nullptr;
   VFX_HIP(hipMalloc(&p, want));
+  // Debug aid (tests): a freshly grown arena is filled with NaN patterns, so that a kernel reading a
+  // workspace buffer before anything wrote it shows up as NaN instead of silently using stale values.
+  if (getenv("VFX_POISON_ARENA")) VFX_HIP(hipMemset(p, 0xFF, want));
   h->arena = static_cast<char*>(p);
   h->arena_bytes = want;
   return h->arena;
