@@ -80,15 +80,17 @@ def measure_roofline(eng, wav, out, args):
     MI355X_MICROARCH.md prescribes, + WRITE_SIZE), null if no such measurement exists for this workload."""
     import csv
     import tempfile
-    dump = tempfile.NamedTemporaryFile(prefix="vfx_convs_", suffix=".csv", delete=False).name
+    keep = os.environ.get("VFX_PROFILE_DUMP")   # a caller-provided path keeps the per-launch table
+    dump = keep or tempfile.NamedTemporaryFile(prefix="vfx_convs_", suffix=".csv", delete=False).name
     os.environ["VFX_PROFILE_DUMP"] = dump
     eng.profile_begin()
     for _ in range(args.steps):
         eng.restore_gsr(wav, out=out)
     n, ms, fl = eng.profile_end()
-    os.environ.pop("VFX_PROFILE_DUMP", None)
     rows = list(csv.DictReader(open(dump)))
-    os.unlink(dump)
+    if not keep:
+        os.environ.pop("VFX_PROFILE_DUMP", None)
+        os.unlink(dump)
     per = {}
     for r in rows:
         k = r["kernel"].replace(";", ",")

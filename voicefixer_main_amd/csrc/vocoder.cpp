@@ -132,22 +132,35 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     });
   }
 
-  // `src_act`: src is an activated tensor (its prologue was applied by the producer's epilogue);
-  // `next_act` != ACT_NONE: the output feeds one convolution only -> store it activated with that prologue.
+  // A tensor between two convolutions exists in up to two forms: raw fp32 (residual adds,
+  // non-GEMM consumers) and ACTIVATED for its consumer convolution (that consumer's prologue applied once by the
+  // producer's epilogue, MFMA operand form, staged by the DMA engine with no arithmetic).
+  constexpr size_t kNone = ~size_t(0);
+  struct Forms {
+    size_t raw = kNone, act = kNone;
+  };
+  auto free_forms = [&](const Forms& f) {
+    if (f.raw != kNone) pb.free(f.raw);
+    if (f.act != kNone) pb.free(f.act);
+  };
+  // Conv1d src -> (raw and / or activated) output.  `src_act`: src is the activated form (no prologue here);
+  // `next_act` != ACT_NONE: also / only store the output activated for its consumer.
   auto conv1d = [&](const VocConvW& cw, size_t src, int Tlen, int K, int dil, int act, float slope, bool reflect,
-                    const size_t* residual, bool src_act = false, int next_act = ACT_NONE,
-                    float next_slope = 1.f) -> size_t {
-    const size_t out = pb.alloc_f((int64_t)B * Tlen * cw.cout);
+                    const size_t* residual, bool src_act, bool want_raw, int next_act, float next_slope) -> Forms {
+    Forms out;
     TapConvParams p{};
     set_conv1d_geometry(p, B, Tlen, K, dil, reflect);
     p.Cout = cw.cout;
     p.bias = cw.bias;
     p.residual = residual ? rel_ptr(*residual) : nullptr;
     p.act_slope = 1.f;
-    if (next_act == ACT_NONE) {
-      p.out = const_cast<float*>(rel_ptr(out));
-    } else {
-      p.out_act = const_cast<float*>(rel_ptr(out));
+    if (want_raw) {
+      out.raw = pb.alloc_f((int64_t)B * Tlen * cw.cout);
+      p.out = const_cast<float*>(rel_ptr(out.raw));
+    }
+    if (next_act != ACT_NONE) {
+      out.act = pb.alloc_f((int64_t)B * Tlen * cw.cout);
+      p.out_act = const_cast<float*>(rel_ptr(out.act));
       p.act_slope = next_slope;
       p.act_elu = next_act == ACT_ELU;
     }
@@ -165,22 +178,33 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
 
   // condnet: Conv1d k3 + ELU; every output feeds exactly one convolution, so the ELU (and the
   // LeakyReLU in front of the first upsampler) is applied by the producer's epilogue
+  Forms cur;
+  cur.raw = x;
   for (size_t i = 0; i < W->cond.size(); ++i) {
-    const size_t y = conv1d(W->cond[i], x, Tp, 3, 1, ACT_NONE, 1.f, false, nullptr, /*src_act=*/i > 0, ACT_ELU, 1.f);
-    pb.free(x);
-    x = y;
+    const Forms y = conv1d(W->cond[i], i > 0 ? cur.act : cur.raw, Tp, 3, 1, ACT_NONE, 1.f, false, nullptr, /*src_act=*/i > 0,
+                           /*want_raw=*/false, ACT_ELU, 1.f);
+    free_forms(cur);
+    cur = y;
   }
   {  // ReflectionPad1d(3) + Conv1d k7 on ELU(condnet output); its output is read by upsampler 0 only
-    const size_t y = conv1d(W->pre, x, Tp, 7, 1, ACT_ELU, 1.f, true, nullptr, /*src_act=*/true, ACT_LEAKY, cfg.voc_up_slope);
-    pb.free(x);
-    x = y;
+    const Forms y = conv1d(W->pre, cur.act, Tp, 7, 1, ACT_ELU, 1.f, true, nullptr, /*src_act=*/true, /*want_raw=*/false, ACT_LEAKY,
+                           cfg.voc_up_slope);
+    free_forms(cur);
+    cur = y;
   }
   int Tlen = Tp;
   for (int st = 0; st < cfg.voc_n_stages; ++st) {
     const int s = cfg.voc_scales[st], pad = s / 2 + s % 2;
     const VocConvW& up = W->up[st];
     const int Tout = Tlen * s;
-    const size_t y = pb.alloc_f((int64_t)B * Tout * up.cout);
+    // HBM-bound stacks (C = 64, 128) run each layer as ONE fused launch on the raw trunk (resblock.hip); the wide
+    // stacks run two launches per layer on a trunk kept in both forms.  `VFX_NO_FUSE` forces the latter (A/B runs).
+    const bool fuse = cfg.precision != 0 && resblock_supported(up.cout) && !getenv("VFX_NO_FUSE");
+    const bool last_stage = st + 1 == cfg.voc_n_stages;
+    Forms y;
+    y.raw = pb.alloc_f((int64_t)B * Tout * up.cout);
+    if (!fuse) y.act = pb.alloc_f((int64_t)B * Tout * up.cout);
+    const bool up_src_act = cur.act != kNone;  // the producer already applied LeakyReLU(up_slope)
     for (int r = 0; r < s; ++r) {
       TapConvParams p{};
       p.B = B;
@@ -192,15 +216,19 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
       p.sw = s;
       p.ow0 = r;
       p.bias = up.bias;
-      p.out = const_cast<float*>(rel_ptr(y));
+      p.out = const_cast<float*>(rel_ptr(y.raw));
       p.act_slope = 1.f;
+      if (!fuse) {
+        p.out_act = const_cast<float*>(rel_ptr(y.act));
+        p.act_slope = cfg.voc_res_slope;
+      }
       p.nseg = 1;
       TapSeg& S = p.seg[0];
-      S.src = rel_ptr(x);
+      S.src = rel_ptr(up_src_act ? cur.act : cur.raw);
       S.C = up.cin;
-      S.act = st == 0 ? ACT_NONE : ACT_LEAKY;  // stage 0 reads the activated output of the k7 convolution
-      S.slope = st == 0 ? 1.f : cfg.voc_up_slope;
-      S.src_act = st == 0 ? 1 : 0;
+      S.act = up_src_act ? ACT_NONE : ACT_LEAKY;
+      S.slope = up_src_act ? 1.f : cfg.voc_up_slope;
+      S.src_act = up_src_act ? 1 : 0;
       S.wt = up.w_phase[r];
       S.ntaps = 0;
       for (auto& ek : phase_taps(s, pad, r)) {
@@ -210,18 +238,17 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
       }
       pb.add_conv(p);
     }
-    pb.free(x);
-    x = y;
+    free_forms(cur);
+    cur = y;
     Tlen = Tout;
     int dil = 1;
-    // HBM-bound stacks (C = 64, 128) run each layer as ONE fused launch (resblock.hip); `VFX_NO_FUSE` keeps
-    // the two-launch form for A/B measurements.
-    const bool fuse = cfg.precision != 0 && resblock_supported(up.cout) && !getenv("VFX_NO_FUSE");
-    for (auto& layer : W->res[st]) {
+    const size_t nlayers = W->res[st].size();
+    for (size_t li = 0; li < nlayers; ++li) {
+      auto& layer = W->res[st][li];
       if (fuse) {
         const size_t y2 = pb.alloc_f((int64_t)B * Tlen * up.cout);
         ResBlockParams rp{};
-        rp.x = rel_ptr(x);
+        rp.x = rel_ptr(cur.raw);
         rp.y = const_cast<float*>(rel_ptr(y2));
         rp.w1 = layer.first.w;
         rp.w2 = layer.second.w;
@@ -233,20 +260,29 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.C = up.cout;
         rp.dil = dil;
         pb.add_resblock(rp);
-        pb.free(x);
-        x = y2;
-        dil *= cfg.voc_dilation_base;
-        continue;
+        free_forms(cur);
+        cur = Forms{};
+        cur.raw = y2;
+      } else {
+        // conv1 reads the activated trunk and writes h activated for conv2; conv2 adds the raw trunk and writes the
+        // next trunk: both forms inside the stack, after its last layer only what the consumer reads (the next
+        // upsampler: activated with its LeakyReLU slope; the vocoder tail: raw)
+        const bool last_layer = li + 1 == nlayers;
+        const Forms hbuf = conv1d(layer.first, cur.act, Tlen, 3, dil, ACT_LEAKY, cfg.voc_res_slope, false, nullptr,
+                                  /*src_act=*/true, /*want_raw=*/false, ACT_LEAKY, cfg.voc_res_slope);
+        const bool want_raw = !last_layer || last_stage;
+        const int next_act = last_layer && last_stage ? ACT_NONE : ACT_LEAKY;
+        const Forms y2 = conv1d(layer.second, hbuf.act, Tlen, 3, 1, ACT_LEAKY, cfg.voc_res_slope, false, &cur.raw,
+                                /*src_act=*/true, want_raw, next_act, last_layer ? cfg.voc_up_slope : cfg.voc_res_slope);
+        free_forms(hbuf);
+        free_forms(cur);
+        cur = y2;
       }
-      const size_t hbuf = conv1d(layer.first, x, Tlen, 3, dil, ACT_LEAKY, cfg.voc_res_slope, false, nullptr,
-                                 /*src_act=*/false, ACT_LEAKY, cfg.voc_res_slope);
-      const size_t y2 = conv1d(layer.second, hbuf, Tlen, 3, 1, ACT_LEAKY, cfg.voc_res_slope, false, &x, /*src_act=*/true);
-      pb.free(hbuf);
-      pb.free(x);
-      x = y2;
       dil *= cfg.voc_dilation_base;
     }
   }
+  x = cur.raw;
+  VFX_CHECK(x != kNone, "vocoder plan: the tail needs the raw trunk");
   {
     const size_t xo = x;
     const int Tl = Tlen;
@@ -258,7 +294,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
                        c.stream);
     });
   }
-  pb.free(x);
+  free_forms(cur);
 }
 
 }  // namespace vfx
