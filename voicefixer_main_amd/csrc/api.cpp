@@ -292,13 +292,17 @@ void build_stages(const TapConvParams& p, const float* ones, const float* zeros,
           st.ntaps = 1;
           st.dh0 = S.dh[w];
           st.dw0 = S.dw[w];
-          st.poff[0] = 0;
+          st.poff[0] = 0;  // tile-sized patch, no shift
         } else {
           st.wt = S.wt + (int64_t)ch * S.ntaps * tstride;
           st.ntaps = S.ntaps;
           st.dh0 = p.dh_min;
           st.dw0 = p.dw_min;
-          for (int t = 0; t < S.ntaps; ++t) st.poff[t] = (S.dh[t] - p.dh_min) * p.PW + (S.dw[t] - p.dw_min);
+          for (int t = 0; t < S.ntaps; ++t) {  // row offset | column shift << 16 | row shift << 24 (conv.hip, compute())
+            const int dpi = S.dh[t] - p.dh_min, dpj = S.dw[t] - p.dw_min;
+            VFX_CHECK(dpi < 128 && dpj < 256 && dpi * p.PW + dpj < 65536, "conv: tap offset out of range");
+            st.poff[t] = (dpi * p.PW + dpj) | (dpj << 16) | (dpi << 24);
+          }
         }
         out[k++] = st;
       }

@@ -53,7 +53,7 @@ namespace vfx {
 // bit 0 no patch request, 1 no weight loads, 2 no barrier, 3 constant fragment addresses, 4 no fragment reads,
 // 5 no epilogue.
 template <int BN, bool ELU, bool SPLIT, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict__ pp) {
+__global__ __launch_bounds__(256, BN == 32 ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
   constexpr int WAVES_N = BN / 32;
   constexpr int WM = BN / 32;  // 32-row blocks per wave (= 4 / WAVES_M)
 
@@ -96,8 +96,20 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
   const int lr = tid >> 3, cg = tid & 7;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tw_shift = p.tw_shift, TWm1 = p.TW - 1, TH = p.TH;
-  const int key_l = (lr >> 1) & 7;                         // swizzle key of this thread's patch rows (lr + 32q)
-  const unsigned dma_piece = (unsigned)(cg ^ key_l) << 4;  // the DMA lane fetches the piece that belongs in slot cg
+  // Swizzle key of patch pixel (pi, pj): ((pj >> 1) + (TW / 2) * pi) & 7.  With an even patch width the bank half of
+  // LDS row pi*PW + pj is pj & 1, and the 16 lanes of a ds_read_b128 group -- runs of consecutive columns in TW-wide
+  // tile rows -- get 16 distinct (bank half, slot) pairs for every tap shift; for a 1-D patch this is (row >> 1) & 7.
+  // The BN = 128 tile (dominated by the vocoder's 1-D layers, and short of registers) keeps the 1-D form
+  // (LDS row >> 1) & 7: cheaper per tap, 2-way conflicts on the 2-D levels it also serves.
+  constexpr bool SWZ2D = BN <= 64;
+  const int hTW = p.TW >> 1;
+  int keyq[CNQ];  // key of this thread's patch pixels lr + 32q
+#pragma unroll
+  for (int q = 0; q < CNQ; ++q) {
+    const int prow = lr + 32 * q;
+    const int pi = prow / PW, pj = prow - pi * PW;
+    keyq[q] = SWZ2D ? ((pj >> 1) + hTW * pi) & 7 : (prow >> 1) & 7;
+  }
   if (tid < CBM) {
     const int li = tid >> tw_shift, lj = tid & TWm1;
     const int i = i0 + li, j = j0 + lj;
@@ -120,11 +132,13 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
   const int wm = wave_u / WAVES_N, wn = wave_u % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
   int arow[WM];  // patch row of this lane's pixel of M block a (tap offset added per step)
+  int ak0[WM];   // its swizzle key before the tap shift: (lj >> 1) + (TW / 2) * li, column parity in bit 16
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
     const int ml = (wm * WM + a) * 32 + l31;
-    const int li = ml >> tw_shift;
-    arow[a] = li < TH ? li * PW + (ml & TWm1) : 0;
+    const int li = ml >> tw_shift, lj = ml & TWm1;
+    arow[a] = li < TH ? li * PW + lj : 0;
+    ak0[a] = li < TH ? (((lj >> 1) + hTW * li) | ((lj & 1) << 16)) : 0;
   }
   const unsigned nb_off = (unsigned)(((n0 >> 5) + wn) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block
 
@@ -167,9 +181,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((const float*)S.src), 0, (int)S.nbytes, 0x00020000);
     praw = (S.flags & 1) == 0;
-    const unsigned piece = praw ? 16u * cg : dma_piece;
 #pragma unroll
     for (int q = 0; q < CNQ; ++q) {
+      // the lane's bytes always land in slot cg: an activated source is fetched pre-swizzled (piece cg ^ key)
+      const unsigned piece = praw ? 16u * cg : (unsigned)(cg ^ keyq[q]) << 4;
       const unsigned o = (okmask & (1u << q)) ? voff[q] + piece : 0xfffffff0u;
       VFX_LDS void* l = (VFX_LDS void*)(lds + dst + (32 * q + 8 * wave_u) * CROW);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
@@ -212,22 +227,26 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
           const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
           // hi of channels 4cg..4cg+3: piece cg>>1, half cg&1; lo: piece 4 + (cg>>1)
           const int half = 8 * (cg & 1);
-          *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ key_l) << 4) + half) = make_uint2(h01, h23);
-          *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ key_l) << 4) + half) = make_uint2(l01, l23);
+          *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ keyq[q]) << 4) + half) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ keyq[q]) << 4) + half) = make_uint2(l01, l23);
         } else {
-          *reinterpret_cast<f32x4*>(rowp + ((cg ^ key_l) << 4)) = v;
+          *reinterpret_cast<f32x4*>(rowp + ((cg ^ keyq[q]) << 4)) = v;
         }
       }
   };
 
-  auto compute = [&](const BFrag& R, int src, int toff) __attribute__((always_inline)) {
+  // `tap` = ConvStage::poff entry: patch row offset of the tap in bits 0..15, its column shift in 16..23, row shift in 24..31
+  auto compute = [&](const BFrag& R, int src, int tap) __attribute__((always_inline)) {
     const char* base[WM];
     int key[WM];
+    const int toff = tap & 0xffff, dpj = (tap >> 16) & 0xff, kdi = hTW * (tap >> 24);
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
       const int row = (ABL & 8) ? arow[a] : arow[a] + toff;
       base[a] = (ABL & 8) ? lds + row * CROW : lds + src + row * CROW;
-      key[a] = (ABL & 8) ? 0 : ((row >> 1) & 7) << 4;
+      // key of pixel (li + dpi, lj + dpj): ((lj + dpj) >> 1) = (lj >> 1) + (((lj & 1) + dpj) >> 1)
+      if constexpr (SWZ2D) key[a] = (((ak0[a] & 0xffff) + (((ak0[a] >> 16) + dpj) >> 1) + kdi) & 7) << 4;
+      else key[a] = (ABL & 8) ? 0 : ((row >> 1) & 7) << 4;
     }
     if constexpr (SPLIT) {
 #pragma unroll
@@ -283,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(const TapConvParams* __restrict
   // until the end-of-stage barrier.
   // vmcnt bookkeeping at the wait for tap t >= RING-1: younger operations = 4 * (RING-1) weight loads
   // + CNQ if the patch has been requested (t >= TP).
-  constexpr int RING = WM >= 4 ? 2 : 3;
+  constexpr int RING = WM == 2 ? 3 : 2;  // BN = 32 trades the third group for a third wave per SIMD (152 VGPRs)
   constexpr int AHEAD = RING - 1;
   BFrag R0, R1, R2;
   auto ring = [&](int i) __attribute__((always_inline)) -> BFrag& { return i % RING == 0 ? R0 : (i % RING == 1 ? R1 : R2); };

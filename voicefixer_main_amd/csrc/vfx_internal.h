@@ -81,7 +81,7 @@ struct ConvStage {
   int tap_stride;      // floats between the weights of consecutive taps (Cout * 32)
   int flags;           // bit 0: src is an activated tensor (LDS-DMA copy, no prologue)
   unsigned nbytes;     // bytes addressable from src (buffer descriptor bound; reads past it return 0)
-  int poff[16];        // patch row offset of every tap (kMaxTaps used)
+  int poff[16];        // per tap (kMaxTaps used): patch row offset | column shift << 16 | row shift << 24
 };
 static_assert(sizeof(ConvStage) == 128, "ConvStage is read as a 128-byte record");
 
