@@ -258,7 +258,7 @@ static void plan_conv(TapConvParams& p) {
   }
 }
 
-int count_stages(const TapConvParams& p) {
+int count_stages(const TapConvParams& p) {  // per phase, for a phased launch
   int n = 0;
   for (int s = 0; s < p.nseg; ++s) n += (p.seg[s].C / kKC) * (p.per_tap ? p.seg[s].ntaps : 1);
   return n;
@@ -266,7 +266,7 @@ int count_stages(const TapConvParams& p) {
 
 void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out) {
   int k = 0;
-  const int64_t tstride = (int64_t)p.Cout * kKC;
+  const int64_t tstride = (int64_t)(p.nphase > 1 ? p.cout_phase : p.Cout) * kKC;  // couts of ONE weight tensor
   for (int s = 0; s < p.nseg; ++s) {
     const TapSeg& S = p.seg[s];
     // per-tap launches run tap-major: the patch origin (and with it the kernel's cached pixel offsets)
@@ -389,6 +389,24 @@ void PlanBuilder::add_conv(TapConvParams p) {
   });
 }
 
+void PlanBuilder::add_conv_phased(TapConvParams p, const std::vector<TapSeg>& phases) {
+  VFX_CHECK(p.nseg == 1 && !phases.empty() && p.Cout % (int)phases.size() == 0, "phased conv: bad arguments");
+  p.nphase = (int)phases.size();
+  p.cout_phase = p.Cout / p.nphase;
+  VFX_CHECK(p.cout_phase % 32 == 0, "phased conv: %d couts per phase", p.cout_phase);
+  const size_t idx = plan->host_params.size();
+  plan->phase_segs[idx] = phases;
+  add_conv(p);
+  TapConvParams& hp = plan->host_params[idx];
+  VFX_CHECK(!hp.per_tap, "phased conv: the union of the phases' taps does not fit one patch");
+  // algorithmic work: every phase multiplies by its own taps only
+  double k = 0;
+  for (auto& S : phases) k += (double)S.ntaps * S.C;
+  const double fl = 2.0 * (double)hp.M * hp.cout_phase * k;
+  plan->conv_flops += fl - conv_flops(hp);
+  hp.flops_override = fl;
+}
+
 void PlanBuilder::add_resblock(ResBlockParams p) {
   plan_resblock(p);
   const size_t idx = plan->host_rb.size();
@@ -448,7 +466,7 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     return reinterpret_cast<const float*>(base + reinterpret_cast<size_t>(rel) - 1);
   };
   size_t total_stages = 0;
-  for (auto& p : abs) total_stages += p.nstages;
+  for (auto& p : abs) total_stages += (size_t)p.nstages * std::max(p.nphase, 1);
   if (!plan.dev_stages && total_stages)
     plan.dev_stages = static_cast<ConvStage*>(plan.blob.alloc(total_stages * sizeof(ConvStage)));
   std::vector<ConvStage> stages(total_stages);
@@ -458,9 +476,20 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     if (p.residual) p.residual = rebase(p.residual);
     if (p.out) p.out = const_cast<float*>(rebase(p.out));
     if (p.out_act) p.out_act = const_cast<float*>(rebase(p.out_act));
-    build_stages(p, h->d_ones, h->d_zeros, stages.data() + so);
+    const size_t pidx = &p - abs.data();
+    if (p.nphase > 1) {  // one stage table per phase, built from that phase's segment on the common patch geometry
+      const std::vector<TapSeg>& segs = plan.phase_segs.at(pidx);
+      for (int r = 0; r < p.nphase; ++r) {
+        TapConvParams q = p;
+        q.seg[0] = segs[r];
+        q.seg[0].src = rebase(q.seg[0].src);
+        build_stages(q, h->d_ones, h->d_zeros, stages.data() + so + (size_t)r * p.nstages);
+      }
+    } else {
+      build_stages(p, h->d_ones, h->d_zeros, stages.data() + so);
+    }
     p.stages = plan.dev_stages + so;
-    so += p.nstages;
+    so += (size_t)p.nstages * std::max(p.nphase, 1);
   }
   if (total_stages)
     VFX_HIP(hipMemcpy(plan.dev_stages, stages.data(), total_stages * sizeof(ConvStage), hipMemcpyHostToDevice));
@@ -938,7 +967,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       } else {
         bool elu = false;
         for (int s2 = 0; s2 < d.nseg; ++s2) elu = elu || d.seg[s2].act == ACT_ELU;
-        snprintf(kname, sizeof(kname), "k_conv<%d; %s; %s>", conv_block_n(d.Cout), elu ? "true" : "false", d.split ? "true" : "false");
+        snprintf(kname, sizeof(kname), "k_conv<%d; %s; %s>", conv_block_n(d), elu ? "true" : "false", d.split ? "true" : "false");
       }
       fprintf(dump, "%zu,%s,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i, kname, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C,
               d.Wi, d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12);

@@ -66,7 +66,6 @@ __global__ __launch_bounds__(256, BN == 32 ? 3 : 2) void k_conv(const TapConvPar
   // The stage table is read-only for the whole launch: address it in the constant address space so
   // that every descriptor field is a scalar load.
   typedef const ConvStage VFX_CONST* StageTab;
-  const StageTab stages = (StageTab)(uintptr_t)p.stages;
   const int nstages = p.nstages;
   const int tid = threadIdx.x;
   const int n_tiles = p.Cout / BN;
@@ -80,6 +79,10 @@ __global__ __launch_bounds__(256, BN == 32 ? 3 : 2) void k_conv(const TapConvPar
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   const int n0 = (tile % n_tiles) * BN;
+  // phased launch: this block's couts belong to phase n0 / cout_phase -- own stage table, own weight tensor
+  const int phase = p.nphase > 1 ? n0 / p.cout_phase : 0;
+  const int n0w = p.nphase > 1 ? n0 - phase * p.cout_phase : n0;  // first cout inside the phase's weight tensor
+  const StageTab stages = (StageTab)(uintptr_t)p.stages + phase * nstages;
   int mt = tile / n_tiles;  // spatial tile: (image, tile row, tile col), col fastest
   const int tj = mt % p.tiles_w;
   mt /= p.tiles_w;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, BN == 32 ? 3 : 2) void k_conv(const TapConvPar
     arow[a] = li < TH ? li * PW + lj : 0;
     ak0[a] = li < TH ? (((lj >> 1) + hTW * li) | ((lj & 1) << 16)) : 0;
   }
-  const unsigned nb_off = (unsigned)(((n0 >> 5) + wn) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block
+  const unsigned nb_off = (unsigned)(((n0w >> 5) + wn) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block
 
   // ---- patch (A) staging ------------------------------------------------------------------------
   // The byte offset of every patch pixel is kept in registers and only recomputed when the patch
@@ -452,7 +455,15 @@ static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams*
   }
 }
 
-int conv_block_n(int Cout) { return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32); }
+// Couts per block: the widest tile that divides Cout, unless that leaves the chip under-filled (the deep
+// ResUNet levels have 16 .. 64 spatial tiles): then narrower tiles, i.e. more blocks of less work each.
+int conv_block_n(const TapConvParams& hp) {
+  const int64_t spatial = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
+  const int cdiv = hp.nphase > 1 ? hp.cout_phase : hp.Cout;  // a block never straddles two phases
+  int bn = cdiv % 128 == 0 ? 128 : (cdiv % 64 == 0 ? 64 : 32);
+  while (bn > 32 && spatial * (hp.Cout / bn) < 384) bn >>= 1;
+  return bn;
+}
 
 void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream) {
   VFX_CHECK(hp.nstages > 0 && hp.P > 0 && hp.P <= kPatchMaxRows && hp.TH * hp.TW <= CBM, "conv: bad stage geometry");
@@ -462,7 +473,7 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
   if (elu)
     for (int s = 0; s < hp.nseg; ++s)
       VFX_CHECK(hp.seg[s].act == ACT_ELU, "conv: ELU cannot be mixed with other prologues in one launch");
-  const int BN = conv_block_n(hp.Cout);
+  const int BN = conv_block_n(hp);
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w * (hp.Cout / BN);
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "conv: bad grid");
 #ifdef VFX_ABLATION_BUILD
@@ -480,6 +491,7 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
 }
 
 double conv_flops(const TapConvParams& hp) {
+  if (hp.flops_override > 0) return hp.flops_override;
   double k = 0;
   for (int s = 0; s < hp.nseg; ++s) k += (double)hp.seg[s].ntaps * hp.seg[s].C;
   return 2.0 * (double)hp.M * hp.Cout * k;

@@ -110,6 +110,12 @@ struct TapConvParams {
   int dh_min, dw_min;     // patch origin of the all-taps window
   int nstages;
   const ConvStage* stages;  // device table (bind time)
+  // Phased launch (the output phases of a transposed convolution as ONE launch): Cout = nphase * cout_phase, the
+  // couts [r * cout_phase, (r+1) * cout_phase) are phase r with its own stage table (stages + r * nstages) and its own
+  // weight tensor.  With the output viewed as (B, T, nphase * cout_phase) this IS ConvTranspose1d's (B, T * nphase,
+  // cout_phase): the input patch is fetched from HBM once for all phases.  nphase = 0 / 1: ordinary launch.
+  int nphase, cout_phase;
+  double flops_override;  // algorithmic flops when they are not 2 * M * Cout * K (phased launches)
   const float* bias;     // [Cout] or nullptr
   const float* residual; // (B, Ho, Wo, Cout) or nullptr, added in the epilogue
   float* out;            // raw fp32 output (B, Ho, Wo, Cout) or nullptr
@@ -153,7 +159,7 @@ void finish_params(TapConvParams& p);  // fills total_steps, M and the tile / pa
 int count_stages(const TapConvParams& p);
 void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out);  // p: absolute pointers
 void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
-int conv_block_n(int Cout);
+int conv_block_n(const TapConvParams& hp);
 double conv_flops(const TapConvParams& hp);
 
 // ---------------------------------------------------------------------------------------------
@@ -243,6 +249,7 @@ struct Plan {
   std::vector<TapConvParams> host_params;  // arena-relative until bind()
   TapConvParams* dev_params = nullptr;
   ConvStage* dev_stages = nullptr;
+  std::map<size_t, std::vector<TapSeg>> phase_segs;  // phased launches: host_params index -> per-phase segment
   std::vector<ResBlockParams> host_rb;     // arena-relative until bind()
   ResBlockParams* dev_rb = nullptr;
   DeviceBlob blob;
@@ -270,6 +277,8 @@ struct PlanBuilder {
   // Adds a tap-convolution whose src/residual/out pointers are arena offsets encoded as
   // (const float*)offset; they are rebased in Plan::bind.
   void add_conv(TapConvParams p);
+  // p.seg[0] carries the UNION of the phases' taps (geometry only); phases[r] = source / prologue / taps / weights of phase r
+  void add_conv_phased(TapConvParams p, const std::vector<TapSeg>& phases);
   void add_resblock(ResBlockParams p);  // x / y are arena offsets encoded with rel_ptr()
 };
 
@@ -303,7 +312,7 @@ struct UNetWeights {
 
 struct VocConvW {
   float* w = nullptr;     // packed (per phase for transposed convs: w_phase[r])
-  float* bias = nullptr;
+  float* bias = nullptr;  // [cout]; transposed convs: repeated once per output phase ([stride][cout])
   std::vector<float*> w_phase;
   int cin = 0, cout = 0;
 };

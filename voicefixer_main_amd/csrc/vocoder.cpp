@@ -83,7 +83,13 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
       for (auto& ek : phase_taps(s, pad, r)) taps.push_back({0, ek.second});
       up.w_phase.push_back(h->blob.upload(pack_conv_transposed(w.data.data(), c, c / 2, 1, 2 * s, taps, h->cfg.precision != 0)));
     }
-    up.bias = h->blob.upload(staged(h, std::string(name) + ".bias").data);
+    {  // the phased launch sees the output as (B, T, stride * cout): one bias copy per phase
+      const std::vector<float>& b = staged(h, std::string(name) + ".bias").data;
+      VFX_CHECK((int)b.size() == c / 2, "vocoder tensor '%s.bias' has an unexpected shape", name);
+      std::vector<float> rep;
+      for (int r = 0; r < s; ++r) rep.insert(rep.end(), b.begin(), b.end());
+      up.bias = h->blob.upload(rep);
+    }
     W->up.push_back(up);
     c /= 2;
     std::vector<std::pair<VocConvW, VocConvW>> stack;
@@ -205,16 +211,16 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     y.raw = pb.alloc_f((int64_t)B * Tout * up.cout);
     if (!fuse) y.act = pb.alloc_f((int64_t)B * Tout * up.cout);
     const bool up_src_act = cur.act != kNone;  // the producer already applied LeakyReLU(up_slope)
-    for (int r = 0; r < s; ++r) {
+    {
+      // ConvTranspose1d(k = 2s, stride s) as ONE phased launch: output phase r (samples s*q + r) is a 2-tap
+      // convolution of the input, and (B, Tlen * s, cout) viewed as (B, Tlen, s * cout) makes the phases plain cout
+      // ranges -- the input patch is read from HBM once for all of them (it was read s times as s launches).
       TapConvParams p{};
       p.B = B;
       p.Hi = p.Hg = p.Ho = 1;
-      p.Wi = p.Wg = Tlen;
-      p.Wo = Tout;
-      p.Cout = up.cout;
-      p.sh = 1;
-      p.sw = s;
-      p.ow0 = r;
+      p.Wi = p.Wg = p.Wo = Tlen;
+      p.Cout = s * up.cout;
+      p.sh = p.sw = 1;
       p.bias = up.bias;
       p.out = const_cast<float*>(rel_ptr(y.raw));
       p.act_slope = 1.f;
@@ -223,20 +229,34 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         p.act_slope = cfg.voc_res_slope;
       }
       p.nseg = 1;
-      TapSeg& S = p.seg[0];
-      S.src = rel_ptr(up_src_act ? cur.act : cur.raw);
-      S.C = up.cin;
-      S.act = up_src_act ? ACT_NONE : ACT_LEAKY;
-      S.slope = up_src_act ? 1.f : cfg.voc_up_slope;
-      S.src_act = up_src_act ? 1 : 0;
-      S.wt = up.w_phase[r];
-      S.ntaps = 0;
-      for (auto& ek : phase_taps(s, pad, r)) {
-        S.dh[S.ntaps] = 0;
-        S.dw[S.ntaps] = -ek.first;
-        ++S.ntaps;
+      std::vector<TapSeg> phases(s);
+      int e_lo = 1 << 30, e_hi = -(1 << 30);
+      for (int r = 0; r < s; ++r) {
+        TapSeg& S = phases[r];
+        S = TapSeg{};
+        S.src = rel_ptr(up_src_act ? cur.act : cur.raw);
+        S.C = up.cin;
+        S.act = up_src_act ? ACT_NONE : ACT_LEAKY;
+        S.slope = up_src_act ? 1.f : cfg.voc_up_slope;
+        S.src_act = up_src_act ? 1 : 0;
+        S.wt = up.w_phase[r];
+        for (auto& ek : phase_taps(s, pad, r)) {
+          S.dh[S.ntaps] = 0;
+          S.dw[S.ntaps] = -ek.first;
+          ++S.ntaps;
+          e_lo = std::min(e_lo, -ek.first);
+          e_hi = std::max(e_hi, -ek.first);
+        }
       }
-      pb.add_conv(p);
+      TapSeg& U = p.seg[0];  // union of the phases' taps: fixes the patch window
+      U = phases[0];
+      U.ntaps = 0;
+      for (int dw = e_lo; dw <= e_hi; ++dw) {
+        U.dh[U.ntaps] = 0;
+        U.dw[U.ntaps] = dw;
+        ++U.ntaps;
+      }
+      pb.add_conv_phased(p, phases);
     }
     free_forms(cur);
     cur = y;
