@@ -74,3 +74,18 @@ def test_poisoned_arena_stays_finite(unet_sd, voc_sd, monkeypatch):
     sp = eng.stft(wav, want_mel=False, want_sp=True)["sp"]
     for y in (eng.resunet_spec(sp, wav), eng.restore_gsr(wav), eng.vocoder(eng.stft(wav)["mel"])):
         assert bool(torch.isfinite(y).all())
+
+
+def test_sub_batches_match_single_launch(engine, monkeypatch):
+    """Batches whose activations would pass 4 GiB run as consecutive sub-batches (32-bit offsets in the
+    convolution kernels); forcing that path with VFX_MAX_CLIPS must not change a single bit."""
+    from voicefixer_main_amd import synth
+    wav = torch.from_numpy(synth.make_clips(3, 0.7, seed=51)[:, 0]).cuda()
+    whole = engine.restore_gsr(wav).clone()
+    monkeypatch.setenv("VFX_MAX_CLIPS", "2")
+    parts = engine.restore_gsr(wav)
+    mel = engine.stft(wav)["mel"]
+    voc_parts = engine.vocoder(mel)
+    monkeypatch.delenv("VFX_MAX_CLIPS")
+    assert torch.equal(parts, whole)
+    assert torch.equal(voc_parts, engine.vocoder(mel))

@@ -835,7 +835,41 @@ int vfx_reserve(vfx_handle* h, int model, int B, int T) {
   VFX_API_END
 }
 
+// The convolution kernels address a tensor with 32-bit byte offsets (buffer descriptors, LDS-DMA), so one
+// launch handles tensors below 4 GiB.  A batch whose largest activation would exceed that is run as
+// consecutive sub-batches on the same stream (clips are independent; each sub-batch re-uses the cached plan).
+// Largest activation per clip: ResUNet level 1 (Tpad x W x 32 ch) and the vocoder's widest-in-bytes stack.
+static int max_clips_per_launch(const vfx_handle* h, int T, bool unet_mel, bool unet_spec, bool voc) {
+  const int64_t Tpad = (T + 63) / 64 * 64;
+  int64_t per_clip = 1;
+  if (unet_mel) per_clip = std::max<int64_t>(per_clip, Tpad * 127 * 64 * 4);      // cat(up, skip) of 2 x 32 channels
+  if (unet_spec) per_clip = std::max<int64_t>(per_clip, Tpad * 1024 * 64 * 4);
+  if (voc) {
+    int64_t len = T + T % 2 + 4, c = h->cfg.voc_channels;
+    per_clip = std::max(per_clip, len * c * 4);
+    for (int i = 0; i < h->cfg.voc_n_stages; ++i) {
+      len *= h->cfg.voc_scales[i];
+      c /= 2;
+      per_clip = std::max(per_clip, len * c * 4);
+    }
+  }
+  int64_t lim = (((int64_t)1 << 32) - (1 << 20)) / per_clip;
+  if (const char* e = getenv("VFX_MAX_CLIPS")) lim = std::min<int64_t>(lim, atoi(e));  // tests: force the sub-batch path
+  return (int)std::max<int64_t>(1, std::min<int64_t>(lim, 1 << 20));
+}
+
+static int vfx_resunet_mel_1(vfx_handle* h, const float* mel_linear, int B, int T, float* logmel_out, void* stream);
 int vfx_resunet_mel(vfx_handle* h, const float* mel_linear, int B, int T, float* logmel_out, void* stream) {
+  if (!h || B <= 0 || T <= 0) return vfx_resunet_mel_1(h, mel_linear, B, T, logmel_out, stream);
+  const int step = max_clips_per_launch(h, T, true, false, false);
+  for (int b = 0; b < B; b += step) {
+    const int rc = vfx_resunet_mel_1(h, mel_linear + (int64_t)b * T * 128, std::min(step, B - b), T,
+                                     logmel_out + (int64_t)b * T * 128, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static int vfx_resunet_mel_1(vfx_handle* h, const float* mel_linear, int B, int T, float* logmel_out, void* stream) {
   VFX_API_BEGIN
   VFX_CHECK(h && mel_linear && logmel_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL], "vfx_resunet_mel: weights of the mel ResUNet are not finalized");
@@ -846,8 +880,22 @@ int vfx_resunet_mel(vfx_handle* h, const float* mel_linear, int B, int T, float*
   VFX_API_END
 }
 
+static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, int B, int T, int L, float* wav_out,
+                              void* stream);
 int vfx_resunet_spec(vfx_handle* h, const float* sp, const float* wav, int B, int T, int L, float* wav_out,
                      void* stream) {
+  if (!h || B <= 0 || T <= 0) return vfx_resunet_spec_1(h, sp, wav, B, T, L, wav_out, stream);
+  const int step = max_clips_per_launch(h, T, false, true, false);
+  const int64_t nb = h->cfg.n_fft / 2 + 1;
+  for (int b = 0; b < B; b += step) {
+    const int rc = vfx_resunet_spec_1(h, sp + (int64_t)b * T * nb, wav + (int64_t)b * L, std::min(step, B - b), T, L,
+                                      wav_out + (int64_t)b * L, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, int B, int T, int L, float* wav_out,
+                              void* stream) {
   VFX_API_BEGIN
   VFX_CHECK(h && sp && wav && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->unet[VFX_MODEL_UNET_SPEC], "vfx_resunet_spec: weights of the spectrogram ResUNet are not finalized");
@@ -880,7 +928,18 @@ int vfx_resunet_spec(vfx_handle* h, const float* sp, const float* wav, int B, in
 
 int64_t vfx_vocoder_out_len(vfx_handle* h, int T) { return h ? vocoder_out_len(h->cfg, T) : -1; }
 
+static int vfx_vocoder_1(vfx_handle* h, const float* mel_linear, int B, int T, float* wav_out, void* stream);
 int vfx_vocoder(vfx_handle* h, const float* mel_linear, int B, int T, float* wav_out, void* stream) {
+  if (!h || B <= 0 || T <= 0) return vfx_vocoder_1(h, mel_linear, B, T, wav_out, stream);
+  const int step = max_clips_per_launch(h, T, false, false, true);
+  const int64_t Llong = vocoder_out_len(h->cfg, T);
+  for (int b = 0; b < B; b += step) {
+    const int rc = vfx_vocoder_1(h, mel_linear + (int64_t)b * T * 128, std::min(step, B - b), T, wav_out + (int64_t)b * Llong, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static int vfx_vocoder_1(vfx_handle* h, const float* mel_linear, int B, int T, float* wav_out, void* stream) {
   VFX_API_BEGIN
   VFX_CHECK(h && mel_linear && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->voc, "vfx_vocoder: vocoder weights are not finalized");
@@ -890,8 +949,22 @@ int vfx_vocoder(vfx_handle* h, const float* mel_linear, int B, int T, float* wav
   VFX_API_END
 }
 
+static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, float* wav_out, float* logmel_out, int flags,
+                             void* stream);
 int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_out, float* logmel_out, int flags,
                     void* stream) {
+  if (!h || B <= 0 || L <= 0) return vfx_restore_gsr_1(h, wav, B, L, wav_out, logmel_out, flags, stream);
+  const int T = L / h->cfg.hop + 1;
+  const int step = max_clips_per_launch(h, T, true, false, true);
+  for (int b = 0; b < B; b += step) {
+    const int rc = vfx_restore_gsr_1(h, wav + (int64_t)b * L, std::min(step, B - b), L, wav_out + (int64_t)b * L,
+                                     logmel_out ? logmel_out + (int64_t)b * T * 128 : nullptr, flags, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, float* wav_out, float* logmel_out, int flags,
+                             void* stream) {
   VFX_API_BEGIN
   VFX_CHECK(h && wav && wav_out && B > 0, "bad argument");
   VFX_CHECK(L > h->cfg.n_fft / 2, "vfx_restore_gsr: clip too short for reflect padding (L=%d)", L);
