@@ -134,6 +134,22 @@ int vfx_vocoder(vfx_handle* h, const float* mel_linear, int B, int T, float* wav
 int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_out,
                     float* logmel_out, int flags, void* stream);
 
+/*
+ * Long-audio chunkers: the two `LambdaOverlapAdd` classes (tools/dsp/overlapadd.py:337-480 and
+ * tools/dsp/overlapadd_boxcar.py:338-513) segment a signal, run the network per chunk and stitch.  The
+ * network call stays with the caller (all equal-length chunks as ONE batch); these are the two data
+ * movements around it.
+ *
+ * vfx_chunk_gather = F.unfold with zero padding (overlapadd.py:421-428, overlapadd_boxcar.py:436-452):
+ *   x (B, L) -> chunks (B, n_chunks, win), chunks[b][k][i] = x[b][k*hop - lead + i], 0 outside [0, L).
+ * vfx_chunk_ola = synthesis window (or `scale` when window is NULL) + F.fold (overlapadd.py:455-471):
+ *   frames (B, n_chunks, win) -> y (B, L), y[b][n] = sum_k frames[b][k][n + lead - k*hop] * window[..].
+ */
+int vfx_chunk_gather(vfx_handle* h, const float* x, int B, int L, int win, int hop, int lead,
+                     int n_chunks, float* chunks, void* stream);
+int vfx_chunk_ola(vfx_handle* h, const float* frames, const float* window, float scale, int B,
+                  int n_chunks, int win, int hop, int lead, int L, float* y, void* stream);
+
 /* Read-and-clear the sticky device flags (synchronises `stream`). */
 int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out);
 

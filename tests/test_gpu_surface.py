@@ -152,3 +152,62 @@ def test_graph_capture_restore_and_streaming_step(engine):
     g2.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, ref)
+
+
+def _toy_net(x):
+    """oracle.chunker.toy_nnet as device code (test stand-in for a network)."""
+    prev = torch.cat([torch.zeros_like(x[..., :1]), x[..., :-1]], -1)
+    n = x.shape[-1]
+    ramp = (torch.arange(n, dtype=torch.float32, device=x.device) / n) * 0.05
+    return {"wav": 0.6 * x + 0.3 * prev + ramp}
+
+
+def test_chunkers_vs_reference_golden(engine):
+    """Both long-audio chunkers (batched nnet calls + vfx_chunk_gather / vfx_chunk_ola) against the outputs of
+    the REFERENCE classes (tests/golden/chunker.npz), and against the oracle at an unaligned length."""
+    from oracle import chunker as oc
+    from voicefixer_main_amd.chunker import LambdaOverlapAdd, LambdaOverlapAddBoxcar
+    g = np.load(os.path.join(G, "chunker.npz"))
+    names = [k[:-2] for k in g.files if k.endswith("_y")]
+    assert len(names) == 10
+    for name in names:
+        x, y = g[name + "_x"], g[name + "_y"]
+        W, p, hann = [int(v) for v in g[name + "_cfg"]]
+        w = "hanning" if hann else "boxcar"
+        if name.startswith("ola"):
+            m = LambdaOverlapAdd(_toy_net, 1, W, hop_size=p, window=w, engine=engine, max_batch=5)
+        else:
+            m = LambdaOverlapAddBoxcar(_toy_net, 1, W, p, window=w, reorder_chunks=False, engine=engine, max_batch=3)
+        got = m(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert got.shape == y.shape, name
+        assert np.abs(got - y).max() <= 1e-6, (name, np.abs(got - y).max())
+    # odd sizes (scalar gather path), un-windowed branch
+    x = np.random.default_rng(9).uniform(-1, 1, (2, 1, 1237)).astype(np.float32)
+    m = LambdaOverlapAdd(_toy_net, 1, 126, hop_size=21, window=None, engine=engine)
+    ref = oc.overlap_add(oc.toy_nnet, x, 126, 21, None)
+    assert np.abs(m(torch.from_numpy(x).cuda()).cpu().numpy() - ref).max() <= 2e-6
+    m = LambdaOverlapAddBoxcar(_toy_net, 1, 126, 7, window=None, engine=engine)
+    ref = oc.overlap_add_boxcar(oc.toy_nnet, x, 126, 7, None)
+    assert np.abs(m(torch.from_numpy(x).cuda()).cpu().numpy() - ref).max() <= 1e-6
+    with pytest.raises(NotImplementedError):
+        LambdaOverlapAdd(_toy_net, 2, 64, engine=engine)
+
+
+def test_chunked_restore_batched_equals_sequential(voicefixer):
+    """A 3.3-s clip restored through 1-s frames with 0.1-s margins: all inner frames as one batch must be
+    bit-identical to the reference's one-chunk-at-a-time order, and every frame equal to restoring that frame
+    (with its margins) on its own."""
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.chunker import LambdaOverlapAdd, LambdaOverlapAddBoxcar
+    wav = torch.from_numpy(synth.make_clips(1, 3.3, seed=21)).cuda()            # (1, 1, L)
+    nnet = lambda c: {"wav": voicefixer.restore(c)}
+    W, M = 44100, 4410
+    batched = LambdaOverlapAddBoxcar(nnet, 1, W, M, window=None, engine=voicefixer.engine)(wav)
+    seq = LambdaOverlapAddBoxcar(nnet, 1, W, M, window=None, engine=voicefixer.engine, max_batch=1)(wav)
+    assert batched.shape == wav.shape and torch.isfinite(batched).all()
+    assert torch.equal(batched, seq)
+    own = voicefixer.restore(wav[..., W - M:2 * W + M].contiguous())[..., M:-M]   # frame 1 on its own
+    assert torch.equal(batched[..., W:2 * W], own)
+    a = LambdaOverlapAdd(nnet, 1, W, window="hanning", engine=voicefixer.engine)(wav)
+    b = LambdaOverlapAdd(nnet, 1, W, window="hanning", engine=voicefixer.engine, max_batch=1)(wav)
+    assert a.shape == wav.shape and torch.equal(a, b)

@@ -41,6 +41,9 @@ SIGNATURES = {
     "vfx_stft_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vfx_mel_project": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "vfx_istft": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vfx_chunk_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vfx_chunk_ola": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
+                      c_void_p, c_void_p]),
     "vfx_resunet_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vfx_resunet_spec": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vfx_vocoder_out_len": (c_int64, [c_void_p, c_int]),

@@ -754,6 +754,24 @@ int vfx_mel_project(vfx_handle* h, const float* sp, int64_t rows, float* mel, vo
   VFX_API_END
 }
 
+int vfx_chunk_gather(vfx_handle* h, const float* x, int B, int L, int win, int hop, int lead, int n_chunks,
+                     float* chunks, void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && x && chunks && B > 0 && L > 0 && win > 0 && hop > 0 && lead >= 0 && n_chunks > 0, "bad argument");
+  VFX_CHECK(B <= 65535 && n_chunks <= 65535, "chunk grid too large");
+  launch_chunk_gather(x, B, L, win, hop, lead, n_chunks, chunks, static_cast<hipStream_t>(stream));
+  VFX_API_END
+}
+
+int vfx_chunk_ola(vfx_handle* h, const float* frames, const float* window, float scale, int B, int n_chunks, int win,
+                  int hop, int lead, int L, float* y, void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && frames && y && B > 0 && L > 0 && win > 0 && hop > 0 && lead >= 0 && n_chunks > 0, "bad argument");
+  VFX_CHECK(B <= 65535, "batch too large");
+  launch_chunk_ola(frames, window, scale, B, n_chunks, win, hop, lead, L, y, static_cast<hipStream_t>(stream));
+  VFX_API_END
+}
+
 int vfx_istft(vfx_handle* h, const float* re, const float* im, int B, int T, int L, float* wav, void* stream) {
   VFX_API_BEGIN
   VFX_CHECK(h && re && im && wav && B > 0 && T > 0 && L > 0, "bad argument");

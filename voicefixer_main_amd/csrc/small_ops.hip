@@ -395,4 +395,71 @@ void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float*
   VFX_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// long-audio chunkers (tools/dsp/overlapadd.py, tools/dsp/overlapadd_boxcar.py)
+// ---------------------------------------------------------------------------------------------
+// F.unfold with zero padding (overlapadd.py:421-428; overlapadd_boxcar.py:436-452):
+//   chunks[b][k][i] = x[b][k * hop - lead + i], zero outside [0, L).
+// One thread per 4 consecutive chunk samples; 16-byte loads when the chunk grid is 16-byte aligned.
+template <bool VEC>
+__global__ void k_chunk_gather(const float* __restrict__ x, int L, int win, int hop, int lead, int n_chunks,
+                               float* __restrict__ chunks) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= win) return;
+  const int k = blockIdx.y, b = blockIdx.z;
+  const int64_t src = (int64_t)k * hop - lead + i;
+  const float* xb = x + (int64_t)b * L;
+  float* dst = chunks + ((int64_t)b * n_chunks + k) * win + i;
+  if (VEC) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (src >= 0 && src + 4 <= L) v = *reinterpret_cast<const f32x4*>(xb + src);
+    *reinterpret_cast<f32x4*>(dst) = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i + e < win) dst[e] = (src + e >= 0 && src + e < L) ? xb[src + e] : 0.f;
+  }
+}
+
+void launch_chunk_gather(const float* x, int B, int L, int win, int hop, int lead, int n_chunks, float* chunks,
+                         hipStream_t s) {
+  const dim3 grid(nblocks(win, 1024), n_chunks, B);
+  const bool vec = (win % 4 == 0) && (hop % 4 == 0) && (lead % 4 == 0) && (L % 4 == 0) &&
+                   (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(chunks) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL(k_chunk_gather<true>, grid, dim3(256), 0, s, x, L, win, hop, lead, n_chunks, chunks);
+  else
+    hipLaunchKernelGGL(k_chunk_gather<false>, grid, dim3(256), 0, s, x, L, win, hop, lead, n_chunks, chunks);
+  VFX_HIP(hipGetLastError());
+}
+
+// Synthesis window (or 1 / (win / hop) scale) + F.fold (overlapadd.py:455-471; overlapadd_boxcar.py:494-507):
+//   y[b][n] = sum_k frames[b][k][n + lead - k * hop] * w[n + lead - k * hop]   over the chunks that cover n,
+// summed in ascending k (a gather, so no atomics and a fixed order).
+__global__ void k_chunk_ola(const float* __restrict__ frames, const float* __restrict__ window, float scale,
+                            int n_chunks, int win, int hop, int lead, int L, float* __restrict__ y) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= L) return;
+  const int b = blockIdx.y;
+  const int pos = n + lead;
+  const int k1 = min(n_chunks - 1, pos / hop);
+  const int k0 = max(0, (pos - win + hop) / hop);  // ceil((pos - win + 1) / hop) for pos - win + 1 > 0
+  const float* fb = frames + (int64_t)b * n_chunks * win;
+  float acc = 0.f;
+  for (int k = k0; k <= k1; ++k) {
+    const int i = pos - k * hop;
+    if (i < 0 || i >= win) continue;
+    const float f = fb[(int64_t)k * win + i];
+    acc += window ? f * window[i] : f * scale;
+  }
+  y[(int64_t)b * L + n] = acc;
+}
+
+void launch_chunk_ola(const float* frames, const float* window, float scale, int B, int n_chunks, int win, int hop,
+                      int lead, int L, float* y, hipStream_t s) {
+  hipLaunchKernelGGL(k_chunk_ola, dim3(nblocks(L, 256), B), dim3(256), 0, s, frames, window, scale, n_chunks, win,
+                     hop, lead, L, y);
+  VFX_HIP(hipGetLastError());
+}
+
 }  // namespace vfx

@@ -198,6 +198,10 @@ void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int
                      hipStream_t s);
 void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, bool have_peak, float* out,
                       hipStream_t s);
+void launch_chunk_gather(const float* x, int B, int L, int win, int hop, int lead, int n_chunks, float* chunks,
+                         hipStream_t s);
+void launch_chunk_ola(const float* frames, const float* window, float scale, int B, int n_chunks, int win, int hop,
+                      int lead, int L, float* y, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // handle-side data structures

@@ -145,6 +145,28 @@ class Engine:
         _lib.check(self.lib.vfx_istft(self.h, _ptr(re), _ptr(im), B, T, length, _ptr(wav), self._stream()), "vfx_istft")
         return wav
 
+    def chunk_gather(self, x, win, hop, lead, n_chunks):
+        """F.unfold with zero padding: x (B, L) -> (B, n_chunks, win), chunk k = x[k*hop - lead : ... + win]."""
+        x = _dev_f32(x, self.device)
+        B, L = x.shape
+        chunks = torch.empty((B, n_chunks, win), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.vfx_chunk_gather(self.h, _ptr(x), B, L, win, hop, lead, n_chunks, _ptr(chunks),
+                                             self._stream()), "vfx_chunk_gather")
+        return chunks
+
+    def chunk_ola(self, frames, window, scale, hop, lead, length):
+        """Synthesis window (or scale) + F.fold: frames (B, n_chunks, win) -> (B, length)."""
+        frames = _dev_f32(frames, self.device)
+        B, n_chunks, win = frames.shape
+        if window is not None:
+            window = _dev_f32(window, self.device)
+            assert window.numel() == win
+        y = torch.empty((B, length), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.vfx_chunk_ola(self.h, _ptr(frames), _ptr(window) if window is not None else None,
+                                          float(scale), B, n_chunks, win, hop, lead, length, _ptr(y),
+                                          self._stream()), "vfx_chunk_ola")
+        return y
+
     def resunet_mel(self, mel_linear):
         """Generator.forward: linear mel (B,T,128) -> log10 mel (B,T,128)."""
         mel = _dev_f32(mel_linear, self.device)
