@@ -34,7 +34,7 @@
 //     sits at slot p ^ ((r >> 1) & 7), applied on the DMA's SOURCE address and on every read, which
 //     makes the 16-lane groups of the ds_read_b128 fragment reads conflict-free.
 //   B (weights): never touch LDS.  Packed on the host in MFMA fragment order, they go
-//     global -> VGPR -> MFMA through a ring of three (two for BN = 128) register groups.  The loads
+//     global -> VGPR -> MFMA through a ring of three (two for BN = 32) register groups.  The loads
 //     are inline asm with hand-counted s_waitcnt vmcnt(N): beside an LDS-DMA the compiler would
 //     wait vmcnt(0) for every ordinary load and drain the patch prefetch at each tap.
 //
@@ -51,9 +51,9 @@ namespace vfx {
 
 // ABL != 0: timing-only ablation builds (-DVFX_ABLATION_BUILD + VFX_ABLATE, wrong results), in the stage loop:
 // bit 0 no patch request, 1 no weight loads, 2 no barrier, 3 constant fragment addresses, 4 no fragment reads,
-// 5 no epilogue.
-template <int BN, bool ELU, bool SPLIT, int ABL = 0>
-__global__ __launch_bounds__(256, BN == 32 ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
+// 5 no epilogue, 6 the end-of-stage wait leaves the patch in flight.
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3>
+__global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
   constexpr int WAVES_N = BN / 32;
   constexpr int WM = BN / 32;  // 32-row blocks per wave (= 4 / WAVES_M)
 
@@ -295,107 +295,99 @@ __global__ __launch_bounds__(256, BN == 32 ? 3 : 2) void k_conv(const TapConvPar
     }
   };
 
-  // ---- stage bodies ------------------------------------------------------------------------------
-  // One straight-line body per tap count NT.  Weight fragments: ring of RING register groups (3, or 2 for
-  // the register-hungry BN = 128 tile), tap t in group t % RING, fetched RING-1 taps ahead (the fetches of
-  // the last taps of a stage go to the first taps of the following stage(s)).  On entry the fragments of
-  // the stage's first RING-1 taps have landed (every body ends with vmcnt(0)).  The next stage's patch is
-  // requested right after the fetch of the stage's LAST tap: every weight wait of the stage is then for a
-  // load issued before the patch request (vmcnt retires in order), so the patch prefetch stays in flight
-  // until the end-of-stage barrier.
-  // vmcnt bookkeeping at the wait for tap t >= RING-1: younger operations = 4 * (RING-1) weight loads
-  // + CNQ if the patch has been requested (t >= TP).
-  constexpr int RING = WM == 2 ? 3 : 2;  // BN = 32 trades the third group for a third wave per SIMD (152 VGPRs)
+  // ---- tap loop ----------------------------------------------------------------------------------
+  // ONE loop over the flattened tap sequence of the launch (stage 0 tap 0, tap 1, ..., stage 1 tap 0, ...),
+  // unrolled by the depth of the weight ring so that tap g always computes from ring group g % RING and
+  // fetches tap g + RING-1 into group (g + RING-1) % RING: the accumulators and the ring flow through one
+  // straight chain (a per-tap-count switch of bodies made the compiler copy all accumulators at every merge).
+  // Everything that depends on the position inside the stage (t of NT taps) is a uniform scalar branch:
+  //   t == 0        barrier: patch `st` is visible and every wave is done with the buffer patch st+1 overwrites;
+  //   t == TP       the next stage's patch is requested right after the fetch of the stage's LAST tap
+  //                 (TP = NT-1-AHEAD), so every weight wait of the stage is for a load issued before the patch
+  //                 request (vmcnt retires in order) and the patch stays in flight until the end of the stage;
+  //   t >= AHEAD    wait for this tap's weights: younger operations = 4 * AHEAD weight loads (+ CNQ once the
+  //                 patch has been requested, t >= TP); the first AHEAD taps of a stage landed at the previous
+  //                 stage's end;
+  //   t == NT-1     everything in flight (next taps' weights, the patch) lands before the transform / barrier.
   constexpr int AHEAD = RING - 1;
   BFrag R0, R1, R2;
-  auto ring = [&](int i) __attribute__((always_inline)) -> BFrag& { return i % RING == 0 ? R0 : (i % RING == 1 ? R1 : R2); };
-  auto body = [&](auto NTc, const ConvStage VFX_CONST& S, const ConvStage VFX_CONST& N, const ConvStage VFX_CONST& N2,
-                  int cur, int nxt) __attribute__((always_inline)) {
-    constexpr int NT = decltype(NTc)::value;
-    constexpr int TP = NT > AHEAD ? NT - 1 - AHEAD : 0;  // the patch request follows the weight fetch issued in iteration TP
-    const float* wt = (const float*)S.wt;
-    const int64_t ts = S.tap_stride;
-    int poff[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) poff[t] = S.poff[t];
-    // taps NT, NT+1 of the flattened tap sequence: first taps of the following stage(s)
-    const float* nw0 = (const float*)N.wt;
-    const float* nw1 = N.ntaps >= 2 ? (const float*)N.wt + N.tap_stride : (const float*)N2.wt;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      BFrag& cur_r = ring(t);
-      const int j = t + AHEAD;  // tap fetched now
-      const float* fw = j < NT ? wt + j * ts : (j == NT ? nw0 : nw1);
-      if constexpr (!(ABL & 2)) load_b_asm(ring(j), fw, nb_off);
-      if constexpr (!(ABL & 1))
-        if (t == TP) issue_patch(N, nxt);
-      if (t >= AHEAD && !(ABL & 3)) {
-        if (t >= TP) wait_b<4 * AHEAD + CNQ>(cur_r);
-        else wait_b<4 * AHEAD>(cur_r);
-      }
-      compute(cur_r, cur, poff[t]);
-      __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of tap t+1 below the MFMAs of tap t (register pressure)
-    }
-    // everything in flight (next taps' weights, the patch) must have landed before the transform / the
-    // barrier / the moves below
-    if constexpr (RING == 3)
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]),
-                     "+v"(R1.f[3]), "+v"(R2.f[0]), "+v"(R2.f[1]), "+v"(R2.f[2]), "+v"(R2.f[3])
-                   :
-                   : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]),
-                     "+v"(R1.f[3])
-                   :
-                   : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (praw) transform_patch(N, nxt);
-    // the next stage's first taps sit in groups NT % RING, ...: rotate them into R0 (, R1)
-    if constexpr (RING == 3) {
-      if constexpr (NT % 3 == 1) {
-        R0 = R1;
-        R1 = R2;
-      } else if constexpr (NT % 3 == 2) {
-        R1 = R0;
-        R0 = R2;
-      }
+  const int last = nstages - 1;
+  // Cursor state lives in scalar registers; table fields are re-read only when a cursor enters a new stage, and the
+  // tap descriptor of the next step is loaded at the end of the current one (no scalar-load latency inside a step).
+  int st = 0, t = 0;                       // current tap: stage st, tap t
+  int NT = stages[0].ntaps;                // taps of the current stage
+  int tap = stages[0].poff[0];             // ConvStage::poff entry of the current tap
+  int fs = 0, ft = 0;                      // fetch cursor: AHEAD taps further on
+  int fnt = stages[0].ntaps;               // (clamped to the last stage: refetched, never consumed)
+  int64_t fstride = stages[0].tap_stride;
+  const float* fw = (const float*)stages[0].wt;
+  auto fetch = [&](BFrag& R) __attribute__((always_inline)) {
+    if constexpr (!(ABL & 2)) load_b_asm(R, fw, nb_off);
+    if (++ft >= fnt) {
+      ft = 0;
+      fs = fs < last ? fs + 1 : last;
+      const ConvStage VFX_CONST& F = stages[fs];
+      fw = (const float*)F.wt;
+      fstride = F.tap_stride;
+      fnt = F.ntaps;
     } else {
-      if constexpr (NT % 2 == 1) R0 = R1;
+      fw += fstride;
     }
   };
-
-  // ---- stage loop ----------------------------------------------------------------------------------
-  {
-    const ConvStage VFX_CONST& S0 = stages[0];
-    const ConvStage VFX_CONST& S1 = stages[nstages > 1 ? 1 : 0];
-    load_b_asm(R0, (const float*)S0.wt, nb_off);
-    if constexpr (RING == 3) load_b_asm(R1, S0.ntaps >= 2 ? (const float*)S0.wt + S0.tap_stride : (const float*)S1.wt, nb_off);
-    else R1 = R0;
-    issue_patch(S0, 0);
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]), "+v"(R1.f[3])
-                 :
-                 : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (praw) transform_patch(S0, 0);
-  }
-  const int last = nstages - 1;
-  for (int st = 0; st < nstages; ++st) {
-    const ConvStage VFX_CONST& S = stages[st];
-    const ConvStage VFX_CONST& N = stages[st + 1 < last ? st + 1 : last];   // past the end: refetch (never consumed)
-    const ConvStage VFX_CONST& N2 = stages[st + 2 < last ? st + 2 : last];
-    const int cur = (st & 1) * CPATCH, nxt = ((st + 1) & 1) * CPATCH;
-    const int ntaps = S.ntaps;
-    if constexpr (!(ABL & 4)) __syncthreads();  // patch `st` is visible; every wave is done with the buffer patch st+1 will overwrite
-    switch (ntaps) {
-      case 1: body(std::integral_constant<int, 1>{}, S, N, N2, cur, nxt); break;
-      case 2: body(std::integral_constant<int, 2>{}, S, N, N2, cur, nxt); break;
-      case 3: body(std::integral_constant<int, 3>{}, S, N, N2, cur, nxt); break;
-      case 4: body(std::integral_constant<int, 4>{}, S, N, N2, cur, nxt); break;
-      case 7: body(std::integral_constant<int, 7>{}, S, N, N2, cur, nxt); break;
-      default: body(std::integral_constant<int, 9>{}, S, N, N2, cur, nxt); break;
+  auto step = [&](BFrag& cur_r, BFrag& fetch_r) __attribute__((always_inline)) {
+    const int TP = NT > AHEAD ? NT - 1 - AHEAD : 0;
+    const int cur = (st & 1) * CPATCH, nxt = CPATCH - cur;
+    if (t == 0 && !(ABL & 4)) __syncthreads();
+    fetch(fetch_r);
+    if constexpr (!(ABL & 1))
+      if (t == TP) issue_patch(stages[st < last ? st + 1 : last], nxt);  // past the end: refetched, never consumed
+    // The waits carry no register operands on purpose: a conditional asm that redefined the ring group would end
+    // in a merge, and a merge copy placed before the wait would read registers whose load is still in flight.  The
+    // group becomes readable at the unconditional use_b() below.
+    if (t >= AHEAD && !(ABL & 3)) {
+      if (t >= TP) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * AHEAD + CNQ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * AHEAD) : "memory");
+    }
+    use_b(cur_r);
+    compute(cur_r, cur, tap);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of the next tap below the MFMAs of this one (register pressure)
+    if (t == NT - 1) {
+      if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * AHEAD + CNQ) : "memory");  // patch latency never exposed
+      else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (praw) transform_patch(stages[st < last ? st + 1 : last], nxt);
+      ++st;
+      t = 0;
+      NT = stages[st < last ? st : last].ntaps;
+    } else {
+      ++t;
+    }
+    tap = stages[st < last ? st : last].poff[t];  // next step's tap (all fragment reads of this step have been consumed)
+  };
+  fetch(R0);
+  if constexpr (RING == 3) fetch(R1);
+  else R1 = R0;
+  issue_patch(stages[0], 0);
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+  use_b(R0);
+  use_b(R1);
+  R2 = R1;  // defined; overwritten by the first step's fetch
+  if (praw) transform_patch(stages[0], 0);
+  if constexpr (RING == 3) {
+    while (true) {
+      step(R0, R2);
+      if (st > last) break;
+      step(R1, R0);
+      if (st > last) break;
+      step(R2, R1);
+      if (st > last) break;
+    }
+  } else {
+    while (true) {
+      step(R0, R1);
+      if (st > last) break;
+      step(R1, R0);
+      if (st > last) break;
     }
   }
 
@@ -417,16 +409,16 @@ static size_t conv_lds_bytes(int BN) {
   return main_bytes + CBM * 4;
 }
 
-template <int BN, bool ELU, bool SPLIT, int ABL = 0>
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3>
 static void launch_one(int grid, hipStream_t stream, const TapConvParams* dparams) {
   const size_t lds = conv_lds_bytes(BN);
   static bool attr_set = false;
   if (!attr_set) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL>),
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL>), dim3(grid), dim3(256), lds, stream, dparams);
+  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING>), dim3(grid), dim3(256), lds, stream, dparams);
 }
 
 #ifdef VFX_ABLATION_BUILD
@@ -441,6 +433,9 @@ static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvP
     case 7: launch_one<128, false, true, 7>(grid, stream, dparams); return true;
     case 23: launch_one<128, false, true, 23>(grid, stream, dparams); return true;
     case 55: launch_one<128, false, true, 55>(grid, stream, dparams); return true;
+    case 64: launch_one<128, false, true, 64>(grid, stream, dparams); return true;
+    case 68: launch_one<128, false, true, 68>(grid, stream, dparams); return true;
+    case 96: launch_one<128, false, true, 96>(grid, stream, dparams); return true;
     default: return false;
   }
 }
@@ -451,7 +446,7 @@ static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams*
   switch (BN) {
     case 128: launch_one<128, ELU, SPLIT>(grid, stream, dparams); break;
     case 64: launch_one<64, ELU, SPLIT>(grid, stream, dparams); break;
-    default: launch_one<32, ELU, SPLIT>(grid, stream, dparams); break;
+    default: launch_one<32, ELU, SPLIT, 0, 2>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
   }
 }
 

@@ -44,6 +44,13 @@ __device__ __forceinline__ void wait_b(BFrag& R) {
   __builtin_amdgcn_sched_barrier(0);  // nothing that reads R may be scheduled above the wait
 }
 
+// The group's registers are readable from here on (the s_waitcnt that made them so precedes this in program order:
+// asm volatile statements are not reordered); nothing that reads R may be scheduled above it.
+__device__ __forceinline__ void use_b(BFrag& R) {
+  asm volatile("" : "+v"(R.f[0]), "+v"(R.f[1]), "+v"(R.f[2]), "+v"(R.f[3]) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Logical patch-row layout: a row is 128 bytes = 8 pieces of 16 bytes (split-bf16: pieces 0..3 = 32 hi bf16,
 // 4..7 = 32 lo bf16; fp32: 32 floats).  Piece p of LDS row r sits at slot p ^ ((r >> 1) & 7).
 __device__ __forceinline__ int swz_key(int row) { return ((row >> 1) & 7) << 4; }
