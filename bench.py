@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--cpu-baseline-clips", type=int, default=2, help="clips in the CPU-oracle sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--precision", type=int, default=1, help="0 = exact fp32 MFMA, 1 = split-bf16 (hi+lo, 3 bf16 MFMAs)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16-vocoder (precision 2) timing at N = 1")
+    ap.add_argument("--precision", type=int, default=1, help="0 = exact fp32 MFMA, 1 = split-bf16 (hi+lo, 3 bf16 MFMAs), 2 = ResUNet split-bf16 + vocoder plain bf16")
     return ap.parse_args()
 
 
@@ -102,7 +103,7 @@ def measure_roofline(eng, wav, out, args):
     dom = max(per, key=lambda k: per[k][1])
     cnt, kms, kfl = per[dom]
     tflops = kfl / (kms * 1e-3) / 1e12
-    split = args.precision == 1
+    split = args.precision >= 1
     peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     traffic, traffic_detail = None, None
     tpath = os.path.join(HERE, "profiles", "r01_traffic.json")
@@ -114,14 +115,17 @@ def measure_roofline(eng, wav, out, args):
                 traffic = traffic_detail["bytes_per_launch"] if traffic_detail else None
         except Exception:
             traffic, traffic_detail = None, None
+    plain = "bf16" in dom.split(">")[-1]     # a plain-bf16 launch of the precision-2 vocoder: one MFMA per product
+    per_product = 1 if (plain or not split) else 3
     return {
         "bound": "mfma",
-        "kernel": "%s (%s)" % (dom, "3 x v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
+        "kernel": "%s (%s)" % (dom, "1 x v_mfma_f32_32x32x16_bf16 per product (plain bf16 operands), fp32 accumulate" if plain
+                               else "3 x v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
                                if split else "v_mfma_f32_32x32x2_f32"),
         "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
         # achieved counts ALGORITHMIC flops (2*M*N*K once); in split-bf16 mode the kernel issues 3 bf16 MFMAs per
         # product, so `frac` is bounded by 1/3 and mfma_issue_frac is the share of the MFMA pipe actually used
-        "mfma_issue_frac": round(tflops * (3 if split else 1) / peak, 4),
+        "mfma_issue_frac": round(tflops * per_product / peak, 4),
         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC passes of profiles/r01_traffic.json)",
         "traffic_detail": traffic_detail,
         "launches_per_step": cnt // steps,
@@ -203,7 +207,9 @@ def main():
             "value": round(audio_s / dt, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)" if args.precision == 1 else "f32", "data": "synthetic",
+            "dtype": {0: "f32", 1: "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)",
+                      2: "bf16 (vocoder: plain bf16 operands; ResUNet: split-bf16 hi+lo; fp32 accumulate)"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": "gsr_voicefixer ResUNet+vocoder restore, batch=%dx%.0f s @44.1 kHz per GPU "
                                    "(BASELINE.json configs[1]); plain bf16 operands miss the log-mel L1<=1e-3 parity bar by "
                                    "19x, split-bf16 meets it with >10x margin" % (B, args.seconds),
@@ -213,6 +219,30 @@ def main():
         }
         if roofline:
             res["roofline"] = roofline
+        if world == 1 and args.precision == 1 and not args.no_alt:
+            # Same workload with the vocoder on plain bf16 operands (precision 2): reported beside `value`, never as it --
+            # its waveform meets an SI-SDR bar (40 dB vs the fp32 oracle) instead of the split mode's 88-94 dB.
+            try:
+                alt = Engine(device, config={"precision": 2})
+                alt.load_state_dict(MODEL_UNET_MEL, synth.make_resunet_state_dict(0))
+                alt.load_state_dict(MODEL_VOCODER, synth.make_vocoder_state_dict(1))
+                for _ in range(max(args.warmup, 1)):
+                    alt.restore_gsr(wav, out=out)
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    alt.restore_gsr(wav, out=out)
+                torch.cuda.synchronize(device)
+                dta = time.perf_counter() - t1
+                res["bf16_vocoder_mode"] = {
+                    "value": round(B * args.seconds * args.steps / dta, 2), "unit": "audio-s/s",
+                    "ms_per_step": round(dta / args.steps * 1e3, 3), "outputs_finite": bool(torch.isfinite(out).all().item()),
+                    "dtype": "vocoder: plain bf16 operands (1 MFMA per product); ResUNet: split-bf16; fp32 accumulate",
+                    "parity": "ResUNet log-mel L1 4e-5 (unchanged); waveform SI-SDR 40 dB vs the fp32 oracle "
+                              "(tests/test_gpu_models.py::test_bf16_vocoder_mode; split mode: 88-94 dB)"}
+                del alt
+            except Exception as e:
+                res["bf16_vocoder_mode"] = {"error": repr(e)}
         if world == 1 and args.cpu_baseline_clips > 0:
             try:
                 res["cpu_baseline"] = cpu_baseline(clips, args.cpu_baseline_clips, args.cpu_threads)

@@ -61,7 +61,10 @@ typedef struct vfx_config {
    * 1 (default) = split-bf16: every operand is hi + lo (two bf16), products hi*hi + hi*lo +
    *     lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-16 relative operand
    *     error; log-mel L1 vs the fp64 oracle 4e-5..8e-5, bar 1e-3);
-   * 0 = exact fp32 (v_mfma_f32_32x32x2_f32), log-mel L1 5e-6..1e-5, ~1.8x slower. */
+   * 0 = exact fp32 (v_mfma_f32_32x32x2_f32), log-mel L1 5e-6..1e-5, ~1.8x slower;
+   * 2 = "bf16 vocoder": the ResUNets as 1 (they carry the log-mel bar), the TFGAN vocoder with
+   *     plain bf16 operands (the hi halves only: one MFMA per product, fp32 accumulation) --
+   *     BASELINE.json's bf16 for config 2; waveform parity is then an SI-SDR bar, see DESIGN.md. */
   int precision;
 } vfx_config;
 

@@ -126,3 +126,24 @@ def test_scatter_gather_two_ranks_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
+
+
+def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
+    """The convolution kernels load weight fragments with inline-asm global loads and hand-counted s_waitcnt; a
+    compiler-generated copy of such a register before its wait reads stale data (a bug that only shows when the
+    register file holds garbage).  Compile both kernels to gfx950 assembly and scan them
+    (scripts/asm_inflight_check.py)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "voicefixer_main_amd", "csrc")
+    for name in ("conv.hip", "resblock.hip"):
+        out = str(tmp_path / (name + ".s"))
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                        "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, name)], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "asm_inflight_check.py"), out],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]

@@ -362,6 +362,42 @@ void finish_params(TapConvParams& p) {
 // ---------------------------------------------------------------------------------------------
 // plans
 // ---------------------------------------------------------------------------------------------
+// Debug hooks.  VFX_POISON_ARENA=2: the bytes of the arena the plan owns are set to NaN patterns before EVERY call, so
+// that a kernel reading a workspace buffer nobody wrote shows up whatever ran before.  VFX_DEBUG_NAN: after every
+// GEMM-shaped launch the outputs are scanned for non-finite values (synchronises; the first hit is reported on stderr).
+static int debug_level(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
+
+// Called by the entry points before anything of the call is staged in the arena.
+static void debug_poison(const Plan& plan, void* stream) {
+  if (debug_level("VFX_POISON_ARENA") >= 2 && plan.bound_base && plan.arena_bytes)
+    VFX_HIP(hipMemsetAsync(plan.bound_base, 0xFF, plan.arena_bytes, static_cast<hipStream_t>(stream)));
+}
+
+void Plan::run(const RunCtx& ctx) {
+  if (debug_level("VFX_DEBUG_NAN") >= 2 && bound_base && arena_bytes) {
+    // whole-arena scan after every op (tiny shapes only)
+    for (size_t i = 0; i < ops.size(); ++i) {
+      ops[i](ctx);
+      const int64_t bad = count_nonfinite(reinterpret_cast<const float*>(bound_base), (int64_t)(arena_bytes / 4), ctx.stream);
+      fprintf(stderr, "[vfx debug] after op %zu of %zu: %lld non-finite floats in the arena\n", i, ops.size(), (long long)bad);
+    }
+    return;
+  }
+  for (auto& f : ops) f(ctx);
+}
+
+static void debug_scan(const Plan* pl, const char* what, size_t idx, const float* rel, int64_t n, int M, int Cout, int K,
+                       hipStream_t s) {
+  if (!rel) return;
+  const float* p = reinterpret_cast<const float*>(pl->bound_base + reinterpret_cast<size_t>(rel) - 1);
+  const int64_t bad = count_nonfinite(p, n, s);
+  if (bad) fprintf(stderr, "[vfx debug] %s #%zu (M=%d Cout=%d K=%d): %lld of %lld non-finite\n", what, idx, M, Cout, K,
+                   (long long)bad, (long long)n);
+}
+
 void PlanBuilder::add_conv(TapConvParams p) {
   p.split = h->cfg.precision != 0;
   finish_params(p);
@@ -385,6 +421,14 @@ void PlanBuilder::add_conv(TapConvParams p) {
       c.prof->desc.push_back(pl->host_params[idx]);
     } else {
       launch(pl->host_params[idx], pl->dev_params + idx, c.stream);
+    }
+    if (debug_level("VFX_DEBUG_NAN")) {
+      const TapConvParams& q = pl->host_params[idx];
+      int K = 0;
+      for (int s2 = 0; s2 < q.nseg; ++s2) K += q.seg[s2].ntaps * q.seg[s2].C;
+      const int64_t n = (int64_t)q.B * q.out_img_stride * q.Cout;
+      debug_scan(pl, "conv out", idx, q.out, n, q.M, q.Cout, K, c.stream);
+      debug_scan(pl, "conv out_act", idx, q.out_act, n, q.M, q.Cout, K, c.stream);
     }
   });
 }
@@ -432,10 +476,13 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
       d.Wi = hp.dil;
       d.seg[0].C = hp.C;
       d.seg[0].ntaps = 6;
+      d.hionly = hp.hionly;
       c.prof->desc.push_back(d);
     } else {
       launch_resblock(hp, pl->dev_rb + idx, c.stream);
     }
+    if (debug_level("VFX_DEBUG_NAN"))
+      debug_scan(pl, "resblock y", idx, hp.y, (int64_t)hp.B * hp.T * hp.C, hp.B * hp.T, hp.C, 6 * hp.C, c.stream);
   });
 }
 
@@ -893,6 +940,7 @@ static int vfx_resunet_mel_1(vfx_handle* h, const float* mel_linear, int B, int 
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL], "vfx_resunet_mel: weights of the mel ResUNet are not finalized");
   auto plan = get_plan(h, key_of("unet_mel", B, T),
                        [&](PlanBuilder& pb) { build_unet_mel(pb, B, T, ext(0), ext(1)); });
+  debug_poison(*plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
@@ -929,6 +977,7 @@ static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, 
     nm["frames"] = pb.alloc_f((size_t)B * T * h->cfg.n_fft);
     build_unet_spec(pb, B, T, ext(0), arena_buf(nm["cos"]), arena_buf(nm["sin"]), arena_buf(nm["re"]), arena_buf(nm["im"]));
   });
+  debug_poison(*plan, stream);
   const size_t off_cos = plan->named["cos"], off_sin = plan->named["sin"], off_re = plan->named["re"],
                off_im = plan->named["im"], off_frames = plan->named["frames"];
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -962,6 +1011,7 @@ static int vfx_vocoder_1(vfx_handle* h, const float* mel_linear, int B, int T, f
   VFX_CHECK(h && mel_linear && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->voc, "vfx_vocoder: vocoder weights are not finalized");
   auto plan = get_plan(h, key_of("vocoder", B, T), [&](PlanBuilder& pb) { build_vocoder(pb, B, T, ext(0), ext(1)); });
+  debug_poison(*plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), wav_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
@@ -1016,6 +1066,7 @@ static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, floa
                        reinterpret_cast<float*>(pl->bound_base + o_pk), /*have_peak=*/true, c.ext[1], c.stream);
     });
   });
+  debug_poison(*plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
@@ -1054,11 +1105,12 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       for (int s2 = 0; s2 < d.nseg; ++s2) K += d.seg[s2].ntaps * d.seg[s2].C;
       char kname[64];
       if (d.nseg == 0) {  // fused ResStack layer
-        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>", d.Cout, d.Cout == 64 ? 4 : 8);
+        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.Cout == 64 ? 4 : 8, d.hionly ? " bf16" : "");
       } else {
         bool elu = false;
         for (int s2 = 0; s2 < d.nseg; ++s2) elu = elu || d.seg[s2].act == ACT_ELU;
-        snprintf(kname, sizeof(kname), "k_conv<%d; %s; %s>", conv_block_n(d), elu ? "true" : "false", d.split ? "true" : "false");
+        snprintf(kname, sizeof(kname), "k_conv<%d; %s; %s>%s", conv_block_n(d), elu ? "true" : "false", d.split ? "true" : "false",
+                 d.hionly ? " bf16" : "");
       }
       fprintf(dump, "%zu,%s,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i, kname, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C,
               d.Wi, d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12);

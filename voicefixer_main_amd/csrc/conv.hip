@@ -38,7 +38,8 @@
 //     are inline asm with hand-counted s_waitcnt vmcnt(N): beside an LDS-DMA the compiler would
 //     wait vmcnt(0) for every ordinary load and drain the patch prefetch at each tap.
 //
-// Arithmetic (vfx_config.precision)
+// Arithmetic (vfx_config.precision; 2 = as 1, except that the vocoder's launches set TapConvParams::hionly and
+// multiply the hi halves only: plain bf16 operands, one MFMA per product, fp32 accumulate)
 //   1: split-bf16 -- every operand is hi + lo (two bf16), products hi*hi + hi*lo + lo*hi on
 //      v_mfma_f32_32x32x16_bf16, fp32 accumulate (~2^-16 relative operand error);
 //   0: exact fp32 on v_mfma_f32_32x32x2_f32.
@@ -52,7 +53,7 @@ namespace vfx {
 // ABL != 0: timing-only ablation builds (-DVFX_ABLATION_BUILD + VFX_ABLATE, wrong results), in the stage loop:
 // bit 0 no patch request, 1 no weight loads, 2 no barrier, 3 constant fragment addresses, 4 no fragment reads,
 // 5 no epilogue, 6 the end-of-stage wait leaves the patch in flight.
-template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3>
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false>
 __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
   constexpr int WAVES_N = BN / 32;
   constexpr int WM = BN / 32;  // 32-row blocks per wave (= 4 / WAVES_M)
@@ -251,7 +252,18 @@ __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvPar
       if constexpr (SWZ2D) key[a] = (((ak0[a] & 0xffff) + (((ak0[a] >> 16) + dpj) >> 1) + kdi) & 7) << 4;
       else key[a] = (ABL & 8) ? 0 : ((row >> 1) & 7) << 4;
     }
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT && HI) {
+      // plain bf16 operands: the hi halves only, one MFMA per product
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, R.f[2 * s]);
+        bf16x8 ah[WM];
+#pragma unroll
+        for (int a = 0; a < WM; ++a) ah[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
+#pragma unroll
+        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[a], acc[a][0], 0, 0, 0);
+      }
+    } else if constexpr (SPLIT) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 bh = __builtin_bit_cast(bf16x8, R.f[2 * s]);
@@ -305,12 +317,13 @@ __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvPar
   //   t == TP       the next stage's patch is requested right after the fetch of the stage's LAST tap
   //                 (TP = NT-1-AHEAD), so every weight wait of the stage is for a load issued before the patch
   //                 request (vmcnt retires in order) and the patch stays in flight until the end of the stage;
-  //   t >= AHEAD    wait for this tap's weights: younger operations = 4 * AHEAD weight loads (+ CNQ once the
+  //   t >= AHEAD    wait for this tap's weights: younger operations = WL * AHEAD weight loads (+ CNQ once the
   //                 patch has been requested, t >= TP); the first AHEAD taps of a stage landed at the previous
   //                 stage's end;
   //   t == NT-1     everything in flight (next taps' weights, the patch) lands before the transform / barrier.
   constexpr int AHEAD = RING - 1;
-  BFrag R0, R1, R2;
+  constexpr int WL = HI ? 2 : 4;  // weight loads per tap and wave
+  BFrag R0 = {}, R1 = {}, R2 = {};
   const int last = nstages - 1;
   // Cursor state lives in scalar registers; table fields are re-read only when a cursor enters a new stage, and the
   // tap descriptor of the next step is loaded at the end of the current one (no scalar-load latency inside a step).
@@ -322,7 +335,12 @@ __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvPar
   int64_t fstride = stages[0].tap_stride;
   const float* fw = (const float*)stages[0].wt;
   auto fetch = [&](BFrag& R) __attribute__((always_inline)) {
-    if constexpr (!(ABL & 2)) load_b_asm(R, fw, nb_off);
+    if constexpr (ABL & 2) {
+    } else if constexpr (HI) {
+      load_b_asm_hi(R, fw, nb_off);
+    } else {
+      load_b_asm(R, fw, nb_off);
+    }
     if (++ft >= fnt) {
       ft = 0;
       fs = fs < last ? fs + 1 : last;
@@ -345,14 +363,15 @@ __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvPar
     // in a merge, and a merge copy placed before the wait would read registers whose load is still in flight.  The
     // group becomes readable at the unconditional use_b() below.
     if (t >= AHEAD && !(ABL & 3)) {
-      if (t >= TP) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * AHEAD + CNQ) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * AHEAD) : "memory");
+      if (t >= TP) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD + CNQ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
     }
-    use_b(cur_r);
+    if constexpr (HI) use_b_hi(cur_r);
+    else use_b(cur_r);
     compute(cur_r, cur, tap);
     __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of the next tap below the MFMAs of this one (register pressure)
     if (t == NT - 1) {
-      if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * AHEAD + CNQ) : "memory");  // patch latency never exposed
+      if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD + CNQ) : "memory");  // patch latency never exposed
       else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (praw) transform_patch(stages[st < last ? st + 1 : last], nxt);
@@ -366,12 +385,20 @@ __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvPar
   };
   fetch(R0);
   if constexpr (RING == 3) fetch(R1);
-  else R1 = R0;
   issue_patch(stages[0], 0);
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-  use_b(R0);
-  use_b(R1);
-  R2 = R1;  // defined; overwritten by the first step's fetch
+  // Ring groups that no fetch has filled yet are defined by copies made AFTER the wait: a copy of a group whose
+  // load is still in flight reads stale registers, and since a copy makes the two groups the same value for the
+  // compiler, the stale one may end up feeding the first tap.
+  if constexpr (HI) use_b_hi(R0);
+  else use_b(R0);
+  if constexpr (RING == 3) {
+    if constexpr (HI) use_b_hi(R1);
+    else use_b(R1);
+  } else {
+    R1 = R0;
+  }
+  R2 = R1;
   if (praw) transform_patch(stages[0], 0);
   if constexpr (RING == 3) {
     while (true) {
@@ -409,16 +436,16 @@ static size_t conv_lds_bytes(int BN) {
   return main_bytes + CBM * 4;
 }
 
-template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3>
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false>
 static void launch_one(int grid, hipStream_t stream, const TapConvParams* dparams) {
   const size_t lds = conv_lds_bytes(BN);
   static bool attr_set = false;
   if (!attr_set) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING>),
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING>), dim3(grid), dim3(256), lds, stream, dparams);
+  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI>), dim3(grid), dim3(256), lds, stream, dparams);
 }
 
 #ifdef VFX_ABLATION_BUILD
@@ -441,12 +468,12 @@ static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvP
 }
 #endif
 
-template <bool ELU, bool SPLIT>
+template <bool ELU, bool SPLIT, bool HI = false>
 static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams* dparams) {
   switch (BN) {
-    case 128: launch_one<128, ELU, SPLIT>(grid, stream, dparams); break;
-    case 64: launch_one<64, ELU, SPLIT>(grid, stream, dparams); break;
-    default: launch_one<32, ELU, SPLIT, 0, 2>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
+    case 128: launch_one<128, ELU, SPLIT, 0, 3, HI>(grid, stream, dparams); break;
+    case 64: launch_one<64, ELU, SPLIT, 0, 3, HI>(grid, stream, dparams); break;
+    default: launch_one<32, ELU, SPLIT, 0, 2, HI>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
   }
 }
 
@@ -475,7 +502,10 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
   static const int abl = getenv("VFX_ABLATE") ? atoi(getenv("VFX_ABLATE")) : 0;
   if (abl && hp.split && !elu && BN == 128 && launch_ablated(abl, (int)grid, stream, dparams)) return;
 #endif
-  if (hp.split) {
+  if (hp.split && hp.hionly) {
+    if (elu) launch_bn<true, true, true>(BN, (int)grid, stream, dparams);
+    else launch_bn<false, true, true>(BN, (int)grid, stream, dparams);
+  } else if (hp.split) {
     if (elu) launch_bn<true, true>(BN, (int)grid, stream, dparams);
     else launch_bn<false, true>(BN, (int)grid, stream, dparams);
   } else {

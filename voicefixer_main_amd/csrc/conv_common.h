@@ -38,6 +38,16 @@ __device__ __forceinline__ void load_b_asm(BFrag& R, const float* wtap, unsigned
       : "v"(voff), "s"(wtap)
       : "memory");
 }
+// Plain-bf16 mode: only the hi fragments (f[0], f[2]) of the group.
+__device__ __forceinline__ void load_b_asm_hi(BFrag& R, const float* wtap, unsigned voff) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "global_load_dwordx4 %0, %2, %3\n\t"
+      "global_load_dwordx4 %1, %2, %3 offset:2048"
+      : "=&v"(R.f[0]), "=&v"(R.f[2])
+      : "v"(voff), "s"(wtap)
+      : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_b(BFrag& R) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R.f[0]), "+v"(R.f[1]), "+v"(R.f[2]), "+v"(R.f[3]) : "n"(N) : "memory");
@@ -48,6 +58,11 @@ __device__ __forceinline__ void wait_b(BFrag& R) {
 // asm volatile statements are not reordered); nothing that reads R may be scheduled above it.
 __device__ __forceinline__ void use_b(BFrag& R) {
   asm volatile("" : "+v"(R.f[0]), "+v"(R.f[1]), "+v"(R.f[2]), "+v"(R.f[3]) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void use_b_hi(BFrag& R) {
+  asm volatile("" : "+v"(R.f[0]), "+v"(R.f[2]) : : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 

@@ -22,6 +22,7 @@ void fill_seg(TapSeg& S, const float* x, int Cin, const float* scale, const floa
 
 void run_one(vfx_handle* h, TapConvParams& p, DeviceBlob& blob, hipStream_t s) {
   p.split = h->cfg.precision != 0;
+  p.hionly = h->cfg.precision == 2;
   finish_params(p);
   std::vector<ConvStage> st(p.nstages);
   build_stages(p, h->d_ones, h->d_zeros, st.data());
@@ -94,7 +95,7 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
     float* db1 = sc.blob.upload(b1, C);
     float* db2 = sc.blob.upload(b2, C);
     if (fused) {
-      VFX_CHECK(split && resblock_supported(C), "vfx_op_resblock: the fused kernel needs precision 1 and C = 64 or 128");
+      VFX_CHECK(split && resblock_supported(C), "vfx_op_resblock: the fused kernel needs precision 1 or 2 and C = 64 or 128");
       ResBlockParams rp{};
       rp.x = x;
       rp.y = y;
@@ -106,6 +107,7 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       rp.B = B;
       rp.T = T;
       rp.C = C;
+      rp.hionly = h->cfg.precision == 2;
       rp.dil = dil;
       plan_resblock(rp);
       ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));

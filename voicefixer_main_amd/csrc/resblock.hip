@@ -19,28 +19,33 @@
 //   3. conv2: A fragments straight from the LDS-resident h, no staging, no barriers;
 //   4. epilogue: + b2 + x (residual, L2-hot), fp32 rows of 16 bytes per lane.
 // Weights as in k_conv: fragment order, global -> VGPR ring, inline-asm loads with hand-counted vmcnt.
-// Arithmetic: split-bf16 only (precision 1); the fp32 mode keeps the two-launch plan.
+// Arithmetic: split-bf16 (precision 1) or, with ResBlockParams::hionly (precision 2), plain bf16 operands = the hi
+// halves only, one MFMA per product; the fp32 mode keeps the two-launch plan.
 #include "conv_common.h"
 #include "vfx_internal.h"
 
 namespace vfx {
 
-// n is a compile-time constant after unrolling; only these counts occur (NG = patch DMA instructions per wave)
-template <int NG>
+// n is a compile-time constant after unrolling; only these counts occur (NG = patch DMA instructions per wave,
+// WL = weight loads per tap and wave)
+template <int NG, int WL, bool HI>
 __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
   switch (n) {
-    case 4: wait_b<4>(R); break;
-    case 8: wait_b<8>(R); break;
-    case 4 + NG: wait_b<4 + NG>(R); break;
-    case 8 + NG: wait_b<8 + NG>(R); break;
-    default: wait_b<0>(R); break;
+    case WL: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL) : "memory"); break;
+    case 2 * WL: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * WL) : "memory"); break;
+    case WL + NG: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL + NG) : "memory"); break;
+    case 2 * WL + NG: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * WL + NG) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); break;
   }
+  if constexpr (HI) use_b_hi(R);
+  else use_b(R);
 }
 
 // NW waves per block: 4 (C = 64, two blocks per CU) or 8 (C = 128: the 112 KB of LDS allow one block per CU,
 // so the block itself brings the second wave per SIMD).
-template <int C, int NW>
+template <int C, int NW, bool HI>
 __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* __restrict__ pp) {
+  constexpr int WL = HI ? 2 : 4;  // weight loads per tap and wave (HI: plain bf16 operands, hi fragments only)
   constexpr int NTHR = NW * 64;
   constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
   constexpr int NG = kPatchMaxRows / RG;     // DMA instructions per wave and patch
@@ -164,6 +169,18 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
       base[a] = img_base + row[a] * stride;
       key[a] = swz_key(row[a]);
     }
+    if constexpr (HI) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, R.f[2 * s]);
+        bf16x8 ah[WM];
+#pragma unroll
+        for (int a = 0; a < WM; ++a) ah[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
+#pragma unroll
+        for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[a], acc[a], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const bf16x8 bh = __builtin_bit_cast(bf16x8, R.f[2 * s]);
@@ -186,26 +203,24 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
   };
 
   // ---- weight ring: global tap g (conv1: 0 .. NT1-1, conv2: NT1 .. 2*NT1-1) in register group g % RING ------
-  BFrag R0, R1, R2;
+  BFrag R0 = {}, R1 = {}, R2 = {};
   auto ring = [&](int g) __attribute__((always_inline)) -> BFrag& { return g % RING == 0 ? R0 : (g % RING == 1 ? R1 : R2); };
   auto fetch = [&](int g) __attribute__((always_inline)) {
     const float* w = g < NT1 ? p.w1 + g * ts : (g < 2 * NT1 ? p.w2 + (g - NT1) * ts : p.w2 + (NT1 - 1) * ts);
-    load_b_asm(ring(g), w, nb_off);
+    if constexpr (HI) load_b_asm_hi(ring(g), w, nb_off);
+    else load_b_asm(ring(g), w, nb_off);
   };
   auto drain = [&]() __attribute__((always_inline)) {
-    if constexpr (RING == 3)
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]),
-                     "+v"(R1.f[3]), "+v"(R2.f[0]), "+v"(R2.f[1]), "+v"(R2.f[2]), "+v"(R2.f[3])
-                   :
-                   : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(R0.f[0]), "+v"(R0.f[1]), "+v"(R0.f[2]), "+v"(R0.f[3]), "+v"(R1.f[0]), "+v"(R1.f[1]), "+v"(R1.f[2]),
-                     "+v"(R1.f[3])
-                   :
-                   : "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    if constexpr (HI) {
+      use_b_hi(R0);
+      use_b_hi(R1);
+      if constexpr (RING == 3) use_b_hi(R2);
+    } else {
+      use_b(R0);
+      use_b(R1);
+      if constexpr (RING == 3) use_b(R2);
+    }
   };
 
   // ---- phase 1: conv1 ------------------------------------------------------------------------------------
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
       const int g = 3 * c + k;
       fetch(g + AHEAD);
       if (k == 2 - AHEAD && has_dma) issue_patch(c + 1, ((c + 1) & 1) * CPATCH);
-      if (k >= AHEAD) wait_b_dyn<NG>(ring(g), 4 * AHEAD + (has_dma ? NG : 0));
+      if (k >= AHEAD) wait_b_dyn<NG, WL, HI>(ring(g), WL * AHEAD + (has_dma ? NG : 0));
       int rows[WM];
 #pragma unroll
       for (int a = 0; a < WM; ++a) rows[a] = arow1[a] + p.poff[k];
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
     for (int k = 0; k < 3; ++k) {
       const int g = NT1 + 3 * c + k;
       fetch(g + AHEAD);
-      if (g >= NT1 + AHEAD) wait_b_dyn<NG>(ring(g), 4 * AHEAD);  // the first AHEAD taps landed with the last drain
+      if (g >= NT1 + AHEAD) wait_b_dyn<NG, WL, HI>(ring(g), WL * AHEAD);  // the first AHEAD taps landed with the last drain
       int rows[WM];
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
@@ -331,16 +346,16 @@ static size_t resblock_lds_bytes(int C) {
   return std::max(h_end, epi_end);
 }
 
-template <int C, int NW>
+template <int C, int NW, bool HI>
 static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
   const size_t lds = resblock_lds_bytes(C);
   static bool attr_set = false;
   if (!attr_set) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_resblock<C, NW>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
+  hipLaunchKernelGGL((k_resblock<C, NW, HI>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
 }
 
 bool resblock_supported(int C) { return C == 64 || C == 128; }
@@ -380,8 +395,13 @@ void plan_resblock(ResBlockParams& p) {
 void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock: bad grid");
-  if (hp.C == 64) launch_rb<64, 4>((int)grid, stream, dparams);
-  else launch_rb<128, 8>((int)grid, stream, dparams);
+  if (hp.C == 64) {
+    if (hp.hionly) launch_rb<64, 4, true>((int)grid, stream, dparams);
+    else launch_rb<64, 4, false>((int)grid, stream, dparams);
+  } else {
+    if (hp.hionly) launch_rb<128, 8, true>((int)grid, stream, dparams);
+    else launch_rb<128, 8, false>((int)grid, stream, dparams);
+  }
   VFX_HIP(hipGetLastError());
 }
 

@@ -462,4 +462,26 @@ void launch_chunk_ola(const float* frames, const float* window, float scale, int
   VFX_HIP(hipGetLastError());
 }
 
+// Debug aid (VFX_DEBUG_NAN): number of non-finite floats in p[0..n).  Synchronises the stream.
+__global__ void k_count_nonfinite(const float* __restrict__ p, int64_t n, unsigned long long* __restrict__ count) {
+  unsigned long long c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const unsigned u = __float_as_uint(p[i]);
+    c += ((u >> 23) & 0xff) == 0xff;
+  }
+  if (c) atomicAdd(count, c);
+}
+
+int64_t count_nonfinite(const float* p, int64_t n, hipStream_t s) {
+  unsigned long long* d = nullptr;
+  VFX_HIP(hipMalloc(&d, sizeof(*d)));
+  VFX_HIP(hipMemsetAsync(d, 0, sizeof(*d), s));
+  hipLaunchKernelGGL(k_count_nonfinite, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, s, p, n, d);
+  unsigned long long hcount = 0;
+  VFX_HIP(hipMemcpyAsync(&hcount, d, sizeof(hcount), hipMemcpyDeviceToHost, s));
+  VFX_HIP(hipStreamSynchronize(s));
+  VFX_HIP(hipFree(d));
+  return (int64_t)hcount;
+}
+
 }  // namespace vfx

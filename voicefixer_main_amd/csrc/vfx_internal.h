@@ -101,6 +101,7 @@ struct TapConvParams {
   int out_img_stride, out_limit;
   int M;                 // output pixels of the launch (B * Hg * Wg, or B * out_limit when folded)
   int split;             // 1 = split-bf16 operand mode, 0 = exact fp32
+  int hionly;            // split layouts, but only the hi halves are multiplied: plain bf16 operands, 1 MFMA per product
   // tile / patch geometry (plan_conv): the M tile is a TH x TW block of the logical grid of one image,
   // every stage stages a PH x PW patch (P = PH * PW <= kPatchMaxRows pixels).
   int TH, TW, tw_shift;   // TH * TW <= 128, TW = 1 << tw_shift
@@ -146,6 +147,7 @@ struct ResBlockParams {
   int tiles_h, tiles_w;
   int PW, P;        // x patch: PH x PW pixels, P <= kPatchMaxRows
   int poff[3];      // patch row offset of conv1's taps
+  int hionly;       // plain bf16 operands (hi halves only), cf. TapConvParams::hionly
 };
 bool resblock_supported(int C);
 void plan_resblock(ResBlockParams& p);
@@ -198,6 +200,7 @@ void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int
                      hipStream_t s);
 void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, bool have_peak, float* out,
                       hipStream_t s);
+int64_t count_nonfinite(const float* p, int64_t n, hipStream_t s);  // debug aid, synchronises
 void launch_chunk_gather(const float* x, int B, int L, int win, int hop, int lead, int n_chunks, float* chunks,
                          hipStream_t s);
 void launch_chunk_ola(const float* frames, const float* window, float scale, int B, int n_chunks, int win, int hop,
@@ -262,9 +265,7 @@ struct Plan {
   double conv_flops = 0;
   int n_conv = 0;
   std::map<std::string, size_t> named;  // named arena offsets (bytes) of stage-level buffers
-  void run(const RunCtx& ctx) {
-    for (auto& f : ops) f(ctx);
-  }
+  void run(const RunCtx& ctx);  // api.cpp (debug hooks: VFX_POISON_ARENA=2, VFX_DEBUG_NAN)
 };
 
 // Arena-relative pointer encoding used inside TapConvParams until bind_plan(): offset + 1

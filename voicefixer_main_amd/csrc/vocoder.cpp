@@ -156,6 +156,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     Forms out;
     TapConvParams p{};
     set_conv1d_geometry(p, B, Tlen, K, dil, reflect);
+    p.hionly = cfg.precision == 2;
     p.Cout = cw.cout;
     p.bias = cw.bias;
     p.residual = residual ? rel_ptr(*residual) : nullptr;
@@ -216,6 +217,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
       // convolution of the input, and (B, Tlen * s, cout) viewed as (B, Tlen, s * cout) makes the phases plain cout
       // ranges -- the input patch is read from HBM once for all of them (it was read s times as s launches).
       TapConvParams p{};
+      p.hionly = cfg.precision == 2;
       p.B = B;
       p.Hi = p.Hg = p.Ho = 1;
       p.Wi = p.Wg = p.Wo = Tlen;
@@ -279,6 +281,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.T = Tlen;
         rp.C = up.cout;
         rp.dil = dil;
+        rp.hionly = cfg.precision == 2;
         pb.add_resblock(rp);
         free_forms(cur);
         cur = Forms{};
