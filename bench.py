@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-baseline-clips", type=int, default=2, help="clips in the CPU-oracle sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dist-selfcheck", action="store_true", help="N > 1: round-trip a tensor through dist.scatter_clips / gather_clips first")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16-vocoder (precision 2) timing at N = 1")
     ap.add_argument("--precision", type=int, default=1, help="0 = exact fp32 MFMA, 1 = split-bf16 (hi+lo, 3 bf16 MFMAs), 2 = ResUNet split-bf16 + vocoder plain bf16")
     return ap.parse_args()
@@ -170,8 +171,9 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    if world > 1:
-        # Exercise the shard scatter / gather over RCCL once, outside the timed region.
+    if world > 1 and args.dist_selfcheck:
+        # Exercise the shard scatter / gather over RCCL once, outside the timed region (opt-in: a point-to-point
+        # problem on one rank would otherwise hang the whole measurement; the logic itself is covered on gloo).
         try:
             from voicefixer_main_amd import dist as vdist
             vdist.selfcheck(device)
