@@ -10,9 +10,14 @@ Weak scaling: every rank restores its own shard, no collective on the data path.
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Arithmetic (--precision): 2 (default) = BASELINE.json's 16-bit operand mode for
+configs[1]: the ResUNet on split-bf16 operands (it carries the log-mel L1 <= 1e-3 bar), the vocoder on
+fp16 operands with one MFMA per product; 1 = split-bf16 everywhere (3 MFMAs per product), timed as well
+at N = 1 and reported beside `value` as `split_bf16_mode`; 0 = exact fp32 MFMA.
+
 Rank 0 prints ONE JSON line.  `roofline` is measured live: HIP events around every convolution
 launch on its own stream over K more steps of the same workload, reported for the kernel with the
-largest share of GPU time (k_conv<128, false, true>, the split-bf16 MFMA tap convolution); `cpu_baseline` times the CPU oracle (oracle/, a port of the reference
+largest share of GPU time; `cpu_baseline` times the CPU oracle (oracle/, a port of the reference
 algorithm) on a bounded sample of the same clips on this box's host cores.
 """
 import argparse
@@ -42,8 +47,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dist-selfcheck", action="store_true", help="N > 1: round-trip a tensor through dist.scatter_clips / gather_clips first")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16-vocoder (precision 2) timing at N = 1")
-    ap.add_argument("--precision", type=int, default=1, help="0 = exact fp32 MFMA, 1 = split-bf16 (hi+lo, 3 bf16 MFMAs), 2 = ResUNet split-bf16 + vocoder plain bf16")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra all-split-bf16 (precision 1) timing at N = 1")
+    ap.add_argument("--precision", type=int, default=2, help="0 = exact fp32 MFMA, 1 = split-bf16 (hi+lo, 3 bf16 MFMAs), 2 = ResUNet split-bf16 + vocoder fp16 (1 MFMA per product)")
     return ap.parse_args()
 
 
@@ -116,11 +121,11 @@ def measure_roofline(eng, wav, out, args):
                 traffic = traffic_detail["bytes_per_launch"] if traffic_detail else None
         except Exception:
             traffic, traffic_detail = None, None
-    plain = "bf16" in dom.split(">")[-1]     # a plain-bf16 launch of the precision-2 vocoder: one MFMA per product
+    plain = "f16" in dom.split(">")[-1]      # a 16-bit launch of the precision-2 vocoder: one MFMA per product
     per_product = 1 if (plain or not split) else 3
     return {
         "bound": "mfma",
-        "kernel": "%s (%s)" % (dom, "1 x v_mfma_f32_32x32x16_bf16 per product (plain bf16 operands), fp32 accumulate" if plain
+        "kernel": "%s (%s)" % (dom, "1 x v_mfma_f32_32x32x16_f16 per product (fp16 operands), fp32 accumulate" if plain
                                else "3 x v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
                                if split else "v_mfma_f32_32x32x2_f32"),
         "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
@@ -210,22 +215,25 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {0: "f32", 1: "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)",
-                      2: "bf16 (vocoder: plain bf16 operands; ResUNet: split-bf16 hi+lo; fp32 accumulate)"}[args.precision],
+                      2: "f16 (vocoder: fp16 operands, 1 MFMA per product; ResUNet: split-bf16 hi+lo; fp32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "gsr_voicefixer ResUNet+vocoder restore, batch=%dx%.0f s @44.1 kHz per GPU "
-                                   "(BASELINE.json configs[1]); plain bf16 operands miss the log-mel L1<=1e-3 parity bar by "
-                                   "19x, split-bf16 meets it with >10x margin" % (B, args.seconds),
+                                   "(BASELINE.json configs[1], 16-bit operands); ResUNet: split-bf16 (plain bf16 misses the "
+                                   "log-mel L1<=1e-3 bar 19x, split meets it with >10x margin: 4e-5); vocoder: fp16 operands, "
+                                   "waveform SI-SDR 58 dB and restored-waveform log-mel L1 2.4e-4 vs the fp32 oracle"
+                                   % (B, args.seconds),
+                       "precision_mode": args.precision,
                        "clips_per_gpu": B, "clip_seconds": args.seconds, "parallelism": "dp%d" % world,
                        "weights": "seeded random (no checkpoint available offline)"},
             "outputs_finite": finite, "negative_input_flag": flags,
         }
         if roofline:
             res["roofline"] = roofline
-        if world == 1 and args.precision == 1 and not args.no_alt:
-            # Same workload with the vocoder on plain bf16 operands (precision 2): reported beside `value`, never as it --
-            # its waveform meets an SI-SDR bar (40 dB vs the fp32 oracle) instead of the split mode's 88-94 dB.
+        if world == 1 and args.precision == 2 and not args.no_alt:
+            # Same workload with every GEMM-shaped layer on split-bf16 operands (precision 1: 3 MFMAs per product in the
+            # vocoder as well): the stricter arithmetic, reported beside `value`.
             try:
-                alt = Engine(device, config={"precision": 2})
+                alt = Engine(device, config={"precision": 1})
                 alt.load_state_dict(MODEL_UNET_MEL, synth.make_resunet_state_dict(0))
                 alt.load_state_dict(MODEL_VOCODER, synth.make_vocoder_state_dict(1))
                 for _ in range(max(args.warmup, 1)):
@@ -236,15 +244,15 @@ def main():
                     alt.restore_gsr(wav, out=out)
                 torch.cuda.synchronize(device)
                 dta = time.perf_counter() - t1
-                res["bf16_vocoder_mode"] = {
+                res["split_bf16_mode"] = {
                     "value": round(B * args.seconds * args.steps / dta, 2), "unit": "audio-s/s",
                     "ms_per_step": round(dta / args.steps * 1e3, 3), "outputs_finite": bool(torch.isfinite(out).all().item()),
-                    "dtype": "vocoder: plain bf16 operands (1 MFMA per product); ResUNet: split-bf16; fp32 accumulate",
-                    "parity": "ResUNet log-mel L1 4e-5 (unchanged); waveform SI-SDR 40 dB vs the fp32 oracle "
-                              "(tests/test_gpu_models.py::test_bf16_vocoder_mode; split mode: 88-94 dB)"}
+                    "dtype": "bf16x3 everywhere (split-bf16 operands hi+lo, 3 MFMAs per product, fp32 accumulate)",
+                    "parity": "waveform SI-SDR 88-94 dB vs the fp32 oracle; value's mode: 58 dB "
+                              "(profiles/r01_parity_fp16_vocoder.json)"}
                 del alt
             except Exception as e:
-                res["bf16_vocoder_mode"] = {"error": repr(e)}
+                res["split_bf16_mode"] = {"error": repr(e)}
         if world == 1 and args.cpu_baseline_clips > 0:
             try:
                 res["cpu_baseline"] = cpu_baseline(clips, args.cpu_baseline_clips, args.cpu_threads)

@@ -62,9 +62,11 @@ typedef struct vfx_config {
    *     lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-16 relative operand
    *     error; log-mel L1 vs the fp64 oracle 4e-5..8e-5, bar 1e-3);
    * 0 = exact fp32 (v_mfma_f32_32x32x2_f32), log-mel L1 5e-6..1e-5, ~1.8x slower;
-   * 2 = "bf16 vocoder": the ResUNets as 1 (they carry the log-mel bar), the TFGAN vocoder with
-   *     plain bf16 operands (the hi halves only: one MFMA per product, fp32 accumulation) --
-   *     BASELINE.json's bf16 for config 2; waveform parity is then an SI-SDR bar, see DESIGN.md. */
+   * 2 = "16-bit vocoder": the ResUNets as 1 (they carry the log-mel bar), the TFGAN vocoder on
+   *     fp16 operands (the hi halves of the same layouts hold fp16 values and are the only ones
+   *     loaded and multiplied: one v_mfma_f32_32x32x16_f16 per product, fp32 accumulation,
+   *     saturating conversion).  BASELINE.json's 16-bit operand mode for config 2; fp16 rather
+   *     than bf16 because bf16 operands hold the waveform to 40 dB SI-SDR only. */
   int precision;
 } vfx_config;
 

@@ -1,0 +1,20 @@
+"""Kernel names as bench.py prints them, from the demangled names rocprofv3 records.
+
+k_conv<BN, ELU, SPLIT, ABL, RING, HI>  ->  "k_conv<BN, ELU, SPLIT>" (+ " f16" for the 16-bit launches of precision 2)
+k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
+"""
+import re
+
+
+def short(n, width=40):
+    m = re.search(r"vfx::(k_\w+)(?:<([^>]*)>)?", n)
+    if not m:
+        return n[:width]
+    name, args = m.group(1), [a.strip() for a in (m.group(2) or "").split(",") if a.strip()]
+    if name == "k_conv" and len(args) >= 3:
+        hi = len(args) >= 6 and args[5] == "true"
+        return "k_conv<%s, %s, %s>%s" % (args[0], args[1], args[2], " f16" if hi else "")
+    if name == "k_resblock" and len(args) >= 2:
+        hi = len(args) >= 3 and args[2] == "true"
+        return "k_resblock<%s, %s>%s" % (args[0], args[1], " f16" if hi else "")
+    return name + ("<%s>" % ", ".join(args) if args else "")

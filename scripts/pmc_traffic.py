@@ -14,10 +14,7 @@ import sqlite3
 import sys
 
 
-def short(n):
-    m = re.search(r"vfx::(k_\w+)(<[^>]*>)?", n)
-    s = (m.group(1) + (m.group(2) or "")) if m else n[:40]
-    return re.sub(r", 0>$", ">", s)
+from kname import short  # noqa: E402  (scripts/ is on sys.path when run as a script)
 
 
 def load(db, counter):

@@ -9,9 +9,7 @@ import sqlite3
 import sys
 
 
-def short(n):
-    m = re.search(r"vfx::(k_\w+)(<[^>]*>)?", n)
-    return (m.group(1) + (m.group(2) or "")) if m else n[:40]
+from kname import short  # noqa: E402  (scripts/ is on sys.path when run as a script)
 
 
 def main():

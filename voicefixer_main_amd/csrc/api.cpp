@@ -122,7 +122,17 @@ static inline float bf16_to_f32(uint16_t b) {
 //   fp32:       4 fragments g (k8 groups), each [64 lanes][4 floats]:
 //               lane l holds W[cout = 32*nb + (l & 31)][k = 8*g + 4*(l >> 5) + 0..3].
 // A wave reads one fragment with ONE coalesced 16-byte-per-lane load (conv.hip).
-void rows_to_fragments(std::vector<float>& packed, int Cout, bool split) {
+static inline uint16_t f16_rne(float f) {
+  const float c = std::min(std::max(f, -65504.f), 65504.f);
+  const _Float16 h = (_Float16)c;
+  uint16_t u;
+  memcpy(&u, &h, sizeof(u));
+  return u;
+}
+
+// mode: 0 = fp32 fragments, 1 = split-bf16 (hi, lo), 2 = fp16 in the hi fragments (lo fragments zero: never loaded)
+void rows_to_fragments(std::vector<float>& packed, int Cout, int mode) {
+  const bool split = mode != 0;
   const size_t blk = (size_t)Cout * kKC;
   std::vector<float> tmp(blk);
   for (size_t o = 0; o + blk <= packed.size(); o += blk) {
@@ -138,8 +148,12 @@ void rows_to_fragments(std::vector<float>& packed, int Cout, bool split) {
             uint16_t q[8];
             for (int j = 0; j < 8; ++j) {
               const float v = row[16 * s2 + 8 * (l >> 5) + j];
-              const uint16_t hi = bf16_rne(v);
-              q[j] = lo ? bf16_rne(v - bf16_to_f32(hi)) : hi;
+              if (mode == 2) {
+                q[j] = lo ? (uint16_t)0 : f16_rne(v);
+              } else {
+                const uint16_t hi = bf16_rne(v);
+                q[j] = lo ? bf16_rne(v - bf16_to_f32(hi)) : hi;
+              }
             }
             memcpy(dst, q, sizeof(q));
           } else {
@@ -152,7 +166,7 @@ void rows_to_fragments(std::vector<float>& packed, int Cout, bool split) {
 }
 
 std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int KW, int c_lo, int C,
-                             const std::vector<std::pair<int, int>>& taps, bool split) {
+                             const std::vector<std::pair<int, int>>& taps, int mode) {
   const int nt = (int)taps.size();
   std::vector<float> out((size_t)C * nt * Cout);
   for (int ch = 0; ch < C / kKC; ++ch)
@@ -163,13 +177,13 @@ std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int
           out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
               w[(((size_t)n * CinTotal + c) * KH + taps[t].first) * KW + taps[t].second];
         }
-  rows_to_fragments(out, Cout, split);
+  rows_to_fragments(out, Cout, mode);
   return out;
 }
 
 // PyTorch ConvTranspose weight (Cin, Cout, KH, KW) -> [Cin/32][ntaps][Cout][32].
 std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,
-                                        const std::vector<std::pair<int, int>>& taps, bool split) {
+                                        const std::vector<std::pair<int, int>>& taps, int mode) {
   const int nt = (int)taps.size();
   std::vector<float> out((size_t)Cin * nt * Cout);
   for (int ch = 0; ch < Cin / kKC; ++ch)
@@ -180,7 +194,7 @@ std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int K
           out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
               w[(((size_t)c * Cout + n) * KH + taps[t].first) * KW + taps[t].second];
         }
-  rows_to_fragments(out, Cout, split);
+  rows_to_fragments(out, Cout, mode);
   return out;
 }
 
@@ -1105,12 +1119,12 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       for (int s2 = 0; s2 < d.nseg; ++s2) K += d.seg[s2].ntaps * d.seg[s2].C;
       char kname[64];
       if (d.nseg == 0) {  // fused ResStack layer
-        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.Cout == 64 ? 4 : 8, d.hionly ? " bf16" : "");
+        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.Cout == 64 ? 4 : 8, d.hionly ? " f16" : "");
       } else {
         bool elu = false;
         for (int s2 = 0; s2 < d.nseg; ++s2) elu = elu || d.seg[s2].act == ACT_ELU;
         snprintf(kname, sizeof(kname), "k_conv<%d; %s; %s>%s", conv_block_n(d), elu ? "true" : "false", d.split ? "true" : "false",
-                 d.hionly ? " bf16" : "");
+                 d.hionly ? " f16" : "");
       }
       fprintf(dump, "%zu,%s,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i, kname, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C,
               d.Wi, d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12);

@@ -38,8 +38,9 @@
 //     are inline asm with hand-counted s_waitcnt vmcnt(N): beside an LDS-DMA the compiler would
 //     wait vmcnt(0) for every ordinary load and drain the patch prefetch at each tap.
 //
-// Arithmetic (vfx_config.precision; 2 = as 1, except that the vocoder's launches set TapConvParams::hionly and
-// multiply the hi halves only: plain bf16 operands, one MFMA per product, fp32 accumulate)
+// Arithmetic (vfx_config.precision; 2 = as 1, except that the vocoder's launches set TapConvParams::hionly: the hi
+// halves of weights and activations hold fp16 values and are the only ones loaded and multiplied -- one
+// v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)
 //   1: split-bf16 -- every operand is hi + lo (two bf16), products hi*hi + hi*lo + lo*hi on
 //      v_mfma_f32_32x32x16_bf16, fp32 accumulate (~2^-16 relative operand error);
 //   0: exact fp32 on v_mfma_f32_32x32x2_f32.
@@ -189,7 +190,9 @@ __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvPar
     for (int q = 0; q < CNQ; ++q) {
       // the lane's bytes always land in slot cg: an activated source is fetched pre-swizzled (piece cg ^ key)
       const unsigned piece = praw ? 16u * cg : (unsigned)(cg ^ keyq[q]) << 4;
-      const unsigned o = (okmask & (1u << q)) ? voff[q] + piece : 0xfffffff0u;
+      // 16-bit mode: only the hi half (pieces 0..3) of an activated row is ever read -- the other lanes fetch nothing
+      const bool need = !HI || praw || piece < 64u;
+      const unsigned o = ((okmask & (1u << q)) && need) ? voff[q] + piece : 0xfffffff0u;
       VFX_LDS void* l = (VFX_LDS void*)(lds + dst + (32 * q + 8 * wave_u) * CROW);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
     }
@@ -221,7 +224,11 @@ __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvPar
           v[e] = (okmask & (1u << q)) ? u : 0.f;
         }
         char* rowp = row0 + 32 * q * CROW;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT && HI) {
+          // fp16 values of channels 4cg..4cg+3 in the hi half of the row: piece cg>>1, half cg&1 (lo pieces unused)
+          *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ keyq[q]) << 4) + 8 * (cg & 1)) =
+              make_uint2(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]));
+        } else if constexpr (SPLIT) {
           // v = hi + lo with hi = bf16(v), lo = bf16(v - hi); logical row layout [32 hi | 32 lo]
           const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
           const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
@@ -253,15 +260,15 @@ __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvPar
       else key[a] = (ABL & 8) ? 0 : ((row >> 1) & 7) << 4;
     }
     if constexpr (SPLIT && HI) {
-      // plain bf16 operands: the hi halves only, one MFMA per product
+      // 16-bit mode: fp16 operands in the hi halves, one MFMA per product
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, R.f[2 * s]);
-        bf16x8 ah[WM];
+        const f16x8 bh = __builtin_bit_cast(f16x8, R.f[2 * s]);
+        f16x8 ah[WM];
 #pragma unroll
-        for (int a = 0; a < WM; ++a) ah[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
+        for (int a = 0; a < WM; ++a) ah[a] = *reinterpret_cast<const f16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
 #pragma unroll
-        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[a], acc[a][0], 0, 0, 0);
+        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah[a], acc[a][0], 0, 0, 0);
       }
     } else if constexpr (SPLIT) {
 #pragma unroll

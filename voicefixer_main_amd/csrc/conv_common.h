@@ -10,6 +10,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// fp16 operand form of the 16-bit mode (TapConvParams::hionly): round to nearest, saturate instead of overflowing
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+  const f32x2 v = {__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f)};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
 
 constexpr int CBM = 128;                     // pixels per tile
 constexpr int CROW = 128;                    // bytes per patch row (32 channels)
@@ -38,7 +46,7 @@ __device__ __forceinline__ void load_b_asm(BFrag& R, const float* wtap, unsigned
       : "v"(voff), "s"(wtap)
       : "memory");
 }
-// Plain-bf16 mode: only the hi fragments (f[0], f[2]) of the group.
+// 16-bit (fp16) mode: only the hi fragments (f[0], f[2]) of the group.
 __device__ __forceinline__ void load_b_asm_hi(BFrag& R, const float* wtap, unsigned voff) {
   asm volatile(
       "s_nop 4\n\t"

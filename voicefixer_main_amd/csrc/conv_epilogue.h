@@ -11,7 +11,7 @@
 // waited loads would serialise on the previous store's acknowledgement.
 //
 // Two outputs, either optional: the raw fp32 tensor, and the ACTIVATED tensor for a consumer
-// convolution (TapConvParams::out_act): y -> affine -> LeakyReLU / ELU -> (split-bf16: hi | lo).  In
+// convolution (TapConvParams::out_act): y -> affine -> LeakyReLU / ELU -> (split-bf16: hi | lo; 16-bit mode: fp16 | 0).  In
 // split mode a lane pair (8 consecutive channels) swaps halves through DPP so that the even lane
 // stores the 8 hi values and the odd lane the 8 lo values, 16 bytes each.
 #pragma once
@@ -24,6 +24,7 @@ typedef float ce_f32x2 __attribute__((ext_vector_type(2)));
 typedef float ce_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned ce_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 ce_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ce_f16x2 __attribute__((ext_vector_type(2)));
 #define VFX_CE_GLOBAL __attribute__((address_space(1)))
 
 template <int BN, int WM, int WN, int WAVES_N, bool SPLIT>
@@ -82,6 +83,7 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
     const float slope = p.act_slope;
     const bool elu = p.act_elu != 0;
     const bool even = (tid & 1) == 0;
+    const bool f16 = p.hionly != 0;
     // split: the pair's 8 channels live in chunk ncol/32; hi block at +0, lo block at +16 floats, 8 channels = 4 floats
     const int aoff = SPLIT ? (ncol & ~31) + ((ncol & 31) >> 3) * 4 + (even ? 0 : 16) : ncol;
 #pragma unroll
@@ -94,12 +96,21 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
       }
       ce_f32x4 o;
       if constexpr (SPLIT) {
-        const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[0], u[1]}, ce_bf16x2));
-        const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[2], u[3]}, ce_bf16x2));
-        const ce_f32x2 r01 = {u[0] - __builtin_bit_cast(float, h01 << 16), u[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
-        const ce_f32x2 r23 = {u[2] - __builtin_bit_cast(float, h23 << 16), u[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
-        const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, ce_bf16x2));
-        const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, ce_bf16x2));
+        unsigned h01, h23, l01, l23;
+        if (f16) {  // 16-bit mode: fp16 (saturating) in the hi half, the lo half is never read
+          const ce_f32x2 c01 = {__builtin_fminf(__builtin_fmaxf(u[0], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[1], -65504.f), 65504.f)};
+          const ce_f32x2 c23 = {__builtin_fminf(__builtin_fmaxf(u[2], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[3], -65504.f), 65504.f)};
+          h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(c01, ce_f16x2));
+          h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(c23, ce_f16x2));
+          l01 = l23 = 0u;
+        } else {
+          h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[0], u[1]}, ce_bf16x2));
+          h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[2], u[3]}, ce_bf16x2));
+          const ce_f32x2 r01 = {u[0] - __builtin_bit_cast(float, h01 << 16), u[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+          const ce_f32x2 r23 = {u[2] - __builtin_bit_cast(float, h23 << 16), u[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+          l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, ce_bf16x2));
+          l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, ce_bf16x2));
+        }
         // quad_perm [1,0,3,2]: swap with the neighbouring lane (the other half of the 8-channel group)
         const unsigned s0 = even ? l01 : h01, s1 = even ? l23 : h23;
         const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, false);
@@ -109,7 +120,8 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
       } else {
         o = u;
       }
-      if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * Cout + aoff) = o;
+      // 16-bit mode: the lo half (odd lanes) is never read by a consumer -- not written either
+      if (opix[q] >= 0 && !(SPLIT && f16 && !even)) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * Cout + aoff) = o;
     }
   }
 }

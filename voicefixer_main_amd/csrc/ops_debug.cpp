@@ -55,7 +55,7 @@ extern "C" int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, i
       }
     S.ntaps = (int)taps.size();
     fill_seg(S, x, Cin, scale, shift, act, slope, sc.blob);
-    S.wt = sc.blob.upload(pack_conv(weight, Cout, Cin, kh, kw, 0, Cin, taps, h->cfg.precision != 0));
+    S.wt = sc.blob.upload(pack_conv(weight, Cout, Cin, kh, kw, 0, Cin, taps, h->cfg.precision == 2 ? 2 : (h->cfg.precision != 0)));
     p.nseg = 1;
     p.B = B;
     p.Hi = p.Hg = p.Ho = H;
@@ -90,8 +90,9 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
     Scratch sc;
     const bool split = h->cfg.precision != 0;
     std::vector<std::pair<int, int>> taps = {{0, 0}, {0, 1}, {0, 2}};
-    float* dw1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, split));
-    float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, split));
+    const int pmode = h->cfg.precision == 2 ? 2 : (int)split;
+    float* dw1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, pmode));
+    float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, pmode));
     float* db1 = sc.blob.upload(b1, C);
     float* db2 = sc.blob.upload(b2, C);
     if (fused) {
@@ -170,7 +171,7 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
             }
           S.ntaps = (int)taps.size();
           fill_seg(S, x, Cin, scale, shift, act, slope, sc.blob);
-          S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 3, 3, taps, h->cfg.precision != 0));
+          S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 3, 3, taps, h->cfg.precision == 2 ? 2 : (h->cfg.precision != 0)));
           p.nseg = 1;
           p.B = B;
           p.Hi = H;
@@ -204,7 +205,7 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
         }
         S.ntaps = (int)taps.size();
         fill_seg(S, x, Cin, scale, shift, act, slope, sc.blob);
-        S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 1, kw, taps, h->cfg.precision != 0));
+        S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 1, kw, taps, h->cfg.precision == 2 ? 2 : (h->cfg.precision != 0)));
         p.nseg = 1;
         p.B = B;
         p.Hi = p.Hg = p.Ho = 1;

@@ -19,8 +19,8 @@
 //   3. conv2: A fragments straight from the LDS-resident h, no staging, no barriers;
 //   4. epilogue: + b2 + x (residual, L2-hot), fp32 rows of 16 bytes per lane.
 // Weights as in k_conv: fragment order, global -> VGPR ring, inline-asm loads with hand-counted vmcnt.
-// Arithmetic: split-bf16 (precision 1) or, with ResBlockParams::hionly (precision 2), plain bf16 operands = the hi
-// halves only, one MFMA per product; the fp32 mode keeps the two-launch plan.
+// Arithmetic: split-bf16 (precision 1) or, with ResBlockParams::hionly (precision 2), fp16 operands in the hi halves
+// only, one MFMA per product; the fp32 mode keeps the two-launch plan.
 #include "conv_common.h"
 #include "vfx_internal.h"
 
@@ -45,7 +45,7 @@ __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
 // so the block itself brings the second wave per SIMD).
 template <int C, int NW, bool HI>
 __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* __restrict__ pp) {
-  constexpr int WL = HI ? 2 : 4;  // weight loads per tap and wave (HI: plain bf16 operands, hi fragments only)
+  constexpr int WL = HI ? 2 : 4;  // weight loads per tap and wave (HI: fp16 operands, hi fragments only)
   constexpr int NTHR = NW * 64;
   constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
   constexpr int NG = kPatchMaxRows / RG;     // DMA instructions per wave and patch
@@ -147,6 +147,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[q][e], raw[q][e] * slope);  // LeakyReLU(0) = 0: DMA zero fill stays zero
+        if constexpr (HI) {  // fp16 in the hi half only
+          *reinterpret_cast<uint2*>(row0 + RG * q * CROW + (((cg >> 1) ^ key_l) << 4) + 8 * (cg & 1)) =
+              make_uint2(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]));
+          continue;
+        }
         const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
         const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
         const f32x2 r01 = {v[0] - __builtin_bit_cast(float, h01 << 16), v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
@@ -172,12 +177,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
     if constexpr (HI) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, R.f[2 * s]);
-        bf16x8 ah[WM];
+        const f16x8 bh = __builtin_bit_cast(f16x8, R.f[2 * s]);
+        f16x8 ah[WM];
 #pragma unroll
-        for (int a = 0; a < WM; ++a) ah[a] = *reinterpret_cast<const bf16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
+        for (int a = 0; a < WM; ++a) ah[a] = *reinterpret_cast<const f16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
 #pragma unroll
-        for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[a], acc[a], 0, 0, 0);
+        for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah[a], acc[a], 0, 0, 0);
       }
       return;
     }
@@ -269,6 +274,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
         const float t = acc[a][4 * j + e] + b1v[j][e];
         u[e] = hval[a] ? fmaxf(t, t * slope) : 0.f;
         acc[a][4 * j + e] = 0.f;
+      }
+      if constexpr (HI) {
+        *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1]), pack_f16x2(u[2], u[3]));
+        continue;
       }
       const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u[0], u[1]}, bf16x2));
       const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u[2], u[3]}, bf16x2));

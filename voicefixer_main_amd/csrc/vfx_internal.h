@@ -101,7 +101,8 @@ struct TapConvParams {
   int out_img_stride, out_limit;
   int M;                 // output pixels of the launch (B * Hg * Wg, or B * out_limit when folded)
   int split;             // 1 = split-bf16 operand mode, 0 = exact fp32
-  int hionly;            // split layouts, but only the hi halves are multiplied: plain bf16 operands, 1 MFMA per product
+  int hionly;            // 16-bit operands: split layouts, but the hi halves hold fp16 values and are the only ones
+                         // loaded and multiplied (1 MFMA per product); weights packed with mode 2
   // tile / patch geometry (plan_conv): the M tile is a TH x TW block of the logical grid of one image,
   // every stage stages a PH x PW patch (P = PH * PW <= kPatchMaxRows pixels).
   int TH, TW, tw_shift;   // TH * TW <= 128, TW = 1 << tw_shift
@@ -147,7 +148,7 @@ struct ResBlockParams {
   int tiles_h, tiles_w;
   int PW, P;        // x patch: PH x PW pixels, P <= kPatchMaxRows
   int poff[3];      // patch row offset of conv1's taps
-  int hionly;       // plain bf16 operands (hi halves only), cf. TapConvParams::hionly
+  int hionly;       // fp16 operands in the hi halves only, cf. TapConvParams::hionly
 };
 bool resblock_supported(int C);
 void plan_resblock(ResBlockParams& p);
@@ -335,10 +336,10 @@ struct VocoderWeights {
 // Conv weights -> MFMA fragment order [C/32][ntaps][Cout/32][1024 floats] (conv.hip); `split`
 // selects the split-bf16 (hi | lo) or the fp32 fragment layout.
 std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int KW, int c_lo, int C,
-                             const std::vector<std::pair<int, int>>& taps, bool split);
+                             const std::vector<std::pair<int, int>>& taps, int mode);
 std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,
-                                        const std::vector<std::pair<int, int>>& taps, bool split);
-void rows_to_fragments(std::vector<float>& packed, int Cout, bool split);  // [..][Cout][32] rows -> fragment order
+                                        const std::vector<std::pair<int, int>>& taps, int mode);
+void rows_to_fragments(std::vector<float>& packed, int Cout, int mode);  // [..][Cout][32] rows -> fragment order
 
 }  // namespace vfx
 

@@ -38,7 +38,7 @@ VocConvW load_conv1d(vfx_handle* h, const std::string& p, int cin, int cout, int
   VocConvW c;
   c.cin = cin;
   c.cout = cout;
-  c.w = h->blob.upload(pack_conv(w.data.data(), cout, cin, 1, K, 0, cin, taps, h->cfg.precision != 0));
+  c.w = h->blob.upload(pack_conv(w.data.data(), cout, cin, 1, K, 0, cin, taps, h->cfg.precision == 2 ? 2 : (h->cfg.precision != 0)));
   const HostTensor& b = staged(h, p + ".bias");
   VFX_CHECK((int)b.data.size() == cout, "vocoder tensor '%s.bias' has an unexpected shape", p.c_str());
   c.bias = h->blob.upload(b.data);
@@ -81,7 +81,7 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
     for (int r = 0; r < s; ++r) {
       std::vector<std::pair<int, int>> taps;
       for (auto& ek : phase_taps(s, pad, r)) taps.push_back({0, ek.second});
-      up.w_phase.push_back(h->blob.upload(pack_conv_transposed(w.data.data(), c, c / 2, 1, 2 * s, taps, h->cfg.precision != 0)));
+      up.w_phase.push_back(h->blob.upload(pack_conv_transposed(w.data.data(), c, c / 2, 1, 2 * s, taps, h->cfg.precision == 2 ? 2 : (h->cfg.precision != 0))));
     }
     {  // the phased launch sees the output as (B, T, stride * cout): one bias copy per phase
       const std::vector<float>& b = staged(h, std::string(name) + ".bias").data;
