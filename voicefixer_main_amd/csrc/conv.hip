@@ -55,12 +55,14 @@ namespace vfx {
 // bit 0 no patch request, 1 no weight loads, 2 no barrier, 3 constant fragment addresses, 4 no fragment reads,
 // 5 no epilogue, 6 the end-of-stage wait leaves the patch in flight.
 template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false>
-__global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
+__global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
   constexpr int WAVES_N = BN / 32;
   constexpr int WM = BN / 32;  // 32-row blocks per wave (= 4 / WAVES_M)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kMainBytes = (2 * CPATCH > CBM * (BN + 4) * 4) ? 2 * CPATCH : CBM * (BN + 4) * 4;
+  constexpr int EPI_HALVES = (BN == 128 && HI) ? 2 : 1;  // 16-bit BN = 128 tile: half-width epilogue staging -> three blocks per CU
+  constexpr int kEpiBytes = CBM * (BN / EPI_HALVES + 4) * 4;
+  constexpr int kMainBytes = (2 * CPATCH > kEpiBytes) ? 2 * CPATCH : kEpiBytes;
   char* const lds = reinterpret_cast<char*>(smem);
   int* otab = reinterpret_cast<int*>(lds + kMainBytes);  // [128] output pixel index or -1
 
@@ -434,18 +436,19 @@ __global__ __launch_bounds__(256, BN <= 64 ? 3 : 2) void k_conv(const TapConvPar
       for (int r = 0; r < 16; ++r) keep += acc[a][0][r];
     if (keep == 12345.678f) p.out_act[tid] = keep;  // keeps the accumulators live
   } else {
-    conv_epilogue<BN, WM, 1, WAVES_N, SPLIT>(p, smem, otab, acc, n0);
+    conv_epilogue<BN, WM, 1, WAVES_N, SPLIT, EPI_HALVES>(p, smem, otab, acc, n0);
   }
 }
 
-static size_t conv_lds_bytes(int BN) {
-  const size_t main_bytes = std::max<size_t>((size_t)2 * CPATCH, (size_t)CBM * (BN + 4) * 4);
+static size_t conv_lds_bytes(int BN, bool hi) {
+  const int halves = (BN == 128 && hi) ? 2 : 1;  // as EPI_HALVES in the kernel
+  const size_t main_bytes = std::max<size_t>((size_t)2 * CPATCH, (size_t)CBM * (BN / halves + 4) * 4);
   return main_bytes + CBM * 4;
 }
 
 template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false>
 static void launch_one(int grid, hipStream_t stream, const TapConvParams* dparams) {
-  const size_t lds = conv_lds_bytes(BN);
+  const size_t lds = conv_lds_bytes(BN, HI);
   static bool attr_set = false;
   if (!attr_set) {
     VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI>),

@@ -27,101 +27,111 @@ typedef __bf16 ce_bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 ce_f16x2 __attribute__((ext_vector_type(2)));
 #define VFX_CE_GLOBAL __attribute__((address_space(1)))
 
-template <int BN, int WM, int WN, int WAVES_N, bool SPLIT>
+template <int BN, int WM, int WN, int WAVES_N, bool SPLIT, int HALVES = 1>
 __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* smem, const int* otab,
                                               ce_f32x16 (&acc)[WM][WN], int n0) {
-  constexpr int LDO = BN + 4;  // staged row length (floats), keeps 16-byte alignment
-  constexpr int V = BN / 4;    // float4 per output row
+  // HALVES = 2: the cout range goes through the staging buffer in two passes (half the LDS: the 16-bit BN = 128 tile
+  // then fits three blocks per CU)
+  constexpr int BH = BN / HALVES;  // couts per pass
+  constexpr int WPH = WAVES_N / HALVES;  // N-waves per pass
+  static_assert(WAVES_N % HALVES == 0 && WPH >= 1, "bad epilogue split");
+  constexpr int LDO = BH + 4;  // staged row length (floats), keeps 16-byte alignment
+  constexpr int V = BH / 4;    // float4 per output row
   constexpr int RPP = 256 / V; // rows per pass
   constexpr int NPASS = 128 / RPP;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
-  __syncthreads();  // every wave is done reading the last stage
-  // C/D layout of the 32x32 MFMA: col = lane & 31 (-> pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> cout).
-#pragma unroll
-  for (int a = 0; a < WM; ++a)
-#pragma unroll
-    for (int b = 0; b < WN; ++b)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = (wm * WM + a) * 32 + l31;
-        *reinterpret_cast<ce_f32x4*>(smem + row * LDO + (wn * WN + b) * 32 + 8 * j + 4 * lh) =
-            ce_f32x4{acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]};
-      }
-  __syncthreads();
   const int c4 = tid % V, r0 = tid / V;
   const int Cout = p.Cout;
-  const int ncol = n0 + 4 * c4;
-  ce_f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) bv = *(const VFX_CE_GLOBAL ce_f32x4*)(p.bias + ncol);
-  int opix[NPASS];
-  ce_f32x4 val[NPASS];
+  const bool even = (tid & 1) == 0;
+  const bool f16 = p.hionly != 0;
 #pragma unroll
-  for (int q = 0; q < NPASS; ++q) {
-    opix[q] = otab[r0 + q * RPP];
-    val[q] = *reinterpret_cast<const ce_f32x4*>(smem + (r0 + q * RPP) * LDO + 4 * c4) + bv;
-  }
-  if (p.residual) {
-    ce_f32x4 res[NPASS];
+  for (int hh = 0; hh < HALVES; ++hh) {
+    __syncthreads();  // every wave is done reading the last stage / the previous pass has been consumed
+    // C/D layout of the 32x32 MFMA: col = lane & 31 (-> pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> cout).
+    if (HALVES == 1 || wn / WPH == hh) {
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q)
-      res[q] = *(const VFX_CE_GLOBAL ce_f32x4*)(p.residual + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * Cout + ncol);
+      for (int a = 0; a < WM; ++a)
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q) val[q] += res[q];
-  }
-  if (p.out) {
+        for (int b = 0; b < WN; ++b)
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q)
-      if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out + (int64_t)opix[q] * Cout + ncol) = val[q];
-  }
-  if (p.out_act) {
-    ce_f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
-    if (p.act_scale) asc = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_scale + ncol);
-    if (p.act_shift) ash = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_shift + ncol);
-    const float slope = p.act_slope;
-    const bool elu = p.act_elu != 0;
-    const bool even = (tid & 1) == 0;
-    const bool f16 = p.hionly != 0;
-    // split: the pair's 8 channels live in chunk ncol/32; hi block at +0, lo block at +16 floats, 8 channels = 4 floats
-    const int aoff = SPLIT ? (ncol & ~31) + ((ncol & 31) >> 3) * 4 + (even ? 0 : 16) : ncol;
+          for (int j = 0; j < 4; ++j) {
+            const int row = (wm * WM + a) * 32 + l31;
+            *reinterpret_cast<ce_f32x4*>(smem + row * LDO + ((wn % WPH) * WN + b) * 32 + 8 * j + 4 * lh) =
+                ce_f32x4{acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]};
+          }
+    }
+    __syncthreads();
+    const int ncol = n0 + hh * BH + 4 * c4;
+    ce_f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *(const VFX_CE_GLOBAL ce_f32x4*)(p.bias + ncol);
+    int opix[NPASS];
+    ce_f32x4 val[NPASS];
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
-      ce_f32x4 u;
+      opix[q] = otab[r0 + q * RPP];
+      val[q] = *reinterpret_cast<const ce_f32x4*>(smem + (r0 + q * RPP) * LDO + 4 * c4) + bv;
+    }
+    if (p.residual) {
+      ce_f32x4 res[NPASS];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t = val[q][e] * asc[e] + ash[e];
-        u[e] = elu ? (t > 0.f ? t : expm1f(t)) : fmaxf(t, t * slope);
-      }
-      ce_f32x4 o;
-      if constexpr (SPLIT) {
-        unsigned h01, h23, l01, l23;
-        if (f16) {  // 16-bit mode: fp16 (saturating) in the hi half, the lo half is never read
-          const ce_f32x2 c01 = {__builtin_fminf(__builtin_fmaxf(u[0], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[1], -65504.f), 65504.f)};
-          const ce_f32x2 c23 = {__builtin_fminf(__builtin_fmaxf(u[2], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[3], -65504.f), 65504.f)};
-          h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(c01, ce_f16x2));
-          h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(c23, ce_f16x2));
-          l01 = l23 = 0u;
-        } else {
-          h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[0], u[1]}, ce_bf16x2));
-          h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[2], u[3]}, ce_bf16x2));
-          const ce_f32x2 r01 = {u[0] - __builtin_bit_cast(float, h01 << 16), u[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
-          const ce_f32x2 r23 = {u[2] - __builtin_bit_cast(float, h23 << 16), u[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
-          l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, ce_bf16x2));
-          l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, ce_bf16x2));
+      for (int q = 0; q < NPASS; ++q)
+        res[q] = *(const VFX_CE_GLOBAL ce_f32x4*)(p.residual + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * Cout + ncol);
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) val[q] += res[q];
+    }
+    if (p.out) {
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q)
+        if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out + (int64_t)opix[q] * Cout + ncol) = val[q];
+    }
+    if (p.out_act) {
+      ce_f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+      if (p.act_scale) asc = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_scale + ncol);
+      if (p.act_shift) ash = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_shift + ncol);
+      const float slope = p.act_slope;
+      const bool elu = p.act_elu != 0;
+      // split: the pair's 8 channels live in chunk ncol/32; hi block at +0, lo block at +16 floats, 8 channels = 4 floats
+      const int aoff = SPLIT ? (ncol & ~31) + ((ncol & 31) >> 3) * 4 + (even ? 0 : 16) : ncol;
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+        ce_f32x4 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = val[q][e] * asc[e] + ash[e];
+          u[e] = elu ? (t > 0.f ? t : expm1f(t)) : fmaxf(t, t * slope);
         }
-        // quad_perm [1,0,3,2]: swap with the neighbouring lane (the other half of the 8-channel group)
-        const unsigned s0 = even ? l01 : h01, s1 = even ? l23 : h23;
-        const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, false);
-        const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, false);
-        const ce_u32x4 w = even ? ce_u32x4{h01, h23, g0, g1} : ce_u32x4{g0, g1, l01, l23};
-        o = __builtin_bit_cast(ce_f32x4, w);
-      } else {
-        o = u;
+        ce_f32x4 o;
+        if constexpr (SPLIT) {
+          unsigned h01, h23, l01, l23;
+          if (f16) {  // 16-bit mode: fp16 (saturating) in the hi half, the lo half is never read
+            const ce_f32x2 c01 = {__builtin_fminf(__builtin_fmaxf(u[0], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[1], -65504.f), 65504.f)};
+            const ce_f32x2 c23 = {__builtin_fminf(__builtin_fmaxf(u[2], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[3], -65504.f), 65504.f)};
+            h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(c01, ce_f16x2));
+            h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(c23, ce_f16x2));
+            l01 = l23 = 0u;
+          } else {
+            h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[0], u[1]}, ce_bf16x2));
+            h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[2], u[3]}, ce_bf16x2));
+            const ce_f32x2 r01 = {u[0] - __builtin_bit_cast(float, h01 << 16), u[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+            const ce_f32x2 r23 = {u[2] - __builtin_bit_cast(float, h23 << 16), u[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+            l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, ce_bf16x2));
+            l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, ce_bf16x2));
+          }
+          // quad_perm [1,0,3,2]: swap with the neighbouring lane (the other half of the 8-channel group)
+          const unsigned s0 = even ? l01 : h01, s1 = even ? l23 : h23;
+          const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, false);
+          const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, false);
+          const ce_u32x4 w = even ? ce_u32x4{h01, h23, g0, g1} : ce_u32x4{g0, g1, l01, l23};
+          o = __builtin_bit_cast(ce_f32x4, w);
+        } else {
+          o = u;
+        }
+        // 16-bit mode: the lo half (odd lanes) is never read by a consumer -- not written either
+        if (opix[q] >= 0 && !(SPLIT && f16 && !even)) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * Cout + aoff) = o;
       }
-      // 16-bit mode: the lo half (odd lanes) is never read by a consumer -- not written either
-      if (opix[q] >= 0 && !(SPLIT && f16 && !even)) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * Cout + aoff) = o;
     }
   }
 }
