@@ -15,7 +15,8 @@
 //   1. conv1: per 32-channel chunk the raw x patch arrives by LDS-DMA (zero fill by the buffer bound),
 //      is turned into MFMA operand form in place (LeakyReLU, hi/lo split, swizzled slots) and read by the
 //      three taps -- same machinery as k_conv (conv.hip), statically scheduled here;
-//   2. h = LeakyReLU(acc + b1), zero outside the sequence, written to LDS in operand form;
+//   2. h = LeakyReLU(acc + b1), zero outside the sequence, written to LDS in operand form -- over the patch buffers,
+//      which are dead by then (one more barrier; 48 / 68 KB of LDS instead of 80 / 112);
 //   3. conv2: A fragments straight from the LDS-resident h, no staging, no barriers;
 //   4. epilogue: + b2 + x (residual, L2-hot), fp32 rows of 16 bytes per lane.
 // Weights as in k_conv: fragment order, global -> VGPR ring, inline-asm loads with hand-counted vmcnt.
@@ -41,10 +42,11 @@ __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
   else use_b(R);
 }
 
-// NW waves per block: 4 (C = 64, two blocks per CU) or 8 (C = 128: the 112 KB of LDS allow one block per CU,
-// so the block itself brings the second wave per SIMD).
+// NW waves per block: 4 (C = 64) or 8 (C = 128: h needs all 128 couts of conv1 in one block).
+// Waves per SIMD the register budget is cut for: C = 64 (4-wave blocks, 48 KB of LDS): three blocks per CU;
+// C = 128 (8-wave blocks, 68 KB): two blocks per CU in the 16-bit mode (116 VGPRs), one in split mode (140).
 template <int C, int NW, bool HI>
-__global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* __restrict__ pp) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resblock(const ResBlockParams* __restrict__ pp) {
   constexpr int WL = HI ? 2 : 4;  // weight loads per tap and wave (HI: fp16 operands, hi fragments only)
   constexpr int NTHR = NW * 64;
   constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
   constexpr int WAVES_N = NCH, WAVES_M = NW / WAVES_N, WM = 4 / WAVES_M;  // (C, NW) = (64, 4): 2, 2, 2;  (128, 8): 4, 2, 2
   constexpr int RING = WM >= 4 ? 2 : 3, AHEAD = RING - 1;
   constexpr int HROW = C * 4;         // bytes per h row
-  constexpr int H_OFF = 2 * CPATCH;   // h buffer behind the two patch buffers
+  constexpr int H_OFF = 0;            // h overlays the patch buffers (dead once conv1 is done): less LDS, more blocks per CU
   constexpr int NT1 = 3 * NCH;        // taps of conv1 (chunk-major); conv2 has as many
   constexpr int LDO = C + 4;          // staged output row (floats)
   constexpr int OTAB_OFF = CBM * LDO * 4;
@@ -258,6 +260,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
     if (has_dma) transform_patch(((c + 1) & 1) * CPATCH);
   }
 
+  __syncthreads();  // every wave is done reading the patch buffers that h overlays
+
   // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------
   // Lane (l31, lh) of M block a holds h pixel m = (wm*WM + a)*32 + l31 and, in registers 4j .. 4j+3, channels
   // wn*32 + 8j + 4lh .. +3: their 4 hi bf16 are half `lh` of piece j of the pixel's chunk row, the 4 lo of piece j+4.
@@ -350,9 +354,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock(const ResBlockParams* _
 }
 
 static size_t resblock_lds_bytes(int C) {
-  const size_t h_end = (size_t)2 * CPATCH + (size_t)CBM * C * 4;
+  const size_t h_end = (size_t)CBM * C * 4;                       // h overlays the patch buffers
   const size_t epi_end = (size_t)CBM * (C + 4) * 4 + CBM * 4;
-  return std::max(h_end, epi_end);
+  return std::max(std::max(h_end, (size_t)2 * CPATCH), epi_end);
 }
 
 template <int C, int NW, bool HI>
