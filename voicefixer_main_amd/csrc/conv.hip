@@ -6,8 +6,9 @@
 //     input) and the residual add (epilogue);
 //   * the channel concat in DecoderBlockRes4B (modules.py:212-220) as two K segments;
 //   * the stride-2 ConvTranspose2d of the decoders as 4 output-parity launches;
-//   * the TFGAN vocoder's Conv1d k3 (dilated) / k7 (reflect padded) and its ConvTranspose1d
-//     upsamplers as `scale` output-phase launches (H = 1).
+//   * the TFGAN vocoder's Conv1d k3 (dilated; folded into rows of d samples when d is wide) / k7 (reflect
+//     padded) and its ConvTranspose1d upsamplers as ONE phased launch each (output phases = cout ranges with
+//     their own stage tables, TapConvParams::nphase).
 //
 // GEMM view:  out[m, n] = sum_seg sum_tap sum_c  P(src_seg[pix(m) + off(tap), c]) * W_seg[tap][c][n]
 //   M = output pixels, N = Cout, K = sum ntaps*C.  Activations are channels-last, 4 bytes per
@@ -37,6 +38,12 @@
 //     global -> VGPR -> MFMA through a ring of three (two for BN = 32) register groups.  The loads
 //     are inline asm with hand-counted s_waitcnt vmcnt(N): beside an LDS-DMA the compiler would
 //     wait vmcnt(0) for every ordinary load and drain the patch prefetch at each tap.
+//     Until its wait a ring register holds stale data and the compiler does not know.  Rules kept here and
+//     checked on the assembly by scripts/asm_inflight_check.py (tests/test_host.py):
+//       - conditional waits carry no register operands (a merge copy could be placed before the wait);
+//       - a group becomes readable at ONE unconditional use_b() between its wait and its first MFMA;
+//       - a group is never copied (R1 = R0) while its load is in flight: the copy reads stale registers and
+//         makes both groups the same value for the compiler, which may then feed the stale one to the MFMAs.
 //
 // Arithmetic (vfx_config.precision; 2 = as 1, except that the vocoder's launches set TapConvParams::hionly: the hi
 // halves of weights and activations hold fp16 values and are the only ones loaded and multiplied -- one
@@ -44,7 +51,8 @@
 //   1: split-bf16 -- every operand is hi + lo (two bf16), products hi*hi + hi*lo + lo*hi on
 //      v_mfma_f32_32x32x16_bf16, fp32 accumulate (~2^-16 relative operand error);
 //   0: exact fp32 on v_mfma_f32_32x32x2_f32.
-//   Plain bf16 / fp16 operands miss the "log-mel L1 <= 1e-3" bar of the reference.
+//   Plain 16-bit operands miss the "log-mel L1 <= 1e-3" bar in the ResUNets (bf16 19x, fp16 3.3x); the vocoder
+//   holds 58 dB SI-SDR on fp16 and only 40 dB on bf16.
 #include "conv_common.h"
 #include "conv_epilogue.h"
 #include "vfx_internal.h"
