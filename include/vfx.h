@@ -155,6 +155,17 @@ int vfx_chunk_gather(vfx_handle* h, const float* x, int B, int L, int win, int h
 int vfx_chunk_ola(vfx_handle* h, const float* frames, const float* window, float scale, int B,
                   int n_chunks, int win, int hop, int lead, int L, float* y, void* stream);
 
+/*
+ * Spectral metrics of the evaluation handlers, per clip, without leaving the device
+ * (evaluation_proc/metrics.py:83-95 `lsd`, `sispec`; evaluation_proc/utils.py:81-101 `energy_unify`,
+ * `pow_p_norm`; used at eval_gsr_voicefixer.py:56-64):  est, target (B, T, F) -> out (B, 2),
+ *   out[b][0] = LSD(est, target)    (linear-scale inputs, "mel-lsd"),
+ *   out[b][1] = SiSpec(est, target) in dB (log-scale inputs for "mel-sispec", linear for "mel-non-log-sispec").
+ * The reference returns the batch mean of these.
+ */
+int vfx_spectral_metrics(vfx_handle* h, const float* est, const float* target, int B, int T, int F,
+                         float* out, void* stream);
+
 /* Read-and-clear the sticky device flags (synchronises `stream`). */
 int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out);
 

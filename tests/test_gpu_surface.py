@@ -211,3 +211,24 @@ def test_chunked_restore_batched_equals_sequential(voicefixer):
     a = LambdaOverlapAdd(nnet, 1, W, window="hanning", engine=voicefixer.engine)(wav)
     b = LambdaOverlapAdd(nnet, 1, W, window="hanning", engine=voicefixer.engine, max_batch=1)(wav)
     assert a.shape == wav.shape and torch.equal(a, b)
+
+
+def test_spectral_metrics_kernel_vs_oracle_and_reference(engine):
+    """vfx_spectral_metrics (per-clip LSD and SiSpec in one pass, double-precision inner products) against the float64
+    oracle and the outputs of the reference's own metric code (tests/golden/metrics.npz)."""
+    from oracle import metrics as om
+    g = np.load(os.path.join(G, "metrics.npz"))
+    for tag in "abc":
+        e, t = g[tag + "_est"], g[tag + "_tgt"]
+        got = engine.spectral_metrics(torch.from_numpy(e), torch.from_numpy(t)).cpu().numpy()
+        assert got.shape == (e.shape[0], 2)
+        assert np.abs(got[:, 0] - om.lsd(e, t)[:, 0]).max() < 2e-6 * max(1.0, got[:, 0].max())
+        assert np.abs(got[:, 1] - om.sispec_per_clip(e, t)).max() < 1e-3
+        assert np.abs(got[:, 0] - g[tag + "_lsd"][:, 0, 0, 0]).max() < 2e-6 * max(1.0, got[:, 0].max())
+        assert abs(got[:, 1].mean() - float(g[tag + "_sispec_lin"])) < 2e-3
+        le, lt = np.log10(np.clip(e, 1e-8, None)), np.log10(np.clip(t, 1e-8, None))
+        got = engine.spectral_metrics(torch.from_numpy(le), torch.from_numpy(lt)).cpu().numpy()
+        assert abs(got[:, 1].mean() - float(g[tag + "_sispec_log"])) < 2e-3
+    x = torch.rand(2, 1, 9, 128) + 0.1
+    m = engine.spectral_metrics(x, x).cpu().numpy()
+    assert m[:, 0].max() < 1e-6 and m[:, 1].min() > 100.0      # identical pair: LSD 0, SiSpec at the eps ceiling

@@ -41,6 +41,7 @@ SIGNATURES = {
     "vfx_stft_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vfx_mel_project": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "vfx_istft": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vfx_spectral_metrics": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vfx_chunk_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vfx_chunk_ola": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_void_p, c_void_p]),

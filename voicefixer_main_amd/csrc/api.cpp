@@ -815,6 +815,18 @@ int vfx_mel_project(vfx_handle* h, const float* sp, int64_t rows, float* mel, vo
   VFX_API_END
 }
 
+int vfx_spectral_metrics(vfx_handle* h, const float* est, const float* target, int B, int T, int F, float* out, void* stream) {
+  VFX_API_BEGIN
+  VFX_CHECK(h && est && target && out && B > 0 && T > 0 && F > 0 && B <= 65535, "bad argument");
+  // per-frame partial sums live in the arena (no plan is running concurrently: single stream, single thread)
+  Plan tmp;
+  tmp.arena_bytes = (size_t)B * T * 4 * sizeof(double);
+  if (tmp.arena_bytes > h->arena_bytes) h->plans.clear();  // plans hold absolute pointers into the old arena
+  bind_plan(h, tmp);
+  launch_spectral_metrics(est, target, B, T, F, reinterpret_cast<double*>(h->arena), out, static_cast<hipStream_t>(stream));
+  VFX_API_END
+}
+
 int vfx_chunk_gather(vfx_handle* h, const float* x, int B, int L, int win, int hop, int lead, int n_chunks,
                      float* chunks, void* stream) {
   VFX_API_BEGIN

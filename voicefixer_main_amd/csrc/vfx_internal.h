@@ -201,6 +201,7 @@ void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int
                      hipStream_t s);
 void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, bool have_peak, float* out,
                       hipStream_t s);
+void launch_spectral_metrics(const float* est, const float* tgt, int B, int T, int F, double* ws, float* out, hipStream_t s);
 int64_t count_nonfinite(const float* p, int64_t n, hipStream_t s);  // debug aid, synchronises
 void launch_chunk_gather(const float* x, int B, int L, int win, int hop, int lead, int n_chunks, float* chunks,
                          hipStream_t s);

@@ -145,6 +145,18 @@ class Engine:
         _lib.check(self.lib.vfx_istft(self.h, _ptr(re), _ptr(im), B, T, length, _ptr(wav), self._stream()), "vfx_istft")
         return wav
 
+    def spectral_metrics(self, est, target):
+        """Per-clip (LSD, SiSpec dB) of est vs target, (B, T, F) or (B, 1, T, F) each -> (B, 2)."""
+        est, target = _dev_f32(est, self.device), _dev_f32(target, self.device)
+        assert est.shape == target.shape
+        F = est.shape[-1]
+        T = est.shape[-2]
+        B = est.numel() // (T * F)
+        out = torch.empty((B, 2), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.vfx_spectral_metrics(self.h, _ptr(est), _ptr(target), B, T, F, _ptr(out), self._stream()),
+                   "vfx_spectral_metrics")
+        return out
+
     def chunk_gather(self, x, win, hop, lead, n_chunks):
         """F.unfold with zero padding: x (B, L) -> (B, n_chunks, win), chunk k = x[k*hop - lead : ... + win]."""
         x = _dev_f32(x, self.device)

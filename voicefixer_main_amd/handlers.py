@@ -17,7 +17,8 @@ import torch
 from . import models
 from .models import from_log, tensor2numpy, to_log
 
-EPS = 1e-9
+EPS = 1e-12        # evaluation_proc/metrics.py:16
+EPS_UNIFY = 1e-8   # evaluation_proc/utils.py:8 (energy_unify)
 SEG_SECONDS = 60
 
 
@@ -82,8 +83,16 @@ def amp_to_original_f(mel_sp_est, mel_sp_target, cutoff=0.2):
 
 
 # ----------------------------------------------------------------------------------------
-# on-device spectral metrics (evaluation_proc/metrics.py:83-95, utils.py:81-101)
+# spectral metrics (evaluation_proc/metrics.py:83-95, utils.py:81-101).  `lsd` / `sispec` are the formulas in torch
+# (any device); the handlers call `device_metrics`, which runs them in libvfx (vfx_spectral_metrics: one pass over the
+# data, no (B,T,F) temporaries) and returns Python floats with one device-to-host copy per pair.
 # ----------------------------------------------------------------------------------------
+def device_metrics(engine, est, target):
+    """-> (lsd, sispec_db) of a (B, 1, T, F) pair as the reference reports them (batch means)."""
+    m = engine.spectral_metrics(est, target).mean(dim=0).tolist()
+    return m[0], m[1]
+
+
 def _pow_p_norm(x):
     return torch.pow(torch.norm(x.reshape(x.shape[0], -1), p=2, dim=1), 2).reshape((-1,) + (1,) * (x.dim() - 1))
 
@@ -95,7 +104,7 @@ def lsd(est, target):
 
 def sispec(est, target):
     scale = torch.sum(est * target, dim=tuple(range(2, est.dim())), keepdim=True)
-    tgt = scale * target / (_pow_p_norm(target) + EPS)
+    tgt = scale * target / (_pow_p_norm(target) + EPS_UNIFY)
     noise = est - tgt
     loss = 10 * torch.log10(_pow_p_norm(tgt) / (_pow_p_norm(noise) + EPS) + EPS)
     return torch.sum(loss) / loss.size()[0]
@@ -152,11 +161,13 @@ def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=Fals
             if target is not None:
                 _, target_mel, _ = _pre(model, target[break_point - seg_length:break_point], device)
                 n = min(target_mel.shape[2], denoised_mel.shape[2])
-                metrics = {
-                    "mel-lsd": float(lsd(denoised_mel[:, :, :n], target_mel[:, :, :n])),
-                    "mel-sispec": float(sispec(out_model["mel"][:, :, :n], to_log(target_mel[:, :, :n]))),
-                    "mel-non-log-sispec": float(sispec(from_log(out_model["mel"][:, :, :n]), target_mel[:, :, :n])),
-                }
+                est_lin, tgt_lin = denoised_mel[:, :, :n].contiguous(), target_mel[:, :, :n].contiguous()
+                m_lsd, m_lin = device_metrics(model.engine, est_lin, tgt_lin)
+                _, m_log = device_metrics(model.engine, out_model["mel"][:, :, :n].contiguous(), to_log(tgt_lin))
+                # non-log SiSpec is defined on from_log(model output) (eval_gsr_voicefixer.py:62), i.e. before unify_energy
+                if meta.get("unify_energy", False):
+                    _, m_lin = device_metrics(model.engine, from_log(out_model["mel"][:, :, :n]).contiguous(), tgt_lin)
+                metrics = {"mel-lsd": m_lsd, "mel-sispec": m_log, "mel-non-log-sispec": m_lin}
             out = model.vocoder(denoised_mel)
             if torch.max(torch.abs(out)) > 1.0:
                 out = out / torch.max(torch.abs(out))
@@ -191,11 +202,10 @@ def handler_ssr_unet(input, output, target, ckpt, device, needrefresh=False, met
                 mel_out = model.mel(sp_o.permute(0, 1, 3, 2)).permute(0, 1, 3, 2)
                 _, target_mel, _ = _pre(model, target[break_point - seg_length:break_point], device)
                 n = min(target_mel.shape[2], mel_out.shape[2])
-                metrics = {
-                    "mel-lsd": float(lsd(mel_out[:, :, :n], target_mel[:, :, :n])),
-                    "mel-sispec": float(sispec(to_log(mel_out[:, :, :n]), to_log(target_mel[:, :, :n]))),
-                    "mel-non-log-sispec": float(sispec(mel_out[:, :, :n], target_mel[:, :, :n])),
-                }
+                est_lin, tgt_lin = mel_out[:, :, :n].contiguous(), target_mel[:, :, :n].contiguous()
+                m_lsd, m_lin = device_metrics(model.engine, est_lin, tgt_lin)
+                _, m_log = device_metrics(model.engine, to_log(est_lin), to_log(tgt_lin))
+                metrics = {"mel-lsd": m_lsd, "mel-sispec": m_log, "mel-non-log-sispec": m_lin}
             if torch.max(torch.abs(out)) > 1.0:
                 out = out / torch.max(torch.abs(out))
                 print("Warning: Exceed energy limit,", input)
