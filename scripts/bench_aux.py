@@ -6,6 +6,7 @@
   configs[4]  gsr_unet streaming, 1-s chunks, hipGraph-captured step  (spectrogram ResUNet, B = 1, T = 101)
 
 One JSON object per line.  Synthetic clips, seeded random weights; inputs resident in HBM.
+    python scripts/bench_aux.py [ssr] [shard] [stream] [--precision=1|2]
 """
 import json
 import os
@@ -33,8 +34,10 @@ def timed(fn, steps, warmup):
 
 
 def main():
-    which = sys.argv[1:] or ["ssr", "shard", "stream"]
-    eng = Engine("cuda:0", config={"precision": 1})
+    args = [a for a in sys.argv[1:] if not a.startswith("--precision=")]
+    precision = int(([a.split("=")[1] for a in sys.argv[1:] if a.startswith("--precision=")] or ["2"])[0])
+    which = args or ["ssr", "shard", "stream"]
+    eng = Engine("cuda:0", config={"precision": precision})   # 2 = bench.py's mode (only the vocoder differs from 1)
     eng.load_state_dict(MODEL_UNET_MEL, synth.make_resunet_state_dict(0))
     eng.load_state_dict(MODEL_VOCODER, synth.make_vocoder_state_dict(1))
     eng.load_state_dict(MODEL_UNET_SPEC, synth.make_resunet_state_dict(2))

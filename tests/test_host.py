@@ -147,3 +147,28 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "asm_inflight_check.py"), out],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The newest committed bench line (profiles/r01_bench_v*.json) carries every key of the bench.py contract,
+    including the `roofline` and `cpu_baseline` objects, with self-consistent numbers."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_bench_v*.json")), key=lambda f: int(re.findall(r"_v(\d+)", f)[0]))
+    d = json.load(open(files[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")
+    # value = audio seconds of all ranks / wall seconds
+    audio = d["n_gpus"] * d["config"]["clips_per_gpu"] * d["config"]["clip_seconds"]
+    assert abs(d["value"] - audio / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
