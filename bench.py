@@ -1,29 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- VoiceFixer 44.1 kHz restoration throughput on MI355X.
 
-Metric (BASELINE.json): restored-audio seconds per wall-second (RTF^-1).  A "step" is one
-pass of the whole `gsr_voicefixer` hot path (STFT -> mel -> ResUNet -> from_log -> TFGAN
-vocoder -> peak normalise -> trim; eval_gsr_voicefixer.py:47-74) over one batch of
-16 x 10 s synthetic clips per GPU (BASELINE.json configs[1]), inputs resident in HBM.
-Weak scaling: every rank restores its own shard, no collective on the data path.
+Metric (BASELINE.json): restored-audio seconds per wall-second (RTF^-1).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--workload NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Arithmetic (--precision): 2 (default) = BASELINE.json's 16-bit operand mode for
-configs[1]: the ResUNet on split-bf16 operands (it carries the log-mel L1 <= 1e-3 bar), the vocoder on
-fp16 operands with one MFMA per product; 1 = split-bf16 everywhere (3 MFMAs per product), timed as well
-at N = 1 and reported beside `value` as `split_bf16_mode`; 0 = exact fp32 MFMA.
+`--gpus N` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N ranks
+(one process per GPU, 127.0.0.1 rendezvous); a WORLD_SIZE that disagrees with --gpus is an error.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live: HIP events around every convolution
-launch on its own stream over K more steps of the same workload, reported for the kernel with the
-largest share of GPU time; `cpu_baseline` times the CPU oracle (oracle/, a port of the reference
-algorithm) on a bounded sample of the same clips on this box's host cores.
+Workloads (BASELINE.json `configs`; a "step" is one pass of the hot path over one batch of synthetic clips that are
+resident in HBM when the clock starts):
+
+  gsr16x10     (default, configs[1]) gsr_voicefixer restore -- STFT -> mel -> ResUNet -> from_log -> TFGAN vocoder ->
+               peak normalise -> trim (eval_gsr_voicefixer.py:47-74) -- of 16 x 10 s clips per GPU.  Weak scaling:
+               every rank restores its own shard, no collective on the data path.
+  sharded1024  (configs[3]) the same restore over 128 clips per GPU (1024 on 8 GPUs) that live on rank 0: scatter over
+               RCCL point-to-point -> per-rank restore (sub-batched) -> gather, ALL inside the timed region.
+  ssr_sr64     (configs[2]) ssr_unet super-resolution forward, 64 x 3 s per GPU: |STFT| -> spectrogram ResUNet (second
+               STFT for the phase, trunk, recombination, ISTFT) (eval_ssr_unet.py:77-114, unet_v2.py:86-148).
+  stream1s     (configs[4]) gsr_unet streaming: one 1-s chunk per step, the step captured in a hipGraph.
+
+Arithmetic (--precision): 2 (default) = BASELINE.json's 16-bit operand mode for configs[1]: the
+ResUNet on split-bf16 operands (it carries the log-mel L1 <= 1e-3 bar), the vocoder on fp16 operands with one MFMA per
+product; 1 = split-bf16 everywhere (3 MFMAs per product), timed as well at N = 1 and reported beside `value` as
+`split_bf16_mode`; 0 = exact fp32 MFMA.
+
+Rank 0 prints ONE JSON line.  Measured in the same run: `parity` (HIP outputs of the benched batch vs the CPU oracle on
+the clips the oracle was run on; the run FAILS when the log-mel L1 exceeds the 1e-3 bar), `roofline` (HIP events around
+every convolution launch on its own stream over K more steps; `traffic` from two rocprofv3 PMC passes of a child run of
+the same workload), `roofline_hbm` (the HBM-bound front-end / back-end kernels), `cpu_baseline` (the CPU oracle, a port
+of the reference algorithm, on a bounded sample of the same clips on this box's host cores).
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,7 +49,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (spec; 2495 measured)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (spec; 2495 measured)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MAC_MEL_PER_FRAME = 92853664
+MAC_SPEC_PER_FRAME = 780251136
+LOGMEL_L1_BAR = 1e-3            # BASELINE.json north_star: mel L1 <= 1e-3 vs the reference forward
+WORKLOADS = ("gsr16x10", "sharded1024", "ssr_sr64", "stream1s")
 
 
 def parse():
@@ -41,58 +62,120 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=16, help="clips per GPU per step")
-    ap.add_argument("--seconds", type=float, default=10.0, help="clip length")
-    ap.add_argument("--cpu-baseline-clips", type=int, default=2, help="clips in the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--workload", choices=WORKLOADS, default="gsr16x10")
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (default: the workload's)")
+    ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default: the workload's)")
+    ap.add_argument("--cpu-baseline-clips", type=int, default=-1, help="clips in the CPU-oracle sample (0 = skip; default per workload)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison (needs the cpu baseline sample)")
+    ap.add_argument("--traffic", choices=("live", "off"), default="live",
+                    help="live: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of a child run of the same workload")
     ap.add_argument("--dist-selfcheck", action="store_true", help="N > 1: round-trip a tensor through dist.scatter_clips / gather_clips first")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra all-split-bf16 (precision 1) timing at N = 1")
     ap.add_argument("--precision", type=int, default=2, help="0 = exact fp32 MFMA, 1 = split-bf16 (hi+lo, 3 bf16 MFMAs), 2 = ResUNet split-bf16 + vocoder fp16 (1 MFMA per product)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    d_clips, d_sec, d_cpu = {"gsr16x10": (16, 10.0, 2), "sharded1024": (128, 10.0, 0), "ssr_sr64": (64, 3.0, 1),
+                             "stream1s": (1, 1.0, 1)}[args.workload]
+    args.clips = args.clips or d_clips
+    args.seconds = args.seconds or d_sec
+    if args.cpu_baseline_clips < 0:
+        args.cpu_baseline_clips = d_cpu
+    return args
 
 
-def cpu_baseline(clips, n_clips, threads):
-    """Time the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only).
+def maybe_spawn(args):
+    """--gpus N without a launcher: become `torch.distributed.run` with N ranks of this very command."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s -- launch N ranks with --gpus N (or drop WORLD_SIZE and let "
+                     "bench.py spawn them)" % (args.gpus, ws))
+        return
+    if args.gpus <= 1:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
-    The oracle's torch-CPU convolutions stop scaling (and then collapse) beyond a few dozen
-    threads at these sizes (measured on the 2 x EPYC 9575F host: 1-s clip 0.23 / 0.18 / 0.25 /
-    0.66 s at 8 / 16 / 32 / 64 threads, minutes at 256), so the baseline uses a fixed, stated
-    thread count instead of every hardware thread.
-    """
+
+# ---------------------------------------------------------------------------------------------------------
+# parity (HIP vs the CPU oracle, measured in the run)
+# ---------------------------------------------------------------------------------------------------------
+def sisdr_db(est, ref):
+    est, ref = np.asarray(est, np.float64), np.asarray(ref, np.float64)
+    err = est - ref
+    return float(10.0 * np.log10((ref ** 2).sum() / ((err ** 2).sum() + 1e-30)))
+
+
+def parity_gsr(out, logmel, ref):
+    """out (n, L), logmel (n, T, 128) of the HIP path vs the oracle's dict for the same n clips."""
+    lm, rl = logmel.cpu().numpy().astype(np.float64), ref["logmel"][:, 0].astype(np.float64)
+    w, rw = out.cpu().numpy(), ref["wav"][:, 0]
+    return {"logmel_l1": float(np.abs(lm - rl).mean()), "logmel_max": float(np.abs(lm - rl).max()),
+            "wav_sisdr_db": round(sisdr_db(w, rw), 2), "wav_max_err": float(np.abs(w - rw).max()), "clips": int(w.shape[0]),
+            "frames": int(lm.shape[1]), "vs": "oracle.pipeline.restore_gsr (fp32 CPU port of the reference forward)",
+            "bar": {"logmel_l1": LOGMEL_L1_BAR}}
+
+
+def parity_wav(out, ref_wav):
+    w = out.cpu().numpy()
+    return {"wav_sisdr_db": round(sisdr_db(w, ref_wav), 2), "wav_max_err": float(np.abs(w - ref_wav).max()),
+            "clips": int(w.shape[0]), "vs": "oracle.pipeline.restore_ssr (fp32 CPU port of unet_v2.py:86-148)"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle timed on this box's host cores; its outputs double as the parity reference)
+# ---------------------------------------------------------------------------------------------------------
+def cpu_baseline(kind, clips, n_clips, threads):
+    """The oracle's torch-CPU convolutions stop scaling (and then collapse) beyond a few dozen threads at these sizes
+    (2 x EPYC 9575F host: 1-s clip 0.23 / 0.18 / 0.25 / 0.66 s at 8 / 16 / 32 / 64 threads, minutes at 256), so the
+    baseline uses a fixed, stated thread count instead of every hardware thread."""
     from oracle import pipeline
     from voicefixer_main_amd import synth
     wav = clips[:n_clips]
-    unet_sd = synth.make_resunet_state_dict(0)
-    voc_sd = synth.make_vocoder_state_dict(1)
     threads = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(threads)
-    pipeline.restore_gsr(unet_sd, voc_sd, wav[:1, :, :44100])          # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    pipeline.restore_gsr(unet_sd, voc_sd, wav)
+    if kind == "gsr":
+        unet_sd, voc_sd = synth.make_resunet_state_dict(0), synth.make_vocoder_state_dict(1)
+        pipeline.restore_gsr(unet_sd, voc_sd, wav[:1, :, :44100])          # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        ref = pipeline.restore_gsr(unet_sd, voc_sd, wav)
+        name = "oracle.pipeline.restore_gsr"
+    else:
+        unet_sd = synth.make_resunet_state_dict(2)
+        pipeline.restore_ssr(unet_sd, wav[:1, :, :22050])
+        t0 = time.perf_counter()
+        ref = pipeline.restore_ssr(unet_sd, wav)
+        name = "oracle.pipeline.restore_ssr"
     dt = time.perf_counter() - t0
     seconds = wav.shape[0] * wav.shape[-1] / 44100.0
     return {"value": round(seconds / dt, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
             "seconds": round(dt, 2), "host_cpus": os.cpu_count(),
-            "sample": "oracle.pipeline.restore_gsr (torch-CPU fp32 + numpy port of the reference algorithm) on "
-                      "%d clip(s) x %.0f s of the same synthetic clips as one batch, same seeded weights, after a "
-                      "1-s warm-up" % (wav.shape[0], wav.shape[-1] / 44100.0)}
+            "sample": "%s (torch-CPU fp32 + numpy port of the reference algorithm) on %d clip(s) x %.0f s of the same "
+                      "synthetic clips as one batch, same seeded weights, after a warm-up call"
+                      % (name, wav.shape[0], wav.shape[-1] / 44100.0)}, ref
 
 
-def measure_roofline(eng, wav, out, args):
-    """HIP events around every convolution launch (on the launch stream) over K more steps of the same
-    workload; per-kernel totals come from the per-launch table libvfx writes (VFX_PROFILE_DUMP).  The
-    roofline object describes the kernel with the largest share of GPU time; `traffic` is the HBM byte count
-    of that kernel per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes, + WRITE_SIZE), null if no such measurement exists for this workload."""
+# ---------------------------------------------------------------------------------------------------------
+# roofline: MFMA-bound convolution kernels (HIP events inside libvfx), HBM-bound DSP kernels, PMC traffic
+# ---------------------------------------------------------------------------------------------------------
+def measure_conv_roofline(eng, step, args, traffic):
+    """HIP events around every convolution launch (on the launch stream) over K more steps of the same workload;
+    per-kernel totals come from the per-launch table libvfx writes (VFX_PROFILE_DUMP).  The roofline object describes
+    the kernel with the largest share of GPU time; achieved = algorithmic flops of its launches / their durations."""
     import csv
-    import tempfile
     keep = os.environ.get("VFX_PROFILE_DUMP")   # a caller-provided path keeps the per-launch table
     dump = keep or tempfile.NamedTemporaryFile(prefix="vfx_convs_", suffix=".csv", delete=False).name
     os.environ["VFX_PROFILE_DUMP"] = dump
+    steps = max(args.steps, 1)
     eng.profile_begin()
-    for _ in range(args.steps):
-        eng.restore_gsr(wav, out=out)
+    for _ in range(steps):
+        step()
     n, ms, fl = eng.profile_end()
     rows = list(csv.DictReader(open(dump)))
     if not keep:
@@ -105,24 +188,14 @@ def measure_roofline(eng, wav, out, args):
         t[0] += 1
         t[1] += float(r["ms"])
         t[2] += float(r["tflops"]) * float(r["ms"]) * 1e9   # flops of the launch
-    steps = max(args.steps, 1)
     dom = max(per, key=lambda k: per[k][1])
     cnt, kms, kfl = per[dom]
     tflops = kfl / (kms * 1e-3) / 1e12
     split = args.precision >= 1
     peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-    traffic, traffic_detail = None, None
-    tpath = os.path.join(HERE, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            t = json.load(open(tpath))
-            if t.get("workload") == "%dx%.0fs" % (wav.shape[0], args.seconds) and t.get("precision") == args.precision:
-                traffic_detail = t.get("kernels", {}).get(dom)
-                traffic = traffic_detail["bytes_per_launch"] if traffic_detail else None
-        except Exception:
-            traffic, traffic_detail = None, None
     plain = "f16" in dom.split(">")[-1]      # a 16-bit launch of the precision-2 vocoder: one MFMA per product
     per_product = 1 if (plain or not split) else 3
+    tr = (traffic or {}).get("kernels", {}).get(dom)
     return {
         "bound": "mfma",
         "kernel": "%s (%s)" % (dom, "1 x v_mfma_f32_32x32x16_f16 per product (fp16 operands), fp32 accumulate" if plain
@@ -132,110 +205,307 @@ def measure_roofline(eng, wav, out, args):
         # achieved counts ALGORITHMIC flops (2*M*N*K once); in split-bf16 mode the kernel issues 3 bf16 MFMAs per
         # product, so `frac` is bounded by 1/3 and mfma_issue_frac is the share of the MFMA pipe actually used
         "mfma_issue_frac": round(tflops * per_product / peak, 4),
-        "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC passes of profiles/r01_traffic.json)",
-        "traffic_detail": traffic_detail,
+        "traffic": tr["bytes_per_launch"] if tr else None,
+        "traffic_unit": "HBM bytes per launch: 2 * FETCH_SIZE + WRITE_SIZE of this run's rocprofv3 PMC passes",
+        "traffic_detail": tr,
+        "traffic_error": (traffic or {}).get("error"),
         "launches_per_step": cnt // steps,
         "avg_launch_us": round(kms * 1e3 / max(cnt, 1), 2),
         "kernel_ms_per_step": round(kms / steps, 3),
         "algorithmic_gflop_per_step": round(kfl / steps / 1e9, 1),
         "share_of_conv_time": round(kms / max(ms, 1e-9), 4),
         "all_conv_kernels": {k: {"launches_per_step": v[0] // steps, "ms_per_step": round(v[1] / steps, 3),
-                                 "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(per.items())},
+                                 "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                                 "hbm_bytes_per_launch": ((traffic or {}).get("kernels", {}).get(k) or {}).get("bytes_per_launch")}
+                             for k, v in sorted(per.items())},
         "all_conv_ms_per_step": round(ms / steps, 3),
         "all_conv_algorithmic_gflop_per_step": round(fl / steps / 1e9, 1),
     }
 
 
+def measure_hbm_stages(eng, B, L, reps=20):
+    """The HBM-bound kernels of the path against the 8 TB/s roofline, algorithmic bytes per frame from SURVEY.md
+    section 8(d): mel-only front-end 441*4 + 128*4 = 2276 B, phase-emitting front-end 441*4 + 3*1025*4 = 14064 B,
+    ISTFT 2*1025*4 + 441*4 = 9964 B.  Timed with events on the stream the kernels run on (torch's current stream is
+    the one handed to libvfx)."""
+    dev = eng.device
+    wav = torch.randn((B, L), device=dev) * 0.1
+    T = L // 441 + 1
+    frames = B * T
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / reps * 1e-3
+
+    mel = torch.empty((B, T, 128), device=dev)
+    sp, co, si = (torch.empty((B, T, 1025), device=dev) for _ in range(3))
+    out = torch.empty((B, L), device=dev)
+    import ctypes
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    lib, h, st = eng.lib, eng.h, eng._stream()
+    t_mel = timed(lambda: lib.vfx_stft_mel(h, P(wav), B, L, P(mel), None, None, None, 0, st))
+    t_ph = timed(lambda: lib.vfx_stft_mel(h, P(wav), B, L, None, P(sp), P(co), P(si), 0, st))
+    re, im = sp * co, sp * si
+    t_is = timed(lambda: lib.vfx_istft(h, P(re), P(im), B, T, L, P(out), st))
+
+    def line(bytes_per_frame, t):
+        gbs = bytes_per_frame * frames / t / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "bytes_per_frame": bytes_per_frame, "frames": frames, "us": round(t * 1e6, 1)}
+    return {"stft_mel": line(2276, t_mel), "stft_phase": line(14064, t_ph), "istft": line(9964, t_is)}
+
+
+def live_traffic(args):
+    """HBM bytes per launch of every convolution kernel from two rocprofv3 PMC passes (FETCH_SIZE; WRITE_SIZE -- they
+    do not fit one pass) of a CHILD run of this workload (1 warm-up + 1 step, kernel-trace only).  bytes = 2 *
+    FETCH_SIZE + WRITE_SIZE (KiB): on gfx950 FETCH_SIZE reports half of the bytes of a wide streaming read
+    (MI355X_MICROARCH.md, HBM section).  Returns {"kernels": {...}} or {"error": ...}."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    sys.path.insert(0, os.path.join(HERE, "scripts"))
+    import collections
+    import sqlite3
+    from kname import short
+    out = tempfile.mkdtemp(prefix="vfx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VFX_PROFILE_DUMP"):
+        env.pop(k, None)
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-roofline", "--no-alt",
+             "--cpu-baseline-clips", "0", "--traffic", "off", "--no-parity", "--workload", args.workload,
+             "--precision", str(args.precision), "--clips", str(args.clips), "--seconds", str(args.seconds)]
+    try:
+        dbs = {}
+        for name, counter in (("tcc1", "FETCH_SIZE"), ("tcc2", "WRITE_SIZE")):
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(out, name), "-o", name, "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            found = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(out, name)) for f in fs if f.endswith("_results.db")]
+            if r.returncode != 0 or not found:
+                return {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:])}
+            dbs[counter] = found[0]
+
+        def load(db, counter):
+            c = sqlite3.connect(db)
+            rows = c.execute("select dispatch_id, kernel_name, sum(value) from counters_collection where counter_name=? "
+                             "group by dispatch_id order by dispatch_id", (counter,)).fetchall()
+            return [(short(k), v) for _, k, v in rows]
+        rd, wr = load(dbs["FETCH_SIZE"], "FETCH_SIZE"), load(dbs["WRITE_SIZE"], "WRITE_SIZE")
+        if len(rd) != len(wr) or not rd:
+            return {"error": "PMC passes disagree on the launch sequence (%d vs %d)" % (len(rd), len(wr))}
+        first = [i for i, (k, _) in enumerate(rd) if k.startswith("k_stft_mel")]
+        last = first[-1] if first else 0                      # launches of the last step
+        per = collections.OrderedDict()
+        for (k, r), (_, w) in list(zip(rd, wr))[last:]:
+            if not (k.startswith("k_conv") or k.startswith("k_resblock")):
+                continue
+            t = per.setdefault(k, [0, 0.0, 0.0])
+            t[0] += 1
+            t[1] += 2.0 * r * 1024.0
+            t[2] += w * 1024.0
+        return {"kernels": {k: {"launches_per_step": v[0], "read_bytes_per_launch": round(v[1] / v[0]),
+                                "write_bytes_per_launch": round(v[2] / v[0]), "bytes_per_launch": round((v[1] + v[2]) / v[0])}
+                            for k, v in per.items()}}
+    except Exception as e:  # never fatal for the throughput measurement
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    maybe_spawn(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    from voicefixer_main_amd import dist as vdist
     from voicefixer_main_amd import synth
-    from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_VOCODER
+    from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER
 
-    eng = Engine(device, config={"precision": args.precision})
-    eng.load_state_dict(MODEL_UNET_MEL, synth.make_resunet_state_dict(0))
-    eng.load_state_dict(MODEL_VOCODER, synth.make_vocoder_state_dict(1))
+    wl = args.workload
+    gsr = wl in ("gsr16x10", "sharded1024")
 
-    clips = synth.make_clips(args.clips, args.seconds, seed=1234 + 1000 * rank)      # (B, 1, L) float32, host
-    wav = torch.from_numpy(clips[:, 0]).to(device)                                   # resident in HBM
-    out = torch.empty_like(wav)
-    B, L = wav.shape
+    def make_engine(precision):
+        e = Engine(device, config={"precision": precision})
+        if gsr:
+            e.load_state_dict(MODEL_UNET_MEL, synth.make_resunet_state_dict(0))
+            e.load_state_dict(MODEL_VOCODER, synth.make_vocoder_state_dict(1))
+        else:
+            e.load_state_dict(MODEL_UNET_SPEC, synth.make_resunet_state_dict(2))
+        return e
+
+    eng = make_engine(args.precision)
+    B = args.clips
+    extra = {}
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
 
     if world > 1 and args.dist_selfcheck:
-        # Exercise the shard scatter / gather over RCCL once, outside the timed region (opt-in: a point-to-point
-        # problem on one rank would otherwise hang the whole measurement; the logic itself is covered on gloo).
-        try:
-            from voicefixer_main_amd import dist as vdist
-            vdist.selfcheck(device)
-        except Exception as e:  # never fatal for the throughput measurement
-            print("[bench] scatter/gather self-check failed on rank %d: %r" % (rank, e), file=sys.stderr)
+        vdist.selfcheck(device)
+    rccl_ranks = vdist.live_ranks(device)
 
+    # ---- the step of each workload ------------------------------------------------------------------
+    if wl == "gsr16x10":
+        clips = synth.make_clips(B, args.seconds, seed=1234 + 1000 * rank)               # (B, 1, L) float32, host
+        wav = torch.from_numpy(clips[:, 0]).to(device)                                   # resident in HBM
+        out = torch.empty_like(wav)
+        L = wav.shape[1]
+        step = lambda e=eng: e.restore_gsr(wav, out=out)
+        audio_per_step = world * B * args.seconds
+    elif wl == "sharded1024":
+        n_total = B * world
+        L = int(round(args.seconds * 44100))
+        if rank == 0:
+            clips = synth.make_clips(n_total, args.seconds, seed=1234)
+            full = torch.from_numpy(clips[:, 0]).to(device)                              # all clips live on rank 0
+        else:
+            clips, full = None, None
+        phases = {"scatter_ms": 0.0, "restore_ms": 0.0, "gather_ms": 0.0}
+        gathered = [None]
+        sync = lambda: torch.cuda.synchronize(device)
+
+        def step(e=eng, acc=phases):
+            back, t = vdist.sharded_step(lambda x: e.restore_gsr(x), full, n_total, L, device, sync=sync)
+            gathered[0] = back
+            for k in acc:
+                acc[k] += t[k]
+        audio_per_step = n_total * args.seconds
+    elif wl == "ssr_sr64":
+        clips = synth.make_clips(B, args.seconds, seed=7 + 1000 * rank, mode="lowpass")   # 1-kHz cheby1 low-pass: 2 kHz -> 44.1 kHz SR
+        wav = torch.from_numpy(clips[:, 0]).to(device)
+        L = wav.shape[1]
+        holder = [None]
+
+        def step(e=eng):
+            sp = e.stft(wav, want_mel=False, want_sp=True)["sp"]        # eval_ssr_unet.py:80
+            holder[0] = e.resunet_spec(sp, wav)                         # STFT (phase) + trunk + ISTFT, unet_v2.py:86-148
+        audio_per_step = world * B * args.seconds
+    else:  # stream1s
+        clips = synth.make_clips(1, args.seconds, seed=11 + 1000 * rank)
+        wav = torch.from_numpy(clips[:, 0]).to(device)
+        L = wav.shape[1]
+        holder = [None]
+
+        def eager(e=eng):
+            sp = e.stft(wav, want_mel=False, want_sp=True)["sp"]
+            holder[0] = e.resunet_spec(sp, wav)
+        eager()                                                         # plans, arena (no allocation inside the capture)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            eager()
+            torch.cuda.synchronize(device)
+            with torch.cuda.graph(graph, stream=side):
+                eager()
+        torch.cuda.current_stream(device).wait_stream(side)
+        step = graph.replay
+        audio_per_step = world * args.seconds
+        extra["hipgraph"] = True
+
+    # ---- timed region ---------------------------------------------------------------------------------
     for _ in range(args.warmup):
-        eng.restore_gsr(wav, out=out)
+        step()
     torch.cuda.synchronize(device)
+    if wl == "sharded1024":
+        for k in phases:
+            phases[k] = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.restore_gsr(wav, out=out)
+        step()
     torch.cuda.synchronize(device)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     flags = eng.take_flags()
-    finite = bool(torch.isfinite(out).all().item())
 
-    roofline = None
-    if not args.no_roofline and rank == 0:
-        roofline = measure_roofline(eng, wav, out, args)
-
+    res = None
+    failed = None
     if rank == 0:
-        audio_s = world * B * args.seconds * args.steps
         res = {
             "metric": "restored-audio sec/s (RTF^-1), VoiceFixer 44.1 kHz",
-            "value": round(audio_s / dt, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "value": round(audio_per_step * args.steps / dt, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {0: "f32", 1: "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)",
-                      2: "f16 (vocoder: fp16 operands, 1 MFMA per product; ResUNet: split-bf16 hi+lo; fp32 accumulate)"}[args.precision],
+                      2: "f16 (vocoder: fp16 operands, 1 MFMA per product; ResUNet: split-bf16 hi+lo; fp32 accumulate)"
+                      if gsr else "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "gsr_voicefixer ResUNet+vocoder restore, batch=%dx%.0f s @44.1 kHz per GPU "
-                                   "(BASELINE.json configs[1], 16-bit operands); ResUNet: split-bf16 (plain bf16 misses the "
-                                   "log-mel L1<=1e-3 bar 19x, split meets it with >10x margin: 4e-5); vocoder: fp16 operands, "
-                                   "waveform SI-SDR 58 dB and restored-waveform log-mel L1 2.4e-4 vs the fp32 oracle"
-                                   % (B, args.seconds),
-                       "precision_mode": args.precision,
-                       "clips_per_gpu": B, "clip_seconds": args.seconds, "parallelism": "dp%d" % world,
-                       "weights": "seeded random (no checkpoint available offline)"},
-            "outputs_finite": finite, "negative_input_flag": flags,
+            "config": {"workload": wl, "precision_mode": args.precision, "clips_per_gpu": B, "clip_seconds": args.seconds,
+                       "parallelism": "dp%d" % world, "weights": "seeded random (no checkpoint available offline)"},
+            "rccl_ranks": rccl_ranks, "negative_input_flag": flags,
         }
-        if roofline:
-            res["roofline"] = roofline
-        if world == 1 and args.precision == 2 and not args.no_alt:
-            # Same workload with every GEMM-shaped layer on split-bf16 operands (precision 1: 3 MFMAs per product in the
-            # vocoder as well): the stricter arithmetic, reported beside `value`.
+        res.update(extra)
+        if gsr and args.precision == 2:
+            res["caveat"] = ("precision 2 runs the vocoder on fp16 operands; its waveform parity is established on seeded "
+                             "synthetic vocoder weights (the pretrained TFGAN checkpoint is not obtainable offline) -- "
+                             "`split_bf16_mode` is the conservative figure")
+
+    # ---- outputs of the benched batch (for parity), oracle sample --------------------------------------
+    if rank == 0 and wl == "gsr16x10":
+        out_p, logmel_p = eng.restore_gsr(wav, want_logmel=True)
+        res["outputs_finite"] = bool(torch.isfinite(out_p).all().item())
+    elif rank == 0 and wl == "sharded1024":
+        res["outputs_finite"] = bool(torch.isfinite(gathered[0]).all().item()) and tuple(gathered[0].shape) == (n_total, L)
+        for k in phases:
+            res[k] = round(phases[k] / args.steps, 3)
+        res["clips_total"] = n_total
+        res["sub_batches_per_rank"] = -(-B // 37)        # 32-bit tensor addressing: <= 37 clips of 10 s per launch
+        # the gathered result is the restore of the scattered clips: check two clips against a direct call
+        chk = eng.restore_gsr(full[:2])
+        res["gather_matches_direct_restore"] = bool(torch.equal(chk, gathered[0][:2]))
+    elif rank == 0:
+        res["outputs_finite"] = bool(torch.isfinite(holder[0]).all().item())
+
+    if rank == 0 and world == 1:
+        traffic = None
+        if not args.no_roofline:
+            if args.traffic == "live" and gsr:
+                traffic = live_traffic(args)
+            rstep = step if wl != "stream1s" else eager      # HIP events cannot be recorded inside a graph replay
+            if wl == "sharded1024":
+                rstep = lambda: eng.restore_gsr(full[:37])   # one full sub-batch of the shard
+            res["roofline"] = measure_conv_roofline(eng, rstep, args, traffic)
+            res["roofline_hbm"] = measure_hbm_stages(eng, min(B, 64), L)
+        if args.cpu_baseline_clips > 0:
             try:
-                alt = Engine(device, config={"precision": 1})
-                alt.load_state_dict(MODEL_UNET_MEL, synth.make_resunet_state_dict(0))
-                alt.load_state_dict(MODEL_VOCODER, synth.make_vocoder_state_dict(1))
+                res["cpu_baseline"], ref = cpu_baseline("gsr" if gsr else "ssr", clips, args.cpu_baseline_clips, args.cpu_threads)
+            except Exception as e:
+                res["cpu_baseline"], ref = {"error": repr(e)}, None
+            if ref is not None and not args.no_parity:
+                n = args.cpu_baseline_clips
+                if wl == "gsr16x10":
+                    res["parity"] = parity_gsr(out_p[:n], logmel_p[:n], ref)
+                    if res["parity"]["logmel_l1"] > LOGMEL_L1_BAR:
+                        failed = "log-mel L1 %.3g exceeds the %.0e bar" % (res["parity"]["logmel_l1"], LOGMEL_L1_BAR)
+                elif wl in ("ssr_sr64", "stream1s"):
+                    res["parity"] = parity_wav(holder[0][:n], ref["wav"][:, 0])
+        if gsr and wl == "gsr16x10" and args.precision == 2 and not args.no_alt:
+            # Same workload with every GEMM-shaped layer on split-bf16 operands (precision 1: 3 MFMAs per product in the
+            # vocoder as well): the stricter arithmetic, reported beside `value`, with its own parity.
+            try:
+                alt = make_engine(1)
                 for _ in range(max(args.warmup, 1)):
                     alt.restore_gsr(wav, out=out)
                 torch.cuda.synchronize(device)
@@ -247,22 +517,23 @@ def main():
                 res["split_bf16_mode"] = {
                     "value": round(B * args.seconds * args.steps / dta, 2), "unit": "audio-s/s",
                     "ms_per_step": round(dta / args.steps * 1e3, 3), "outputs_finite": bool(torch.isfinite(out).all().item()),
-                    "dtype": "bf16x3 everywhere (split-bf16 operands hi+lo, 3 MFMAs per product, fp32 accumulate)",
-                    "parity": "waveform SI-SDR 88-94 dB vs the fp32 oracle; value's mode: 58 dB "
-                              "(profiles/r01_parity_fp16_vocoder.json)"}
+                    "dtype": "bf16x3 everywhere (split-bf16 operands hi+lo, 3 MFMAs per product, fp32 accumulate)"}
+                if "parity" in res:
+                    n = args.cpu_baseline_clips
+                    o1, l1 = alt.restore_gsr(wav[:n], want_logmel=True)
+                    res["split_bf16_mode"]["parity"] = parity_gsr(o1, l1, ref)
                 del alt
             except Exception as e:
                 res["split_bf16_mode"] = {"error": repr(e)}
-        if world == 1 and args.cpu_baseline_clips > 0:
-            try:
-                res["cpu_baseline"] = cpu_baseline(clips, args.cpu_baseline_clips, args.cpu_threads)
-            except Exception as e:
-                res["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        if failed:
+            res["parity_failed"] = failed
         print(json.dumps(res))
     if world > 1:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: parity check failed: " + failed)
 
 
 if __name__ == "__main__":

@@ -106,6 +106,13 @@ int vfx_reserve(vfx_handle* h, int model, int B, int T);
 int vfx_stft_mel(vfx_handle* h, const float* wav, int B, int L, float* mel, float* sp,
                  float* cosp, float* sinp, int log10_mel, void* stream);
 
+/* FDomainHelper.spectrogram_phase(input, eps) (tools/pytorch/modules/fDomainHelper.py:60-65) with the caller's eps:
+ * mag = sqrt(clamp(re^2 + im^2, eps, inf)), cos = re / mag, sin = im / mag; any of sp / cosp / sinp (B, T, 1025) may be
+ * NULL.  eps = 0 (the reference default of this method) gives 0/0 = NaN phases at exactly silent bins, as the
+ * reference does; vfx_stft_mel is the eps = 1e-8 case every handler call site uses (fDomainHelper.py:67). */
+int vfx_stft_phase(vfx_handle* h, const float* wav, int B, int L, float* sp, float* cosp, float* sinp,
+                   float eps, void* stream);
+
 /* MelScale.forward alone (tools/pytorch/mel_scale.py:52-64): sp (rows, 1025) -> mel (rows, 128). */
 int vfx_mel_project(vfx_handle* h, const float* sp, int64_t rows, float* mel, void* stream);
 

@@ -102,8 +102,8 @@ def istft(re, im, length, n_fft=N_FFT, hop=HOP, dtype=np.float64):
     """(B, T, 1025) real / imag -> (B, length) waveform.
 
     Hermitian-extend, IDFT, multiply by the synthesis window, overlap-add, divide
-    by the window sum-of-squares envelope where it is non-tiny, strip n_fft//2
-    samples each side, then zero-pad / truncate to `length`.
+    by the window sum-of-squares envelope where it is non-tiny, strip the leading
+    n_fft//2 samples and keep `length` samples (`y[:, n_fft//2 : n_fft//2 + length]`).
     """
     re = np.asarray(re, np.float64)
     im = np.asarray(im, np.float64)
@@ -115,10 +115,12 @@ def istft(re, im, length, n_fft=N_FFT, hop=HOP, dtype=np.float64):
     env = window_sumsquare(T, n_fft, hop)
     nz = env > np.finfo(np.float32).tiny
     y[:, nz] /= env[nz]
-    y = y[:, n_fft // 2:y.shape[1] - n_fft // 2]
+    # torchlibrosa: y[:, n_fft//2 : n_fft//2 + length]; the in-repo twin tools/dsp/base.py:193-200 does the same
+    # (start = n_fft//2, end = start + length): the samples past hop*(T-1) are reconstructed from the tail of the
+    # last frames, NOT zeroed.  Zeros only past the end of the overlap-add buffer (T not matching length).
+    y = y[:, n_fft // 2:n_fft // 2 + length]
     out = np.zeros((B, length), np.float64)
-    n = min(length, y.shape[1])
-    out[:, :n] = y[:, :n]
+    out[:, :y.shape[1]] = y
     return out.astype(dtype)
 
 

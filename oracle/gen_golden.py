@@ -150,7 +150,9 @@ def main():
     spec.f_helper = TorchStftHelper()
     sd2 = synth.make_resunet_state_dict(2)
     spec.load_state_dict(sd2, strict=False)
-    wav = torch.from_numpy(synth.make_clips(1, 0.32, seed=99))           # (1,1,14112) -> T = 33
+    # L = 14312 = 32 * 441 + 200: NOT a multiple of the hop, so the fixture pins the last L mod 441 samples, which
+    # torch.istft(length=L) (like torchlibrosa and tools/dsp/base.py:193-200) reconstructs from the last frames' tails
+    wav = torch.from_numpy(synth.make_clips(1, 14312 / 44100.0, seed=99))   # (1,1,14312) -> T = 33
     sp, _, _ = spec.f_helper.wav_to_spectrogram_phase(wav)
     mags = {}
     spec.after_conv2.register_forward_hook(lambda m, i, o: mags.__setitem__("mag", o.detach()))

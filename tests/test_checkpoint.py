@@ -1,0 +1,130 @@
+"""Lightning-format checkpoint path: `Model(hp, ...).load_from_checkpoint(ckpt)` of
+eval_gsr_voicefixer.py:33 / models/gsr_voicefixer.py:106,139.
+
+The file is built the way pytorch_lightning 1.5 writes it: a dict with `state_dict` (module-prefixed keys incl. the
+frozen STFT conv weights, `mel.fb`, BatchNorm `num_batches_tracked` counters, the vocoder's weight-norm pairs) and
+`hyper_parameters` pickled with a project class that is NOT importable where the file is read.
+"""
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lightning_state_dict(unet_sd, voc_sd):
+    from voicefixer_main_amd.models import MelScale
+    sd = {}
+    for k, v in unet_sd.items():
+        sd["generator.analysis_module." + k] = v.clone()
+        if k.endswith("running_var"):
+            sd["generator.analysis_module." + k[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(1234)
+    # frozen front-end buffers Lightning saves with the module (fDomainHelper.py:26-32, mel_scale.py:49)
+    sd["f_helper.stft.conv_real.weight"] = torch.zeros(1025, 1, 2048)
+    sd["f_helper.stft.conv_imag.weight"] = torch.zeros(1025, 1, 2048)
+    sd["f_helper.istft.conv_real.weight"] = torch.zeros(2048, 2048, 1)
+    sd["mel.fb"] = MelScale.filterbank(1025, 128, 44100, 22050.0)
+    # the pip vocoder keeps weight_norm parametrisations: weight = g * v / ||v||
+    for k, v in voc_sd.items():
+        if k.endswith(".weight"):
+            base = "vocoder.model." + k[:-len("weight")]
+            norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape((-1,) + (1,) * (v.dim() - 1))
+            scale = torch.rand(norm.shape, generator=torch.Generator().manual_seed(len(k))) + 0.5
+            sd[base + "weight_g"] = norm * 1.0
+            sd[base + "weight_v"] = v * scale / scale      # same direction, g carries the norm
+        else:
+            sd["vocoder.model." + k] = v.clone()
+    return sd
+
+
+def _write_lightning_ckpt(path, sd):
+    """`hyper_parameters` holds an instance of a class from a module that does not exist at read time."""
+    mod = types.ModuleType("tools_of_the_training_repo")
+    cls = type("HParams", (object,), {"__module__": mod.__name__})
+    mod.HParams = cls
+    sys.modules[mod.__name__] = mod
+    try:
+        hp = cls()
+        hp.model = {"window_size": 2048, "hop_size": 441, "mel_freq_bins": 128}
+        hp.data = {"sampling_rate": 44100}
+        torch.save({"epoch": 3, "global_step": 1000, "pytorch-lightning_version": "1.5.0", "state_dict": sd,
+                    "hyper_parameters": {"hp": hp, "channels": 2, "type_target": "vocals"},
+                    "optimizer_states": [], "lr_schedulers": []}, path)
+    finally:
+        del sys.modules[mod.__name__]
+
+
+def test_read_lightning_checkpoint_with_unimportable_hparams(tmp_path):
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.models import fold_weight_norm, read_checkpoint
+    unet_sd, voc_sd = synth.make_resunet_state_dict(0), synth.make_vocoder_state_dict(1)
+    sd = _lightning_state_dict(unet_sd, voc_sd)
+    path = str(tmp_path / "epoch=3-step=1000-val_l=0.12.ckpt")
+    _write_lightning_ckpt(path, sd)
+    with pytest.raises(pickle.UnpicklingError):      # this is why the second reader exists
+        torch.load(path, map_location="cpu", weights_only=True)
+    got = read_checkpoint(path)
+    assert set(got) == set(sd)
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    # what the engine is fed: prefixes stripped, weight-norm folded back to the plain weights
+    voc = fold_weight_norm({k[len("vocoder.model."):]: v for k, v in got.items() if k.startswith("vocoder.model.")})
+    assert set(voc) == set(voc_sd)
+    for k in voc_sd:
+        assert torch.allclose(voc[k], voc_sd[k], rtol=1e-6, atol=1e-8), k
+    # a bare state_dict file works too
+    bare = str(tmp_path / "bare.pt")
+    torch.save(unet_sd, bare)
+    assert set(read_checkpoint(bare)) == set(unet_sd)
+
+
+class _Evil:
+    def __reduce__(self):
+        return (os.system, ("touch %s" % _Evil.marker,))
+
+
+def test_checkpoint_reader_executes_nothing_the_file_names(tmp_path):
+    from voicefixer_main_amd.models import read_checkpoint
+    _Evil.marker = str(tmp_path / "pwned")
+    path = str(tmp_path / "evil.ckpt")
+    torch.save({"state_dict": {"w": torch.ones(3)}, "hyper_parameters": {"x": _Evil()}}, path)
+    sd = read_checkpoint(path)                       # os.system is replaced by an inert stand-in
+    assert not os.path.exists(_Evil.marker)
+    assert torch.equal(sd["w"], torch.ones(3))
+    torch.save({"state_dict": {"w": _Evil()}}, path)
+    with pytest.raises(ValueError):
+        read_checkpoint(path)
+    assert not os.path.exists(_Evil.marker)
+
+
+@pytest.mark.gpu
+def test_load_from_checkpoint_equals_load_state_dict(tmp_path):
+    """VoiceFixer(hp, ...).load_from_checkpoint(path) -> the same restored audio, bit for bit, as load_state_dict of
+    the plain tensors (eval_gsr_voicefixer.py:31-35)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from voicefixer_main_amd import models, synth
+    unet_sd, voc_sd = synth.make_resunet_state_dict(0), synth.make_vocoder_state_dict(1)
+    path = str(tmp_path / "model.ckpt")
+    _write_lightning_ckpt(path, _lightning_state_dict(unet_sd, voc_sd))
+    wav = torch.from_numpy(synth.make_clips(2, 0.7)).cuda()
+    a = models.VoiceFixer(None, channels=2, type_target="vocals").load_from_checkpoint(path)
+    a.eval()
+    a = a.to(torch.device("cuda:0"))
+    ya = a.restore(wav)
+    b = models.VoiceFixer(None, channels=2, type_target="vocals")
+    plain = {"generator.analysis_module." + k: v for k, v in unet_sd.items()}
+    plain.update({"vocoder." + k: v for k, v in voc_sd.items()})
+    b.load_state_dict(plain)
+    yb = b.restore(wav)
+    assert torch.isfinite(ya).all()
+    # the folded weights g * v / ||v|| differ from the originals in the last bit, so compare at fp32 rounding level
+    err = float((ya - yb).abs().max())
+    assert err < 2e-5, err
+    mel = a.pre(wav)[1]
+    assert torch.equal(a(mel)["mel"], b(mel)["mel"])          # the ResUNet weights are bit-identical

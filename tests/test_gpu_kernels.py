@@ -131,20 +131,60 @@ def test_stft_mag_phase_mel(engine):
     assert np.abs(lg - dsp.to_log(mel[:, 0])).mean() < 1e-5
 
 
-def test_istft_roundtrip_and_oracle(engine):
+@pytest.mark.parametrize("tail", [0, 1, 200, 440])
+def test_istft_roundtrip_and_oracle(engine, tail):
+    """Whole output incl. the L mod 441 tail samples, against the oracle and torch.istft(length=L)
+    (tools/dsp/base.py:196-200: `end = start + length`)."""
     from oracle import dsp
     from voicefixer_main_amd import synth
-    wav = synth.make_clips(2, 0.6)[:, 0]
-    L = wav.shape[-1]
+    L = 441 * 60 + tail
+    wav = synth.make_clips(2, L / 44100.0)[:, 0]
+    assert wav.shape[-1] == L
     re, im = dsp.stft(wav.astype(np.float64))
     got = engine.istft(re.astype(np.float32), im.astype(np.float32), L).cpu().numpy()
     ref = dsp.istft(re, im, L)
     assert np.abs(got - ref).max() < 5e-6
-    # STFT -> ISTFT perfect reconstruction (tools/dsp/base.py:214-232)
+    ti = torch.istft(torch.complex(torch.from_numpy(re), torch.from_numpy(im)).transpose(1, 2), 2048, 441, 2048,
+                     torch.hann_window(2048, periodic=True, dtype=torch.float64), center=True, length=L).numpy()
+    assert np.abs(got - ti).max() < 5e-6
+    if tail:
+        assert np.abs(got[:, -tail:] - ti[:, -tail:]).max() < 5e-6 and np.abs(got[:, -tail:]).max() > 1e-3
+    # STFT -> ISTFT perfect reconstruction over the WHOLE clip (tools/dsp/base.py:214-232)
     o = engine.stft(wav, want_mel=False, want_sp=True, want_phase=True)
     back = engine.istft(o["sp"] * o["cos"], o["sp"] * o["sin"], L).cpu().numpy()
-    n = (L // 441) * 441
-    assert np.abs(back[:, :n] - wav[:, :n]).max() < 1e-5
+    assert np.abs(back - wav).max() < 1e-5
+    # T frames that do not reach L: zeros only past the end of the overlap-add buffer
+    short = engine.istft(re[:, :20].astype(np.float32), im[:, :20].astype(np.float32), L).cpu().numpy()
+    assert np.abs(short - dsp.istft(re[:, :20], im[:, :20], L)).max() < 5e-6
+    assert np.all(short[:, 1024 + 441 * 19:] == 0)
+
+
+def test_spectrogram_phase_eps(engine):
+    """FDomainHelper.spectrogram_phase(input, eps) (fDomainHelper.py:60-65): the clamp is on the POWER and is the
+    caller's; eps = 0 (that method's default) leaves exactly silent bins at magnitude 0 with NaN phases."""
+    from oracle import dsp
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.models import FDomainHelper
+    fh = FDomainHelper(engine)
+    wav = synth.make_clips(2, 0.4)[:, 0]
+    wav[1] = 0.0                                               # a silent clip: every bin exactly zero
+    x = torch.from_numpy(wav).cuda()
+    for eps in (1e-8, 1e-4, 0.0):
+        sp, cos, sin = fh.spectrogram_phase(x, eps=eps)
+        mag, c, s_ = dsp.spectrogram_phase(wav[:, None].astype(np.float64), eps=max(eps, 1e-300))
+        assert sp.shape == (2, 1, wav.shape[-1] // 441 + 1, 1025)
+        assert np.abs(sp.cpu().numpy()[0] - mag[0]).max() < 3e-6 * mag.max()
+        if eps > 0:
+            assert float(sp.min()) >= np.sqrt(eps) * (1 - 1e-6)
+            assert torch.isfinite(cos).all() and torch.isfinite(sin).all()
+            assert float(sp[1].max()) <= np.sqrt(eps) * (1 + 1e-6)
+        else:
+            assert float(sp[1].abs().max()) == 0.0 and torch.isnan(cos[1]).all() and torch.isnan(sin[1]).all()
+            assert torch.isfinite(cos[0]).all()
+    sp8, _, _ = fh.wav_to_spectrogram_phase(x[:, None])        # the handlers' call: eps = 1e-8
+    assert float(sp8.min()) >= 1e-4 * (1 - 1e-6)
+    with pytest.raises(ValueError):
+        fh.spectrogram_phase(x, eps=-1.0)
 
 
 def test_mel_project(engine):

@@ -95,7 +95,13 @@ def test_handler_end_to_end(voicefixer, unet_sd, voc_sd, tmp_path):
     handlers._state["model"] = voicefixer
     metrics = handlers.handler(src, dst, src, ckpt=None, device=torch.device("cuda:0"), needrefresh=False,
                                meta={"unify_energy": False})
-    assert set(metrics) == {"mel-lsd", "mel-sispec", "mel-non-log-sispec"}
+    assert set(metrics) == {"mel-lsd", "mel-sispec", "mel-non-log-sispec", "mel-ssim"}     # eval_gsr_voicefixer.py:59-64
+    assert all(isinstance(v, float) and np.isfinite(v) for v in metrics.values()) and -1.0 <= metrics["mel-ssim"] <= 1.0
+    # a target of another length is an error, as in the reference (no silent trimming)
+    short = str(tmp_path / "short.wav")
+    handlers.save_wave(wav[0, 0, :30000], short)
+    with pytest.raises(RuntimeError):
+        handlers.handler(src, dst, short, ckpt=None, device=torch.device("cuda:0"), needrefresh=False, meta={"unify_energy": False})
     out = handlers.load_wav(dst)
     x = handlers.load_wav(src)
     assert out.shape == x.shape

@@ -79,6 +79,33 @@ def test_handler_glue_matches_oracle_glue():
     assert float(handlers.sispec(est, est)) > 60
 
 
+def test_ssim_matches_the_skimage_algorithm():
+    """handlers.ssim restates skimage.metrics.structural_similarity(win_size=7) (evaluation_proc/metrics.py:97-106;
+    skimage is not installed): checked against the published algorithm written with scipy's uniform_filter."""
+    from scipy.ndimage import uniform_filter
+    from voicefixer_main_amd import handlers
+    rng = np.random.default_rng(0)
+    a = rng.random((2, 1, 40, 128)).astype(np.float32)
+    b = (a + 0.1 * rng.normal(size=a.shape)).astype(np.float32)
+
+    def sk(im1, im2, win=7, R=2.0):
+        im1, im2 = im1.astype(np.float64), im2.astype(np.float64)
+        NP = win * win
+        cov_norm = NP / (NP - 1)
+        ux, uy = uniform_filter(im1, size=win), uniform_filter(im2, size=win)
+        uxx, uyy, uxy = uniform_filter(im1 * im1, size=win), uniform_filter(im2 * im2, size=win), uniform_filter(im1 * im2, size=win)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        C1, C2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+        pad = (win - 1) // 2
+        return S[pad:-pad, pad:-pad].mean()
+    got = handlers.ssim(torch.from_numpy(a), torch.from_numpy(b))
+    assert got.shape == (2, 1, 1, 1)
+    for i in range(2):
+        assert abs(float(got[i, 0, 0, 0]) - sk(a[i, 0], b[i, 0])) < 1e-9
+    assert abs(float(handlers.ssim(torch.from_numpy(a[:1]), torch.from_numpy(a[:1]))) - 1.0) < 1e-12
+
+
 def test_weight_norm_folding():
     from voicefixer_main_amd.models import fold_weight_norm
     v = torch.randn(4, 3, 5)
@@ -86,6 +113,21 @@ def test_weight_norm_folding():
     ref = torch._weight_norm(v, g, 0)
     out = fold_weight_norm({"c.weight_g": g, "c.weight_v": v, "c.bias": torch.zeros(4)})
     assert set(out) == {"c.weight", "c.bias"} and torch.allclose(out["c.weight"], ref, atol=1e-6)
+
+
+def test_sharded_step_without_process_group():
+    """A single process (bench.py --workload sharded1024 at N = 1) is a world of one: no torch.distributed needed."""
+    from voicefixer_main_amd import dist as vdist
+    full = torch.arange(40.0).reshape(5, 8)
+    back, t = vdist.sharded_step(lambda x: x + 1.0, full, 5, 8, torch.device("cpu"))
+    assert torch.equal(back, full + 1.0) and vdist.live_ranks(torch.device("cpu")) == 1
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env,
+                       timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
 def test_shard_bounds():
@@ -112,6 +154,14 @@ back = vdist.gather_clips(mine + 1.0, n, L, dev)
 if rank == 0:
     assert torch.equal(back, full + 1.0)
 assert vdist.selfcheck(dev)
+# the timed step of bench.py --workload sharded1024 (BASELINE.json configs[3]): scatter -> restore -> gather
+assert vdist.world_rank() == (world, rank) and vdist.live_ranks(dev) == world
+back, t = vdist.sharded_step(lambda x: x * 3.0 + 1.0, full, n, L, dev)
+if rank == 0:
+    assert torch.equal(back, full * 3.0 + 1.0)
+else:
+    assert back is None
+assert set(t) == {"scatter_ms", "restore_ms", "gather_ms"} and all(v >= 0 for v in t.values())
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

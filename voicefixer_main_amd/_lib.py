@@ -39,6 +39,7 @@ SIGNATURES = {
     "vfx_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "vfx_reserve": (c_int, [c_void_p, c_int, c_int, c_int]),
     "vfx_stft_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfx_stft_phase": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "vfx_mel_project": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "vfx_istft": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vfx_spectral_metrics": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

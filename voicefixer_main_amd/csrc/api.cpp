@@ -643,27 +643,6 @@ void init_front_end(vfx_handle* h) {
   h->fe.voc_inv_weight = h->blob.upload(invw);
 }
 
-// 1 / window-sumsquare envelope of T frames (librosa.filters.window_sumsquare semantics; bins
-// whose envelope is tiny are left undivided).
-const float* istft_envelope(vfx_handle* h, int T) {
-  if (h->fe.inv_env && h->fe.inv_env_T == T) return h->fe.inv_env;
-  const int N = h->cfg.n_fft, hop = h->cfg.hop;
-  std::vector<double> env((size_t)N + (size_t)hop * (T - 1), 0.0);
-  std::vector<double> w2(N);
-  for (int n = 0; n < N; ++n) {
-    const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * n / N);
-    w2[n] = w * w;
-  }
-  for (int t = 0; t < T; ++t)
-    for (int n = 0; n < N; ++n) env[(size_t)t * hop + n] += w2[n];
-  std::vector<float> inv(env.size());
-  for (size_t i = 0; i < env.size(); ++i) inv[i] = env[i] > 1.1754944e-38 ? (float)(1.0 / env[i]) : 1.0f;
-  VFX_HIP(hipDeviceSynchronize());
-  h->fe.inv_env = h->blob.upload(inv);  // previous tables stay allocated until destroy (few, small)
-  h->fe.inv_env_T = T;
-  return h->fe.inv_env;
-}
-
 }  // namespace vfx
 
 // =============================================================================================
@@ -672,6 +651,8 @@ const float* istft_envelope(vfx_handle* h, int T) {
 using namespace vfx;
 
 #define VFX_API_BEGIN try {
+// entry points that take a handle: NULL check + run on the handle's device, restore the caller's on exit
+#define VFX_API_BEGIN_H(h) try { VFX_CHECK((h) != nullptr, "NULL handle"); ::vfx::DeviceGuard device_guard_((h)->device);
 #define VFX_API_END                         \
   }                                         \
   catch (const vfx::Error&) { return 1; }   \
@@ -714,7 +695,7 @@ int vfx_default_config(vfx_config* cfg) {
 int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   VFX_API_BEGIN
   VFX_CHECK(out != nullptr, "vfx_create: out is NULL");
-  VFX_HIP(hipSetDevice(device));
+  DeviceGuard device_guard_(device);  // the caller's current device is left as it was
   auto h = std::make_unique<vfx_handle>();
   h->device = device;
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
@@ -733,11 +714,14 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
 
 int vfx_destroy(vfx_handle* h) {
   if (!h) return 0;
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) prev = -1;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   h->plans.clear();
   if (h->arena) (void)hipFree(h->arena);
   delete h;
+  if (prev >= 0) (void)hipSetDevice(prev);
   return 0;
 }
 
@@ -757,9 +741,7 @@ int vfx_load_tensor(vfx_handle* h, int model, const char* name, const float* dat
 }
 
 int vfx_finalize_weights(vfx_handle* h, int model) {
-  VFX_API_BEGIN
-  VFX_CHECK(h, "NULL handle");
-  VFX_HIP(hipSetDevice(h->device));
+  VFX_API_BEGIN_H(h)
   h->plans.clear();
   if (model == VFX_MODEL_UNET_MEL || model == VFX_MODEL_UNET_SPEC) {
     h->unet[model] = build_unet_weights(h, model);
@@ -782,7 +764,7 @@ int vfx_finalize_weights(vfx_handle* h, int model) {
 }
 
 int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && flags_out, "NULL argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   int v = 0;
@@ -800,23 +782,34 @@ static int frames_of(const vfx_handle* h, int L) { return L / h->cfg.hop + 1; }
 
 int vfx_stft_mel(vfx_handle* h, const float* wav, int B, int L, float* mel, float* sp, float* cosp, float* sinp,
                  int log10_mel, void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && wav, "NULL argument");
   VFX_CHECK(B > 0 && L > h->cfg.n_fft / 2, "vfx_stft_mel: need B > 0 and L > n_fft/2 (reflect padding), got B=%d L=%d", B, L);
-  launch_stft_mel(h->fe, wav, B, L, frames_of(h, L), mel, sp, cosp, sinp, log10_mel, h->cfg.hop,
+  launch_stft_mel(h->fe, wav, B, L, frames_of(h, L), mel, sp, cosp, sinp, log10_mel, h->cfg.hop, 1e-8f,
+                  static_cast<hipStream_t>(stream));
+  VFX_API_END
+}
+
+int vfx_stft_phase(vfx_handle* h, const float* wav, int B, int L, float* sp, float* cosp, float* sinp, float eps,
+                   void* stream) {
+  VFX_API_BEGIN_H(h)
+  VFX_CHECK(wav && (sp || cosp || sinp), "NULL argument");
+  VFX_CHECK(B > 0 && L > h->cfg.n_fft / 2, "vfx_stft_phase: need B > 0 and L > n_fft/2 (reflect padding), got B=%d L=%d", B, L);
+  VFX_CHECK(eps >= 0.f, "vfx_stft_phase: eps must be >= 0 (got %g)", (double)eps);
+  launch_stft_mel(h->fe, wav, B, L, frames_of(h, L), nullptr, sp, cosp, sinp, 0, h->cfg.hop, eps,
                   static_cast<hipStream_t>(stream));
   VFX_API_END
 }
 
 int vfx_mel_project(vfx_handle* h, const float* sp, int64_t rows, float* mel, void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && sp && mel && rows > 0, "bad argument");
   launch_mel_project(h->fe, sp, rows, mel, static_cast<hipStream_t>(stream));
   VFX_API_END
 }
 
 int vfx_spectral_metrics(vfx_handle* h, const float* est, const float* target, int B, int T, int F, float* out, void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && est && target && out && B > 0 && T > 0 && F > 0 && B <= 65535, "bad argument");
   // per-frame partial sums live in the arena (no plan is running concurrently: single stream, single thread)
   Plan tmp;
@@ -829,7 +822,7 @@ int vfx_spectral_metrics(vfx_handle* h, const float* est, const float* target, i
 
 int vfx_chunk_gather(vfx_handle* h, const float* x, int B, int L, int win, int hop, int lead, int n_chunks,
                      float* chunks, void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && x && chunks && B > 0 && L > 0 && win > 0 && hop > 0 && lead >= 0 && n_chunks > 0, "bad argument");
   VFX_CHECK(B <= 65535 && n_chunks <= 65535, "chunk grid too large");
   launch_chunk_gather(x, B, L, win, hop, lead, n_chunks, chunks, static_cast<hipStream_t>(stream));
@@ -838,7 +831,7 @@ int vfx_chunk_gather(vfx_handle* h, const float* x, int B, int L, int win, int h
 
 int vfx_chunk_ola(vfx_handle* h, const float* frames, const float* window, float scale, int B, int n_chunks, int win,
                   int hop, int lead, int L, float* y, void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && frames && y && B > 0 && L > 0 && win > 0 && hop > 0 && lead >= 0 && n_chunks > 0, "bad argument");
   VFX_CHECK(B <= 65535, "batch too large");
   launch_chunk_ola(frames, window, scale, B, n_chunks, win, hop, lead, L, y, static_cast<hipStream_t>(stream));
@@ -846,16 +839,15 @@ int vfx_chunk_ola(vfx_handle* h, const float* frames, const float* window, float
 }
 
 int vfx_istft(vfx_handle* h, const float* re, const float* im, int B, int T, int L, float* wav, void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && re && im && wav && B > 0 && T > 0 && L > 0, "bad argument");
-  const float* env = istft_envelope(h, T);
   const size_t need = (size_t)B * T * h->cfg.n_fft * sizeof(float);
   if (need > h->arena_bytes) h->plans.clear();  // plans hold absolute pointers into the old arena
   // reuse the arena as the frame buffer (no plan is running concurrently: single stream, single thread)
   Plan tmp;
   tmp.arena_bytes = need;
   bind_plan(h, tmp);
-  launch_istft(h->fe, re, im, B, T, L, h->cfg.hop, env, reinterpret_cast<float*>(h->arena), wav,
+  launch_istft(h->fe, re, im, B, T, L, h->cfg.hop, reinterpret_cast<float*>(h->arena), wav,
                static_cast<hipStream_t>(stream));
   VFX_API_END
 }
@@ -872,10 +864,19 @@ static std::shared_ptr<Plan> get_plan(vfx_handle* h, const std::string& key,
     PlanBuilder pb{h, plan.get(), {}};
     build(pb);
     plan->arena_bytes = pb.arena.high;
+    // bounded cache: drop the least recently used plan(s) first (their parameter blocks are hipFree'd, which waits
+    // for the device: nothing in flight still reads them)
+    while (h->plans.size() >= kMaxCachedPlans) {
+      auto victim = h->plans.begin();
+      for (auto i = h->plans.begin(); i != h->plans.end(); ++i)
+        if (i->second->last_use < victim->second->last_use) victim = i;
+      h->plans.erase(victim);
+    }
     h->plans[key] = plan;
   } else {
     plan = it->second;
   }
+  plan->last_use = ++h->plan_tick;
   const char* old = h->arena;
   bind_plan(h, *plan);
   if (old && old != h->arena) {
@@ -904,6 +905,8 @@ static BufRef arena_buf(size_t off) {
 
 size_t vfx_workspace_bytes(vfx_handle* h, int model, int B, int T) {
   try {
+    if (!h) return 0;
+    DeviceGuard device_guard_(h->device);
     Plan plan;
     PlanBuilder pb{h, &plan, {}};
     if (model == VFX_MODEL_UNET_MEL) build_unet_mel(pb, B, T, ext(0), ext(1));
@@ -917,7 +920,7 @@ size_t vfx_workspace_bytes(vfx_handle* h, int model, int B, int T) {
 }
 
 int vfx_reserve(vfx_handle* h, int model, int B, int T) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   const size_t need = vfx_workspace_bytes(h, model, B, T);
   VFX_CHECK(need > 0, "vfx_reserve: cannot plan model %d (weights finalized?): %s", model, vfx_last_error());
   Plan tmp;
@@ -961,7 +964,7 @@ int vfx_resunet_mel(vfx_handle* h, const float* mel_linear, int B, int T, float*
   return 0;
 }
 static int vfx_resunet_mel_1(vfx_handle* h, const float* mel_linear, int B, int T, float* logmel_out, void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && mel_linear && logmel_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL], "vfx_resunet_mel: weights of the mel ResUNet are not finalized");
   auto plan = get_plan(h, key_of("unet_mel", B, T),
@@ -988,11 +991,10 @@ int vfx_resunet_spec(vfx_handle* h, const float* sp, const float* wav, int B, in
 }
 static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, int B, int T, int L, float* wav_out,
                               void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && sp && wav && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->unet[VFX_MODEL_UNET_SPEC], "vfx_resunet_spec: weights of the spectrogram ResUNet are not finalized");
   VFX_CHECK(T == frames_of(h, L), "vfx_resunet_spec: T=%d does not match L=%d (expected %d frames)", T, L, frames_of(h, L));
-  const float* env = istft_envelope(h, T);
   const size_t nsp = (size_t)B * T * (h->cfg.n_fft / 2 + 1);
   auto plan = get_plan(h, key_of("unet_spec", B, T), [&](PlanBuilder& pb) {
     auto& nm = pb.plan->named;
@@ -1011,11 +1013,11 @@ static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, 
   float* cosb = reinterpret_cast<float*>(base + off_cos);
   float* sinb = reinterpret_cast<float*>(base + off_sin);
   // second STFT of the same audio for the phase (unet_v2.py:96)
-  launch_stft_mel(h->fe, wav, B, L, T, nullptr, nullptr, cosb, sinb, 0, h->cfg.hop, s);
+  launch_stft_mel(h->fe, wav, B, L, T, nullptr, nullptr, cosb, sinb, 0, h->cfg.hop, 1e-8f, s);
   RunCtx ctx{s, {const_cast<float*>(sp)}, h->d_flags, &h->prof};
   plan->run(ctx);
   launch_istft(h->fe, reinterpret_cast<float*>(base + off_re), reinterpret_cast<float*>(base + off_im), B, T, L,
-               h->cfg.hop, env, reinterpret_cast<float*>(base + off_frames), wav_out, s);
+               h->cfg.hop, reinterpret_cast<float*>(base + off_frames), wav_out, s);
   VFX_API_END
 }
 
@@ -1033,7 +1035,7 @@ int vfx_vocoder(vfx_handle* h, const float* mel_linear, int B, int T, float* wav
   return 0;
 }
 static int vfx_vocoder_1(vfx_handle* h, const float* mel_linear, int B, int T, float* wav_out, void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && mel_linear && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->voc, "vfx_vocoder: vocoder weights are not finalized");
   auto plan = get_plan(h, key_of("vocoder", B, T), [&](PlanBuilder& pb) { build_vocoder(pb, B, T, ext(0), ext(1)); });
@@ -1059,7 +1061,7 @@ int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_ou
 }
 static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, float* wav_out, float* logmel_out, int flags,
                              void* stream) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h && wav && wav_out && B > 0, "bad argument");
   VFX_CHECK(L > h->cfg.n_fft / 2, "vfx_restore_gsr: clip too short for reflect padding (L=%d)", L);
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL] && h->voc, "vfx_restore_gsr: weights are not finalized");
@@ -1075,7 +1077,7 @@ static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, floa
     // pre(): STFT -> magnitude -> mel (eval_gsr_voicefixer.py:19-25)
     pl->ops.push_back([=](const RunCtx& c) {
       launch_stft_mel(hh->fe, c.ext[0], B, L, T, reinterpret_cast<float*>(pl->bound_base + o_mel), nullptr, nullptr,
-                      nullptr, 0, hh->cfg.hop, c.stream);
+                      nullptr, 0, hh->cfg.hop, 1e-8f, c.stream);
     });
     build_unet_mel(pb, B, T, arena_buf(o_mel), arena_buf(o_log));
     pl->ops.push_back([=](const RunCtx& c) {
@@ -1103,7 +1105,7 @@ static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, floa
 // stream the kernels are launched on.
 // ---------------------------------------------------------------------------------------------
 int vfx_profile_begin(vfx_handle* h) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h, "NULL handle");
   h->prof.enabled = true;
   h->prof.events.clear();
@@ -1115,7 +1117,7 @@ int vfx_profile_begin(vfx_handle* h) {
 // Synchronises, then returns: number of launches, sum of their durations (ms) and of their
 // algorithmic FLOPs (2 * M * Cout * K).  Any out pointer may be NULL.
 int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* total_flops) {
-  VFX_API_BEGIN
+  VFX_API_BEGIN_H(h)
   VFX_CHECK(h, "NULL handle");
   VFX_HIP(hipDeviceSynchronize());
   double ms = 0, fl = 0;

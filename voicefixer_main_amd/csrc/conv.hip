@@ -457,11 +457,10 @@ static size_t conv_lds_bytes(int BN, bool hi) {
 template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false>
 static void launch_one(int grid, hipStream_t stream, const TapConvParams* dparams) {
   const size_t lds = conv_lds_bytes(BN, HI);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static uint64_t attr_devices = 0;  // one static per instantiation
+  if (first_use_on_current_device(attr_devices)) {
     VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI>), dim3(grid), dim3(256), lds, stream, dparams);
 }

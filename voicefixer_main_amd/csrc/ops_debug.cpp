@@ -41,7 +41,7 @@ extern "C" int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, i
   try {
     VFX_CHECK(h && x && weight && y, "NULL argument");
     VFX_CHECK(kh * kw <= kMaxTaps, "vfx_op_conv: at most %d taps", kMaxTaps);
-    VFX_HIP(hipSetDevice(h->device));
+    DeviceGuard device_guard_(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scratch sc;
     std::vector<std::pair<int, int>> taps;
@@ -85,7 +85,7 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
   try {
     VFX_CHECK(h && x && w1 && b1 && w2 && b2 && y, "NULL argument");
     VFX_CHECK(C % kKC == 0 && B > 0 && T > 0 && dil >= 1, "vfx_op_resblock: bad shape");
-    VFX_HIP(hipSetDevice(h->device));
+    DeviceGuard device_guard_(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scratch sc;
     const bool split = h->cfg.precision != 0;
@@ -152,7 +152,7 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
                                      void* stream) {
   try {
     VFX_CHECK(h && x && weight && y, "NULL argument");
-    VFX_HIP(hipSetDevice(h->device));
+    DeviceGuard device_guard_(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scratch sc;
     const float* dbias = bias ? sc.blob.upload(bias, Cout) : nullptr;

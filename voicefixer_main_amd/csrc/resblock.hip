@@ -362,11 +362,10 @@ static size_t resblock_lds_bytes(int C) {
 template <int C, int NW, bool HI>
 static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
   const size_t lds = resblock_lds_bytes(C);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static uint64_t attr_devices = 0;  // one static per instantiation
+  if (first_use_on_current_device(attr_devices)) {
     VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_resblock<C, NW, HI>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
 }

@@ -14,8 +14,8 @@
 //
 // Inverse (vfx_istft): one workgroup per frame: Hermitian spectrum -> packed 1024-point complex
 //   inverse FFT -> x synthesis window -> frame buffer; a second kernel gathers the <=5
-//   overlapping frames per output sample, divides by the window sum-of-squares envelope and
-//   strips the centre padding (torchlibrosa ISTFT semantics, see oracle/dsp.py).
+//   overlapping frames per output sample, divides by the window sum-of-squares envelope (summed in
+//   the same loop) and strips the leading centre padding (torchlibrosa ISTFT semantics, oracle/dsp.py).
 #include "vfx_internal.h"
 
 namespace vfx {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(const float* __restrict__ wav,
                                                    const int* __restrict__ fb_start,
                                                    const int* __restrict__ fb_off, float* __restrict__ mel,
                                                    float* __restrict__ sp, float* __restrict__ cosp,
-                                                   float* __restrict__ sinp, int log10_mel, int hop) {
+                                                   float* __restrict__ sinp, int log10_mel, int hop, float eps) {
   __shared__ float2 z[NC];
   __shared__ float mag_s[NBINS + 3];
   const int frame = blockIdx.x;       // b * T + t
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(const float* __restrict__ wav,
     const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
     const float2 wo = cmul(rtw[k], o);
     const float re = e.x + wo.x, im = e.y + wo.y;
-    const float mag = sqrtf(fmaxf(re * re + im * im, 1e-8f));
+    const float mag = sqrtf(fmaxf(re * re + im * im, eps));  // clamp on the POWER (fDomainHelper.py:62)
     mag_s[k] = mag;
     if (sp) sp[row + k] = mag;
     if (cosp) cosp[row + k] = re / mag;
@@ -189,34 +189,40 @@ __global__ __launch_bounds__(256) void k_istft_frames(const float* __restrict__ 
   }
 }
 
-// Overlap-add gather: wav[b, n] = (sum_t frames[b, t, n + 1024 - t*hop]) * inv_env[n + 1024], n < min(L, (T-1)*hop); 0 beyond.
-__global__ __launch_bounds__(256) void k_istft_ola(const float* __restrict__ frames, const float* __restrict__ inv_env,
+// Overlap-add gather: wav[b, n] = (sum_t frames[b, t, p - t*hop]) / (sum_t window[p - t*hop]^2), p = n + 1024, for every
+// n < L inside the overlap-add buffer (p < 2048 + hop*(T-1)); 0 beyond it.  This is torchlibrosa's
+// `y[:, n_fft//2 : n_fft//2 + length]` (same in the in-repo twin tools/dsp/base.py:193-200, `end = start + length`):
+// the L mod hop samples past hop*(T-1) are reconstructed from the tails of the last frames.  The window sum-of-squares
+// envelope (librosa.filters.window_sumsquare) is summed over the same <= 5 frames instead of being read from a
+// per-T table; positions whose envelope is tiny are left undivided.
+__global__ __launch_bounds__(256) void k_istft_ola(const float* __restrict__ frames, const float* __restrict__ window,
                                                     int T, int L, int hop, float* __restrict__ wav) {
   const int b = blockIdx.y;
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= L) return;
   const int p = n + NFFT / 2;                // position in the un-trimmed OLA buffer
-  float acc = 0.f;
-  if (n < (T - 1) * hop) {
-    int t_hi = p / hop;                      // last frame starting at or before p
-    if (t_hi > T - 1) t_hi = T - 1;
-    int t_lo = (p - NFFT + hop) / hop;       // first frame with t*hop + 2048 > p
-    if (t_lo < 0) t_lo = 0;
-    const float* fr = frames + (int64_t)b * T * NFFT;
-    for (int t = t_lo; t <= t_hi; ++t) {
-      const int o = p - t * hop;
-      if (o >= 0 && o < NFFT) acc += fr[(int64_t)t * NFFT + o];
+  float acc = 0.f, env = 0.f;
+  int t_hi = p / hop;                        // last frame starting at or before p
+  if (t_hi > T - 1) t_hi = T - 1;
+  int t_lo = (p - NFFT + hop) / hop;         // first frame with t*hop + 2048 > p
+  if (t_lo < 0) t_lo = 0;
+  const float* fr = frames + (int64_t)b * T * NFFT;
+  for (int t = t_lo; t <= t_hi; ++t) {
+    const int o = p - t * hop;
+    if (o >= 0 && o < NFFT) {
+      acc += fr[(int64_t)t * NFFT + o];
+      const float w = window[o];
+      env = fmaf(w, w, env);
     }
-    acc *= inv_env[p];
   }
-  wav[(int64_t)b * L + n] = acc;
+  wav[(int64_t)b * L + n] = env > 1.1754944e-38f ? acc / env : acc;
 }
 
 void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, int T, float* mel, float* sp,
-                     float* cosp, float* sinp, int log10_mel, int hop, hipStream_t stream) {
+                     float* cosp, float* sinp, int log10_mel, int hop, float eps, hipStream_t stream) {
   hipLaunchKernelGGL(k_stft_mel, dim3(B * T), dim3(256), 0, stream, wav, L, T, t.window,
                      reinterpret_cast<const float2*>(t.twiddle), reinterpret_cast<const float2*>(t.rtwiddle),
-                     t.fb_val, t.fb_start, t.fb_off, mel, sp, cosp, sinp, log10_mel, hop);
+                     t.fb_val, t.fb_start, t.fb_off, mel, sp, cosp, sinp, log10_mel, hop, eps);
   VFX_HIP(hipGetLastError());
 }
 
@@ -227,11 +233,11 @@ void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, 
 }
 
 void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop,
-                  const float* inv_env, float* frames_ws, float* wav, hipStream_t stream) {
+                  float* frames_ws, float* wav, hipStream_t stream) {
   hipLaunchKernelGGL(k_istft_frames, dim3(B * T), dim3(256), 0, stream, re, im, t.window,
                      reinterpret_cast<const float2*>(t.twiddle), reinterpret_cast<const float2*>(t.rtwiddle),
                      frames_ws);
-  hipLaunchKernelGGL(k_istft_ola, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames_ws, inv_env, T, L, hop, wav);
+  hipLaunchKernelGGL(k_istft_ola, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames_ws, t.window, T, L, hop, wav);
   VFX_HIP(hipGetLastError());
 }
 

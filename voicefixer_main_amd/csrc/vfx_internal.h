@@ -39,6 +39,32 @@ struct Error {};  // thrown after set_error(); caught at the C boundary
     }                                \
   } while (0)
 
+// Every entry point that takes a handle works on the handle's device whatever the caller's current device is, and
+// leaves the caller's current device as it found it (two handles on two GPUs in one process, torch.cuda.set_device
+// elsewhere).
+struct DeviceGuard {
+  int prev = -1, dev = -1;
+  explicit DeviceGuard(int device) : dev(device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) VFX_HIP(hipSetDevice(dev));
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: done once per (kernel, device).
+inline bool first_use_on_current_device(uint64_t& mask) {
+  int dev = 0;
+  VFX_HIP(hipGetDevice(&dev));
+  const uint64_t bit = uint64_t(1) << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage-driven tap-convolution (implicit GEMM on the MFMA) -- see conv.hip
 // ---------------------------------------------------------------------------------------------
@@ -46,7 +72,9 @@ constexpr int kMaxTaps = 9;
 constexpr int kMaxSegs = 3;
 constexpr int kKC = 32;             // input channels per K step
 constexpr int kIdentityLen = 4096;  // length of the identity scale/shift tables
-constexpr int kPatchMaxRows = 192;  // patch pixels per stage (6 row groups of 32)
+constexpr int kPatchMaxRows = 192;
+constexpr size_t kMaxCachedPlans = 8;  // per handle: a plan owns host + device parameter blocks (the eval handler's last
+                                        // segment has a new length for every file)  // patch pixels per stage (6 row groups of 32)
 
 enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_ELU = 2 };
 
@@ -175,16 +203,14 @@ struct FrontEndTables {
   float* fb_val = nullptr;    // packed non-zeros of the mel filterbank, band-major
   int* fb_start = nullptr;    // [128] first frequency bin of band m
   int* fb_off = nullptr;      // [129] offsets into fb_val
-  float* inv_env = nullptr;   // ISTFT 1/window-sumsquare envelope for inv_env_T frames
-  int inv_env_T = 0;
   float* voc_inv_weight = nullptr;  // [128] 1 / mel band weight
 };
 
 void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, int T, float* mel, float* sp,
-                     float* cosp, float* sinp, int log10_mel, int hop, hipStream_t stream);
+                     float* cosp, float* sinp, int log10_mel, int hop, float eps, hipStream_t stream);
 void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, float* mel, hipStream_t stream);
 void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop,
-                  const float* inv_env, float* frames_ws, float* wav, hipStream_t stream);
+                  float* frames_ws, float* wav, hipStream_t stream);
 
 void launch_prep_logmel(const float* mel_linear, int B, int T, int Tpad, float* x, int* flags, hipStream_t s);
 void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s);
@@ -267,6 +293,7 @@ struct Plan {
   double conv_flops = 0;
   int n_conv = 0;
   std::map<std::string, size_t> named;  // named arena offsets (bytes) of stage-level buffers
+  uint64_t last_use = 0;                // handle tick of the last call (LRU eviction, get_plan)
   void run(const RunCtx& ctx);  // api.cpp (debug hooks: VFX_POISON_ARENA=2, VFX_DEBUG_NAN)
 };
 
@@ -352,7 +379,8 @@ struct vfx_handle {
   vfx::DeviceBlob blob;  // front-end tables + weights
   std::shared_ptr<vfx::UNetWeights> unet[2];
   std::shared_ptr<vfx::VocoderWeights> voc;
-  std::map<std::string, std::shared_ptr<vfx::Plan>> plans;
+  std::map<std::string, std::shared_ptr<vfx::Plan>> plans;  // at most kMaxCachedPlans, least recently used evicted
+  uint64_t plan_tick = 0;
   char* arena = nullptr;
   size_t arena_bytes = 0;
   int* d_flags = nullptr;
@@ -364,7 +392,6 @@ struct vfx_handle {
 namespace vfx {
 void init_front_end(vfx_handle* h);
 void set_mel_filterbank(vfx_handle* h, const float* fb /*1025x128*/);
-const float* istft_envelope(vfx_handle* h, int T);
 void bind_plan(vfx_handle* h, Plan& plan);  // ensures the arena is large enough and rebases the plan on it
 std::shared_ptr<UNetWeights> build_unet_weights(vfx_handle* h, int model);
 std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h);

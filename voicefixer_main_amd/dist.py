@@ -8,8 +8,27 @@ and collects the results with grouped point-to-point sends: over xGMI rank 0 has
 to each of its 7 peers, so a grouped isend/irecv drives all links concurrently (RCCL has no
 native scatter).  Works with the `nccl` (= RCCL) backend on GPUs and `gloo` on CPU (tests).
 """
+import time
+
 import torch
 import torch.distributed as dist
+
+
+def world_rank():
+    """(world, rank); a process that never initialised torch.distributed is a world of one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def live_ranks(device):
+    """Number of ranks that actually take part in collectives: an all-reduce of ones (1 without a process group)."""
+    world, _ = world_rank()
+    if world == 1:
+        return 1
+    t = torch.ones(1, device=device, dtype=torch.int32)
+    dist.all_reduce(t)
+    return int(t.item())
 
 
 def shard_bounds(n, world):
@@ -25,7 +44,7 @@ def shard_bounds(n, world):
 
 def scatter_clips(full, n, length, device, src=0, dtype=torch.float32):
     """`full` (n, length) on rank `src` (ignored elsewhere) -> this rank's shard (n_r, length)."""
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = world_rank()
     bounds = shard_bounds(n, world)
     lo, hi = bounds[rank]
     if rank == src:
@@ -42,7 +61,7 @@ def scatter_clips(full, n, length, device, src=0, dtype=torch.float32):
 
 def gather_clips(shard, n, length, device, dst=0):
     """Inverse of scatter_clips: returns (n, length) on rank `dst`, None elsewhere."""
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = world_rank()
     bounds = shard_bounds(n, world)
     if rank == dst:
         full = torch.empty((n, length), device=device, dtype=shard.dtype)
@@ -65,9 +84,29 @@ def restore_sharded(engine_fn, full, n, length, device, src=0):
     return gather_clips(out, n, length, device, src)
 
 
+def sharded_step(engine_fn, full, n, length, device, src=0, sync=None):
+    """One step of the sharded job (BASELINE.json configs[3]) with its three phases clocked: returns
+    (gathered (n, length) on `src` / None elsewhere, {"scatter_ms", "restore_ms", "gather_ms"}).
+    `sync()` makes the device work of a phase finish before its clock is read (torch.cuda.synchronize on GPUs;
+    nothing on CPU)."""
+    sync = sync or (lambda: None)
+    sync()
+    t0 = time.perf_counter()
+    mine = scatter_clips(full, n, length, device, src)
+    sync()
+    t1 = time.perf_counter()
+    out = engine_fn(mine) if mine.shape[0] > 0 else mine
+    sync()
+    t2 = time.perf_counter()
+    back = gather_clips(out, n, length, device, src)
+    sync()
+    t3 = time.perf_counter()
+    return back, {"scatter_ms": (t1 - t0) * 1e3, "restore_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3}
+
+
 def selfcheck(device, n=11, length=4096):
     """Round-trip a small tensor through scatter/gather; raises on mismatch."""
-    rank = dist.get_rank()
+    _, rank = world_rank()
     full = torch.arange(n * length, device=device, dtype=torch.float32).reshape(n, length) if rank == 0 else None
     back = restore_sharded(lambda x: x * 2.0, full, n, length, device)
     if rank == 0 and not torch.equal(back, full * 2.0):

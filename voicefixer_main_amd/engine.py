@@ -112,22 +112,32 @@ class Engine:
         return f.value
 
     # ------------------------------------------------------------------ stages
-    def stft(self, wav, want_mel=True, want_sp=False, want_phase=False, log10_mel=False):
-        """wav (B, L) -> dict with any of mel (B,T,128), sp / cos / sin (B,T,1025)."""
+    def stft(self, wav, want_mel=True, want_sp=False, want_phase=False, log10_mel=False, eps=1e-8):
+        """wav (B, L) -> dict with any of mel (B,T,128), sp / cos / sin (B,T,1025).  `eps` is the clamp on the power
+        (fDomainHelper.py:60-65); the fused mel output exists for the handlers' eps = 1e-8 only."""
         wav = _dev_f32(wav, self.device)
         B, L = wav.shape
         T = self.frames(L)
+        eps = float(eps)
+        if eps < 0.0:
+            raise ValueError("eps must be >= 0")
         out = {}
         if want_mel:
+            if eps != 1e-8:
+                raise ValueError("the fused mel output is defined for eps = 1e-8 (wav_to_spectrogram_phase) only")
             out["mel"] = torch.empty((B, T, N_MELS), device=self.device, dtype=torch.float32)
         if want_sp:
             out["sp"] = torch.empty((B, T, N_BINS), device=self.device, dtype=torch.float32)
         if want_phase:
             out["cos"] = torch.empty((B, T, N_BINS), device=self.device, dtype=torch.float32)
             out["sin"] = torch.empty((B, T, N_BINS), device=self.device, dtype=torch.float32)
-        _lib.check(self.lib.vfx_stft_mel(self.h, _ptr(wav), B, L, _ptr(out.get("mel")), _ptr(out.get("sp")),
-                                         _ptr(out.get("cos")), _ptr(out.get("sin")), int(log10_mel), self._stream()),
-                   "vfx_stft_mel")
+        if eps == 1e-8:
+            _lib.check(self.lib.vfx_stft_mel(self.h, _ptr(wav), B, L, _ptr(out.get("mel")), _ptr(out.get("sp")),
+                                             _ptr(out.get("cos")), _ptr(out.get("sin")), int(log10_mel), self._stream()),
+                       "vfx_stft_mel")
+        else:
+            _lib.check(self.lib.vfx_stft_phase(self.h, _ptr(wav), B, L, _ptr(out.get("sp")), _ptr(out.get("cos")),
+                                               _ptr(out.get("sin")), eps, self._stream()), "vfx_stft_phase")
         return out
 
     def mel_project(self, sp):

@@ -110,6 +110,28 @@ def sispec(est, target):
     return torch.sum(loss) / loss.size()[0]
 
 
+def ssim(est, target, win_size=7, data_range=2.0, k1=0.01, k2=0.03):
+    """evaluation_proc/metrics.py:97-106: per (batch, channel) `skimage.metrics.structural_similarity(est, target,
+    win_size=7)` -> (B, C, 1, 1).  skimage's defaults restated on the device: uniform 7x7 window, sample covariance
+    (normalised by N-1), K1 = 0.01, K2 = 0.03, the mean taken over the region whose window lies inside the image
+    (the (win_size-1)//2 border is cropped), and -- for floating-point images without an explicit data_range, which
+    is how the reference calls it -- data_range = 2 (the dtype range [-1, 1] of the skimage releases that accept that
+    call).  The reference moves both spectrograms to the host for this; here they stay on the device."""
+    x, y = est.double(), target.double()
+    B, C, H, W = x.shape
+    x, y = x.reshape(B * C, 1, H, W), y.reshape(B * C, 1, H, W)
+    box = lambda t: torch.nn.functional.avg_pool2d(t, win_size, stride=1)     # 'valid' box mean == uniform_filter, cropped
+    n = float(win_size * win_size)
+    cov_norm = n / (n - 1.0)
+    ux, uy = box(x), box(y)
+    vx = cov_norm * (box(x * x) - ux * ux)
+    vy = cov_norm * (box(y * y) - uy * uy)
+    vxy = cov_norm * (box(x * y) - ux * uy)
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    s_map = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+    return s_map.mean(dim=(1, 2, 3)).reshape(B, C, 1, 1)
+
+
 # ----------------------------------------------------------------------------------------
 # eval_gsr_voicefixer.py
 # ----------------------------------------------------------------------------------------
@@ -159,15 +181,19 @@ def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=Fals
             if meta.get("unify_energy", False):
                 denoised_mel, mel_noisy = amp_to_original_f(mel_sp_est=denoised_mel, mel_sp_target=mel_noisy)
             if target is not None:
+                # like the reference (eval_gsr_voicefixer.py:56-64) the estimate and the target segment must have the
+                # same number of frames: a shorter / longer target file raises instead of being trimmed silently
                 _, target_mel, _ = _pre(model, target[break_point - seg_length:break_point], device)
-                n = min(target_mel.shape[2], denoised_mel.shape[2])
-                est_lin, tgt_lin = denoised_mel[:, :, :n].contiguous(), target_mel[:, :, :n].contiguous()
-                m_lsd, m_lin = device_metrics(model.engine, est_lin, tgt_lin)
-                _, m_log = device_metrics(model.engine, out_model["mel"][:, :, :n].contiguous(), to_log(tgt_lin))
+                if target_mel.shape != denoised_mel.shape:
+                    raise RuntimeError("The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton "
+                                       "dimension 2" % (denoised_mel.shape[2], target_mel.shape[2]))
+                m_lsd, m_lin = device_metrics(model.engine, denoised_mel.contiguous(), target_mel.contiguous())
+                _, m_log = device_metrics(model.engine, out_model["mel"].contiguous(), to_log(target_mel))
                 # non-log SiSpec is defined on from_log(model output) (eval_gsr_voicefixer.py:62), i.e. before unify_energy
                 if meta.get("unify_energy", False):
-                    _, m_lin = device_metrics(model.engine, from_log(out_model["mel"][:, :, :n]).contiguous(), tgt_lin)
-                metrics = {"mel-lsd": m_lsd, "mel-sispec": m_log, "mel-non-log-sispec": m_lin}
+                    _, m_lin = device_metrics(model.engine, from_log(out_model["mel"]).contiguous(), target_mel.contiguous())
+                metrics = {"mel-lsd": m_lsd, "mel-sispec": m_log, "mel-non-log-sispec": m_lin,
+                           "mel-ssim": float(ssim(denoised_mel, target_mel))}
             out = model.vocoder(denoised_mel)
             if torch.max(torch.abs(out)) > 1.0:
                 out = out / torch.max(torch.abs(out))
@@ -201,11 +227,13 @@ def handler_ssr_unet(input, output, target, ckpt, device, needrefresh=False, met
                 sp_o, _, _ = model.f_helper.wav_to_spectrogram_phase(out)
                 mel_out = model.mel(sp_o.permute(0, 1, 3, 2)).permute(0, 1, 3, 2)
                 _, target_mel, _ = _pre(model, target[break_point - seg_length:break_point], device)
-                n = min(target_mel.shape[2], mel_out.shape[2])
-                est_lin, tgt_lin = mel_out[:, :, :n].contiguous(), target_mel[:, :, :n].contiguous()
-                m_lsd, m_lin = device_metrics(model.engine, est_lin, tgt_lin)
-                _, m_log = device_metrics(model.engine, to_log(est_lin), to_log(tgt_lin))
-                metrics = {"mel-lsd": m_lsd, "mel-sispec": m_log, "mel-non-log-sispec": m_lin}
+                if target_mel.shape != mel_out.shape:
+                    raise RuntimeError("The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton "
+                                       "dimension 2" % (mel_out.shape[2], target_mel.shape[2]))
+                m_lsd, m_lin = device_metrics(model.engine, mel_out.contiguous(), target_mel.contiguous())
+                _, m_log = device_metrics(model.engine, to_log(mel_out), to_log(target_mel))
+                metrics = {"mel-lsd": m_lsd, "mel-sispec": m_log, "mel-non-log-sispec": m_lin,
+                           "mel-ssim": float(ssim(mel_out, target_mel))}
             if torch.max(torch.abs(out)) > 1.0:
                 out = out / torch.max(torch.abs(out))
                 print("Warning: Exceed energy limit,", input)
