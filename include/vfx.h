@@ -213,6 +213,14 @@ int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H, int W, in
 int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int C, const float* w1, const float* b1,
                     const float* w2, const float* b2, int dil, float slope, int fused, float* y, void* stream);
 
+/* One fused 2-D ConvBlockRes of the ResUNets (models/components/modules.py:223-271; Cin == Cout = C in {32, 64},
+ * identity shortcut): y = x + conv2(lrelu(bn2(conv1(lrelu(bn1(x)))))) with 3x3 convolutions in ONE launch (h stays
+ * in LDS).  x, y (B, H, W, C) on the device; w1, w2 (C, C, 3, 3) and the folded eval-mode BatchNorm affines
+ * sc1, sh1, sc2, sh2 [C] on the HOST.  precision 1 only. */
+int vfx_op_block2d(vfx_handle* h, const float* x, int B, int H, int W, int C, const float* w1,
+                   const float* sc1, const float* sh1, const float* w2, const float* sc2,
+                   const float* sh2, float slope, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

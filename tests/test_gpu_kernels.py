@@ -193,3 +193,23 @@ def test_mel_project(engine):
     ref = dsp.mel_project(sp.astype(np.float64), dsp.mel_filterbank().astype(np.float64))
     got = engine.mel_project(torch.from_numpy(sp)).cpu().numpy()
     assert np.abs(got - ref).max() < 1e-5 * ref.max()
+
+
+@pytest.mark.parametrize("C,H,W", [(32, 40, 127), (64, 33, 63), (32, 7, 5), (64, 130, 20)])
+def test_fused_conv_block_res(engine, C, H, W):
+    """One ConvBlockRes with identity shortcut as ONE launch (k_resblock, 2-D mode): bn1 -> lrelu -> 3x3 -> bn2 -> lrelu ->
+    3x3 -> + x, against the same block in float64 torch; tiles that overhang every image border."""
+    if engine.tol['name'] != 'split-bf16':
+        pytest.skip("the fused block exists for split-bf16 only")
+    B = 2
+    x = _rand((B, C, H, W), 41)
+    w1, w2 = _rand((C, C, 3, 3), 42, 0.06), _rand((C, C, 3, 3), 43, 0.06)
+    g = torch.Generator().manual_seed(44)
+    sc1, sc2 = torch.rand(C, generator=g) + 0.5, torch.rand(C, generator=g) + 0.5
+    sh1, sh2 = _rand((C,), 45, 0.2), _rand((C,), 46, 0.2)
+    aff = lambda t, sc, sh: t * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    h = F.conv2d(F.leaky_relu(aff(x.double(), sc1, sh1), 0.01), w1.double(), padding=1)
+    ref = F.conv2d(F.leaky_relu(aff(h, sc2, sh2), 0.01), w2.double(), padding=1) + x.double()
+    y = engine.op_block2d(_nhwc(x), w1.numpy(), sc1.numpy(), sh1.numpy(), w2.numpy(), sc2.numpy(), sh2.numpy(), 0.01)
+    err = (_nchw(y.cpu()).double() - ref).abs().max().item()
+    assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), err

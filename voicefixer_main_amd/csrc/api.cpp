@@ -466,7 +466,8 @@ void PlanBuilder::add_conv_phased(TapConvParams p, const std::vector<TapSeg>& ph
 }
 
 void PlanBuilder::add_resblock(ResBlockParams p) {
-  plan_resblock(p);
+  if (p.geo2d) plan_block2d(p);
+  else plan_resblock(p);
   const size_t idx = plan->host_rb.size();
   plan->host_rb.push_back(p);
   plan->conv_flops += resblock_flops(p);
@@ -1133,7 +1134,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       for (int s2 = 0; s2 < d.nseg; ++s2) K += d.seg[s2].ntaps * d.seg[s2].C;
       char kname[64];
       if (d.nseg == 0) {  // fused ResStack layer
-        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.Cout == 64 ? 4 : 8, d.hionly ? " f16" : "");
+        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.Cout == 128 ? 8 : 4, d.hionly ? " f16" : "");
       } else {
         bool elu = false;
         for (int s2 = 0; s2 < d.nseg; ++s2) elu = elu || d.seg[s2].act == ACT_ELU;

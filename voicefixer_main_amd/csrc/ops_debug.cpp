@@ -146,6 +146,46 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
   return 0;
 }
 
+// One fused 2-D ConvBlockRes (Cin == Cout = C in {32, 64}, identity shortcut; resblock.hip, G2 mode):
+//   y = x + conv2(lrelu(bn2(conv1(lrelu(bn1(x))))));  x, y (B, H, W, C) on the device; w1, w2 in PyTorch layout (C, C, 3, 3)
+//   and the folded BatchNorm affines sc*/sh* [C] on the HOST.
+extern "C" int vfx_op_block2d(vfx_handle* h, const float* x, int B, int H, int W, int C, const float* w1, const float* sc1,
+                              const float* sh1, const float* w2, const float* sc2, const float* sh2, float slope, float* y,
+                              void* stream) {
+  try {
+  VFX_CHECK(h && x && y && w1 && w2 && sc1 && sh1 && sc2 && sh2 && B > 0 && H > 0 && W > 0, "bad argument");
+  VFX_HIP(hipSetDevice(h->device));
+  VFX_CHECK(h->cfg.precision == 1 && block2d_supported(C), "vfx_op_block2d: needs precision 1 and C = 32 or 64");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Scratch sc;
+  std::vector<std::pair<int, int>> taps;
+  for (int kh = 0; kh < 3; ++kh)
+    for (int kw = 0; kw < 3; ++kw) taps.push_back({kh, kw});
+  ResBlockParams rp{};
+  rp.x = x;
+  rp.y = y;
+  rp.w1 = sc.blob.upload(pack_conv(w1, C, C, 3, 3, 0, C, taps, 1));
+  rp.w2 = sc.blob.upload(pack_conv(w2, C, C, 3, 3, 0, C, taps, 1));
+  rp.sc1 = sc.blob.upload(sc1, C);
+  rp.sh1 = sc.blob.upload(sh1, C);
+  rp.sc2 = sc.blob.upload(sc2, C);
+  rp.sh2 = sc.blob.upload(sh2, C);
+  rp.slope = slope;
+  rp.B = B;
+  rp.H = H;
+  rp.W = W;
+  rp.C = C;
+  plan_block2d(rp);
+  ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
+  VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
+  launch_resblock(rp, d, s);
+  VFX_HIP(hipStreamSynchronize(s));
+  } catch (const vfx::Error&) {
+    return 1;
+  }
+  return 0;
+}
+
 extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H, int W, int Cin, const float* weight,
                                      int Cout, int kh, int kw, int stride, int prune_w, const float* scale,
                                      const float* shift, int act, float slope, const float* bias, float* y,

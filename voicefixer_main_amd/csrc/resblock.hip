@@ -45,8 +45,12 @@ __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
 // NW waves per block: 4 (C = 64) or 8 (C = 128: h needs all 128 couts of conv1 in one block).
 // Waves per SIMD the register budget is cut for: C = 64 (4-wave blocks, 48 KB of LDS): three blocks per CU;
 // C = 128 (8-wave blocks, 68 KB): two blocks per CU in the 16-bit mode (116 VGPRs), one in split mode (140).
-template <int C, int NW, bool HI>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resblock(const ResBlockParams* __restrict__ pp) {
+// G2 = true: the same machinery as a fused 2-D ConvBlockRes of the ResUNets (models/components/modules.py:223-271,
+// Cin == Cout, identity shortcut):  y = x + conv2(lrelu(bn2(conv1(lrelu(bn1(x))))))  with 3x3 convolutions.  Tile = h grid
+// of TH x W1 = 128 pixels (8 x 16 or 16 x 8), outputs = its interior, x patch = (TH + 2) x (W1 + 2) = 180 pixels.
+template <int C, int NW, bool HI, bool G2 = false>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)) void k_resblock(const ResBlockParams* __restrict__ pp) {
+  constexpr int KT = G2 ? 9 : 3;  // taps per convolution
   constexpr int WL = HI ? 2 : 4;  // weight loads per tap and wave (HI: fp16 operands, hi fragments only)
   constexpr int NTHR = NW * 64;
   constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
   constexpr int RING = WM >= 4 ? 2 : 3, AHEAD = RING - 1;
   constexpr int HROW = C * 4;         // bytes per h row
   constexpr int H_OFF = 0;            // h overlays the patch buffers (dead once conv1 is done): less LDS, more blocks per CU
-  constexpr int NT1 = 3 * NCH;        // taps of conv1 (chunk-major); conv2 has as many
+  constexpr int NT1 = KT * NCH;       // taps of conv1 (chunk-major); conv2 has as many
   constexpr int LDO = C + 4;          // staged output row (floats)
   constexpr int OTAB_OFF = CBM * LDO * 4;
 
@@ -77,9 +81,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
   const int img = tile / (p.tiles_w * p.tiles_h);
   const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
   const int rowstride = p.fold ? d : 0;
-  const int j0 = tj * p.TWo;  // first output column (folded) / position (1-D) of the tile
+  const int j0 = tj * p.TWo;  // first output column (folded, 2-D) / position (1-D) of the tile
   const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
   const int base_x = base_h - d;                                // position of x patch pixel (0, 0)
+  const int Hh = p.H, Ww = p.W;      // 2-D mode: image extent
+  const int i0 = ti * (TH - 2);      // 2-D mode: first output row of the tile
   const float slope = p.slope;
 
   const int lr = tid >> 3, cg = tid & 7;
@@ -97,10 +103,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
   for (int q = 0; q < NG; ++q) {
     const int prow = lr + RG * q;
     const int pi = prow / PW, pj = prow - pi * PW;
-    const int pos = base_x + pi * rowstride + pj;
-    const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
-    voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 4);
-    okmask |= ok ? (1u << q) : 0u;
+    if constexpr (G2) {  // patch pixel (pi, pj) = image pixel (i0 - 2 + pi, j0 - 2 + pj)
+      const int r = i0 - 2 + pi, c = j0 - 2 + pj;
+      const bool ok = (prow < P) & ((unsigned)r < (unsigned)Hh) & ((unsigned)c < (unsigned)Ww);
+      voff[q] = (unsigned)((img * Hh + r) * Ww + c) * (unsigned)(C * 4);
+      okmask |= ok ? (1u << q) : 0u;
+    } else {
+      const int pos = base_x + pi * rowstride + pj;
+      const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
+      voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 4);
+      okmask |= ok ? (1u << q) : 0u;
+    }
   }
   int arow1[WM], arow2[WM];  // A row of this lane's h pixel: in the x patch (tap offset added) / in the h buffer
   bool hval[WM];             // that h pixel lies inside the tile's h grid and inside the sequence
@@ -110,14 +123,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
     const int li = ml / W1, lj = ml - li * W1;
     arow1[a] = li < TH ? li * PW + lj : 0;
     arow2[a] = ml;
-    const int pos = base_h + li * rowstride + lj;
-    hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
+    if constexpr (G2) {  // h pixel (li, lj) = image pixel (i0 - 1 + li, j0 - 1 + lj)
+      hval[a] = (li < TH) & ((unsigned)(i0 - 1 + li) < (unsigned)Hh) & ((unsigned)(j0 - 1 + lj) < (unsigned)Ww);
+    } else {
+      const int pos = base_h + li * rowstride + lj;
+      hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
+    }
   }
   const unsigned nb_off = (unsigned)(wn * 1024 + lane * 4) * 4u;
   const int64_t ts = (int64_t)C * kKC;  // floats per tap of a weight tensor
-  f32x4 b1v[4];  // bias of conv1 for this lane's accumulator channels: runs wn*32 + 8j + 4lh .. +3
+  f32x4 b1v[4];  // bias of conv1 for this lane's accumulator channels: runs wn*32 + 8j + 4lh .. +3 (2-D mode: none)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) b1v[j] = *(const VFX_GLOBAL f32x4*)(p.b1 + wn * 32 + 8 * j + 4 * lh);
+  for (int j = 0; j < 4; ++j)
+    b1v[j] = G2 ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const VFX_GLOBAL f32x4*)(p.b1 + wn * 32 + 8 * j + 4 * lh);
 
   f32x16 acc[WM];
 #pragma unroll
@@ -128,7 +146,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
   // ---- x patch: LDS-DMA request and in-place transform (cf. conv.hip) -------------------------------------
   auto issue_patch = [&](int c, int dst) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + c * kKC), 0, (int)(unsigned)((int64_t)p.B * T * C * 4 - (int64_t)c * kKC * 4), 0x00020000);
+        const_cast<float*>(p.x + c * kKC), 0,
+        (int)(unsigned)((int64_t)p.B * (G2 ? (int64_t)Hh * Ww : (int64_t)T) * C * 4 - (int64_t)c * kKC * 4), 0x00020000);
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       const unsigned o = (okmask & (1u << q)) ? voff[q] + 16u * cg : 0xfffffff0u;
@@ -137,8 +156,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
     }
   };
   const int nq = (P + RG - 1) / RG;
-  auto transform_patch = [&](int dst) __attribute__((always_inline)) {
+  auto transform_patch = [&](int dst, int c) __attribute__((always_inline)) {
     char* row0 = lds + dst + lr * CROW;
+    f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};  // 2-D mode: bn1 of this thread's 4 channels
+    if constexpr (G2) {
+      psc = *(const VFX_GLOBAL f32x4*)(p.sc1 + c * kKC + 4 * cg);
+      psh = *(const VFX_GLOBAL f32x4*)(p.sh1 + c * kKC + 4 * cg);
+    }
     f32x4 raw[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q)
@@ -148,7 +172,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
       if (q * RG < 128 || q < nq) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[q][e], raw[q][e] * slope);  // LeakyReLU(0) = 0: DMA zero fill stays zero
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (G2) {  // affine first, so the zero fill of the DMA is not zero any more: mask after the activation
+            const float t = raw[q][e] * psc[e] + psh[e];
+            v[e] = (okmask & (1u << q)) ? fmaxf(t, t * slope) : 0.f;
+          } else {
+            v[e] = fmaxf(raw[q][e], raw[q][e] * slope);  // LeakyReLU(0) = 0: DMA zero fill stays zero
+          }
+        }
         if constexpr (HI) {  // fp16 in the hi half only
           *reinterpret_cast<uint2*>(row0 + RG * q * CROW + (((cg >> 1) ^ key_l) << 4) + 8 * (cg & 1)) =
               make_uint2(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]));
@@ -239,25 +270,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
   for (int g = 0; g < AHEAD; ++g) fetch(g);
   issue_patch(0, 0);
   drain();
-  transform_patch(0);
+  transform_patch(0, 0);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const bool has_dma = c + 1 < NCH;
     __syncthreads();  // patch c is visible; the other buffer is free
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int g = 3 * c + k;
+    for (int k = 0; k < KT; ++k) {
+      const int g = KT * c + k;
       fetch(g + AHEAD);
-      if (k == 2 - AHEAD && has_dma) issue_patch(c + 1, ((c + 1) & 1) * CPATCH);
-      if (k >= AHEAD) wait_b_dyn<NG, WL, HI>(ring(g), WL * AHEAD + (has_dma ? NG : 0));
+      // the next chunk's patch is requested right after the fetch of this chunk's LAST tap, so every counted wait
+      // below is for a fetch issued before it
+      if (k == KT - 1 - AHEAD && has_dma) issue_patch(c + 1, ((c + 1) & 1) * CPATCH);
+      if (k >= AHEAD) wait_b_dyn<NG, WL, HI>(ring(g), WL * AHEAD + ((has_dma && k >= KT - 1 - AHEAD) ? NG : 0));
       int rows[WM];
 #pragma unroll
-      for (int a = 0; a < WM; ++a) rows[a] = arow1[a] + p.poff[k];
+      for (int a = 0; a < WM; ++a) rows[a] = arow1[a] + (G2 ? p.poff9[k] : p.poff[k]);
       mma(ring(g), lds + (c & 1) * CPATCH, CROW, rows);
       __builtin_amdgcn_sched_barrier(0);
     }
     drain();
-    if (has_dma) transform_patch(((c + 1) & 1) * CPATCH);
+    if (has_dma) transform_patch(((c + 1) & 1) * CPATCH, c + 1);
   }
 
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
@@ -273,9 +306,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 u;
+      f32x4 hsc = {1.f, 1.f, 1.f, 1.f};  // 2-D mode: bn2 of the run's 4 channels (b1v carries the shift)
+      if constexpr (G2) {
+        hsc = *(const VFX_GLOBAL f32x4*)(p.sc2 + wn * 32 + 8 * j + 4 * lh);
+        b1v[j] = *(const VFX_GLOBAL f32x4*)(p.sh2 + wn * 32 + 8 * j + 4 * lh);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float t = acc[a][4 * j + e] + b1v[j][e];
+        const float t = acc[a][4 * j + e] * hsc[e] + b1v[j][e];
         u[e] = hval[a] ? fmaxf(t, t * slope) : 0.f;
         acc[a][4 * j + e] = 0.f;
       }
@@ -299,14 +337,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int g = NT1 + 3 * c + k;
+    for (int k = 0; k < KT; ++k) {
+      const int g = NT1 + KT * c + k;
       fetch(g + AHEAD);
       if (g >= NT1 + AHEAD) wait_b_dyn<NG, WL, HI>(ring(g), WL * AHEAD);  // the first AHEAD taps landed with the last drain
       int rows[WM];
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
-        const int r = arow2[a] + k - 1;
+        const int r = arow2[a] + (G2 ? p.hoff9[k] : k - 1);
         rows[a] = r < 0 ? 0 : (r > CBM - 1 ? CBM - 1 : r);  // clamped rows only feed outputs that are masked anyway
       }
       mma(ring(g), lds + H_OFF + c * CROW, HROW, rows);
@@ -319,10 +357,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
   int* otab = reinterpret_cast<int*>(lds + OTAB_OFF);
   if (tid < CBM) {
     const int li = tid / W1, lj = tid - li * W1;
-    const int pos = base_h + li * rowstride + lj;
-    const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) &
-                    (!p.fold | (j0 + lj - 1 < d));
-    otab[tid] = ok ? img * T + pos : -1;
+    if constexpr (G2) {  // outputs = interior of the h grid, inside the image
+      const int r = i0 - 1 + li, c = j0 - 1 + lj;
+      const bool ok = (li >= 1) & (li <= TH - 2) & (lj >= 1) & (lj <= W1 - 2) & (r < Hh) & (c < Ww);
+      otab[tid] = ok ? (img * Hh + r) * Ww + c : -1;
+    } else {
+      const int pos = base_h + li * rowstride + lj;
+      const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) &
+                      (!p.fold | (j0 + lj - 1 < d));
+      otab[tid] = ok ? img * T + pos : -1;
+    }
   }
 #pragma unroll
   for (int a = 0; a < WM; ++a)
@@ -336,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
   {
     constexpr int V = C / 4, RPP = NTHR / V, NPASS = CBM / RPP;
     const int c4 = tid % V, r0 = tid / V;
-    const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
+    const f32x4 bv = G2 ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
     int opix[NPASS];
     f32x4 val[NPASS], res[NPASS];
 #pragma unroll
@@ -356,21 +400,56 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (HI ? 4 : 2)) void k_resbloc
 static size_t resblock_lds_bytes(int C) {
   const size_t h_end = (size_t)CBM * C * 4;                       // h overlays the patch buffers
   const size_t epi_end = (size_t)CBM * (C + 4) * 4 + CBM * 4;
-  return std::max(std::max(h_end, (size_t)2 * CPATCH), epi_end);
+  const size_t patches = (size_t)(C == 32 ? 1 : 2) * CPATCH;      // one chunk: one buffer
+  return std::max(std::max(h_end, patches), epi_end);
 }
 
-template <int C, int NW, bool HI>
+template <int C, int NW, bool HI, bool G2 = false>
 static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
   const size_t lds = resblock_lds_bytes(C);
   static uint64_t attr_devices = 0;  // one static per instantiation
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI, G2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   }
-  hipLaunchKernelGGL((k_resblock<C, NW, HI>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
+  hipLaunchKernelGGL((k_resblock<C, NW, HI, G2>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
 }
 
 bool resblock_supported(int C) { return C == 64 || C == 128; }
+bool block2d_supported(int C) { return C == 32 || C == 64; }
+
+// Tile geometry of a fused 2-D ConvBlockRes (B, H, W, C must be set): h grid TH x W1 = 128 pixels in the orientation that
+// wastes fewer pixels on the image borders, outputs = its interior, x patch = (TH + 2) x (W1 + 2).
+void plan_block2d(ResBlockParams& p) {
+  VFX_CHECK(block2d_supported(p.C), "block2d: C=%d is not supported", p.C);
+  double best = -1.0;
+  for (int W1 : {16, 8}) {
+    const int TH = 128 / W1, oh = TH - 2, ow = W1 - 2;
+    const double covered = (double)((p.H + oh - 1) / oh) * oh * ((p.W + ow - 1) / ow) * ow;
+    const double util = (double)p.H * p.W / covered;
+    if (util > best) {
+      best = util;
+      p.W1 = W1;
+      p.TH = TH;
+    }
+  }
+  p.geo2d = 1;
+  p.fold = 0;
+  p.dil = 1;
+  p.T = p.H * p.W;
+  p.TWo = p.W1 - 2;
+  p.PW = p.W1 + 2;
+  p.P = (p.TH + 2) * p.PW;
+  p.tiles_h = (p.H + p.TH - 3) / (p.TH - 2);
+  p.tiles_w = (p.W + p.TWo - 1) / p.TWo;
+  for (int dy = 0; dy < 3; ++dy)
+    for (int dx = 0; dx < 3; ++dx) {
+      p.poff9[dy * 3 + dx] = dy * p.PW + dx;                 // conv1: x patch rows of the tap, relative to the h pixel's row
+      p.hoff9[dy * 3 + dx] = (dy - 1) * p.W1 + (dx - 1);    // conv2: h rows
+    }
+  VFX_CHECK(p.P <= kPatchMaxRows && p.TH * p.W1 == CBM, "block2d: bad tile geometry");
+  VFX_CHECK((int64_t)p.B * p.H * p.W * p.C * 4 < ((int64_t)1 << 32) - 4096, "block2d: tensor exceeds 4 GiB");
+}
 
 // Fills the tile geometry of a fused ResStack layer (B, T, C, dil must be set).
 void plan_resblock(ResBlockParams& p) {
@@ -407,6 +486,13 @@ void plan_resblock(ResBlockParams& p) {
 void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock: bad grid");
+  if (hp.geo2d) {
+    VFX_CHECK(!hp.hionly, "block2d: split-bf16 only");
+    if (hp.C == 32) launch_rb<32, 4, false, true>((int)grid, stream, dparams);
+    else launch_rb<64, 4, false, true>((int)grid, stream, dparams);
+    VFX_HIP(hipGetLastError());
+    return;
+  }
   if (hp.C == 64) {
     if (hp.hionly) launch_rb<64, 4, true>((int)grid, stream, dparams);
     else launch_rb<64, 4, false>((int)grid, stream, dparams);
@@ -417,6 +503,8 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
   VFX_HIP(hipGetLastError());
 }
 
-double resblock_flops(const ResBlockParams& hp) { return 2.0 * 2.0 * (double)hp.B * hp.T * hp.C * (3.0 * hp.C); }
+double resblock_flops(const ResBlockParams& hp) {
+  return 2.0 * 2.0 * (double)hp.B * hp.T * hp.C * ((hp.geo2d ? 9.0 : 3.0) * hp.C);
+}
 
 }  // namespace vfx

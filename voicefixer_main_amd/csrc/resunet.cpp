@@ -210,6 +210,29 @@ struct TrunkBuilder {
   Act4 conv_block(const ConvBlockW& w, const Act4* srcs, int nsrc, const Act4* pre_h = nullptr,
                   const Act4* pre_sc = nullptr) {
     const Act4& g = srcs ? srcs[0] : *pre_h;
+    // EXPERIMENTAL (VFX_FUSE_UNET=1, not yet verified on hardware): identity-shortcut blocks of the C = 32 / 64 levels
+    // as ONE launch of k_resblock's 2-D mode -- h stays in LDS, 402 instead of 872 HBM bytes per output pixel.
+    static const bool fuse2d = getenv("VFX_FUSE_UNET") && atoi(getenv("VFX_FUSE_UNET")) != 0;
+    if (fuse2d && srcs && nsrc == 1 && !w.shortcut && !pre_h && block2d_supported(w.cout) && pb.h->cfg.precision != 0) {
+      Act4 y = make(g.H, g.W, w.cout);
+      ResBlockParams rp{};
+      rp.geo2d = 1;
+      rp.x = rel_ptr(srcs[0].off);
+      rp.y = const_cast<float*>(rel_ptr(y.off));
+      rp.w1 = w.w1[0];
+      rp.w2 = w.w2;
+      rp.sc1 = w.bn1_scale;
+      rp.sh1 = w.bn1_shift;
+      rp.sc2 = w.bn2_scale;
+      rp.sh2 = w.bn2_shift;
+      rp.slope = kSlope;
+      rp.B = B;
+      rp.H = g.H;
+      rp.W = g.W;
+      rp.C = w.cout;
+      pb.add_resblock(rp);
+      return y;
+    }
     Act4 hbuf;
     if (pre_h) {
       hbuf = *pre_h;

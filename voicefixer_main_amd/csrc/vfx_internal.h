@@ -177,9 +177,19 @@ struct ResBlockParams {
   int PW, P;        // x patch: PH x PW pixels, P <= kPatchMaxRows
   int poff[3];      // patch row offset of conv1's taps
   int hionly;       // fp16 operands in the hi halves only, cf. TapConvParams::hionly
+  // 2-D ConvBlockRes mode (plan_block2d): x, y are (B, H, W, C), both convolutions 3x3, folded BatchNorm affines
+  int geo2d, H, W;
+  const float* sc1;  // bn1 scale / shift [C]: prologue of conv1
+  const float* sh1;
+  const float* sc2;  // bn2 scale / shift [C]: prologue of conv2, applied to h
+  const float* sh2;
+  int poff9[9];      // conv1: patch row offset of tap (dy, dx)
+  int hoff9[9];      // conv2: h row offset of tap (dy, dx)
 };
 bool resblock_supported(int C);
+bool block2d_supported(int C);
 void plan_resblock(ResBlockParams& p);
+void plan_block2d(ResBlockParams& p);
 void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 double resblock_flops(const ResBlockParams& hp);
 

@@ -266,6 +266,19 @@ class Engine:
                                             int(bool(fused)), _ptr(y), self._stream()), "vfx_op_resblock")
         return y
 
+    def op_block2d(self, x, w1, sc1, sh1, w2, sc2, sh2, slope=0.01):
+        """One fused ConvBlockRes (identity shortcut) on x (B, H, W, C) channels-last; w1 / w2 (C, C, 3, 3) and the folded
+        BatchNorm affines (C) in torch layout on the host."""
+        x = _dev_f32(x, self.device)
+        B, H, W, C = x.shape
+        hp = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        w1, sc1, sh1, w2, sc2, sh2 = hp(w1), hp(sc1), hp(sh1), hp(w2), hp(sc2), hp(sh2)
+        cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        y = torch.empty_like(x)
+        _lib.check(self.lib.vfx_op_block2d(self.h, _ptr(x), B, H, W, C, cp(w1), cp(sc1), cp(sh1), cp(w2), cp(sc2), cp(sh2),
+                                           float(slope), _ptr(y), self._stream()), "vfx_op_block2d")
+        return y
+
     def op_conv_transpose(self, x, weight, stride, prune_w=False, scale=None, shift=None, act=0, slope=0.0, bias=None):
         x = _dev_f32(x, self.device)
         B, H, W, Cin = x.shape
