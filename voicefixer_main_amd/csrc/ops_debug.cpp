@@ -154,8 +154,8 @@ extern "C" int vfx_op_block2d(vfx_handle* h, const float* x, int B, int H, int W
                               void* stream) {
   try {
   VFX_CHECK(h && x && y && w1 && w2 && sc1 && sh1 && sc2 && sh2 && B > 0 && H > 0 && W > 0, "bad argument");
-  VFX_HIP(hipSetDevice(h->device));
-  VFX_CHECK(h->cfg.precision == 1 && block2d_supported(C), "vfx_op_block2d: needs precision 1 and C = 32 or 64");
+  DeviceGuard device_guard_(h->device);
+  VFX_CHECK(h->cfg.precision != 0 && block2d_supported(C), "vfx_op_block2d: needs a split-bf16 mode and C = 32 or 64");
   hipStream_t s = static_cast<hipStream_t>(stream);
   Scratch sc;
   std::vector<std::pair<int, int>> taps;

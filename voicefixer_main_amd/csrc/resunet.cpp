@@ -210,9 +210,9 @@ struct TrunkBuilder {
   Act4 conv_block(const ConvBlockW& w, const Act4* srcs, int nsrc, const Act4* pre_h = nullptr,
                   const Act4* pre_sc = nullptr) {
     const Act4& g = srcs ? srcs[0] : *pre_h;
-    // EXPERIMENTAL (VFX_FUSE_UNET=1, not yet verified on hardware): identity-shortcut blocks of the C = 32 / 64 levels
-    // as ONE launch of k_resblock's 2-D mode -- h stays in LDS, 402 instead of 872 HBM bytes per output pixel.
-    static const bool fuse2d = getenv("VFX_FUSE_UNET") && atoi(getenv("VFX_FUSE_UNET")) != 0;
+    // Identity-shortcut blocks of the C = 32 / 64 levels run as ONE launch of k_resblock's 2-D mode: h stays in LDS, 402
+    // instead of 872 HBM bytes per output pixel (VFX_FUSE_UNET=0: the two-launch form, for A/B runs).
+    static const bool fuse2d = !(getenv("VFX_FUSE_UNET") && atoi(getenv("VFX_FUSE_UNET")) == 0);
     if (fuse2d && srcs && nsrc == 1 && !w.shortcut && !pre_h && block2d_supported(w.cout) && pb.h->cfg.precision != 0) {
       Act4 y = make(g.H, g.W, w.cout);
       ResBlockParams rp{};
