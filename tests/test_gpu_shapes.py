@@ -44,7 +44,8 @@ def _ssr_oracle(n_clips, n_samples, seed):
     wav = synth.make_clips(n_clips, n_samples / 44100.0, seed=seed, mode="lowpass")
     assert wav.shape[-1] == n_samples
     # float64 oracle: two fp32 evaluations of this trunk (linear-magnitude input, 1024 bins) agree to ~58 dB only
-    return wav, pipeline.restore_ssr(synth.make_resunet_state_dict(2), wav, dtype=torch.float64)
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in synth.make_resunet_state_dict(2).items()}
+    return wav, pipeline.restore_ssr(sd, wav, dtype=torch.float64)
 
 
 def _check_gsr(engine, wav, ref, stages=True):

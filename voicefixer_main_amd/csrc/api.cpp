@@ -130,20 +130,32 @@ static inline uint16_t f16_rne(float f) {
   return u;
 }
 
-// mode: 0 = fp32 fragments, 1 = split-bf16 (hi, lo), 2 = fp16 in the hi fragments (lo fragments zero: never loaded)
+// mode: 0 = fp32 fragments, 1 = split-bf16 (hi, lo), 2 = fp16 in the hi fragments (lo fragments zero: never loaded),
+//       3 = fp16, 64-channel chunks (conv_chunk(mode) input channels per block): the four fragments of a cout block are
+//           the K = 16 steps k 0..15 | 16..31 | 32..47 | 48..63, lane l holds W[cout = 32*nb + (l & 31)][k = 16*f + 8*(l >> 5) + 0..7]
+//           -- the weights of a convolution whose source is an activated fp16 tensor (k_conv, H64)
+int conv_chunk(int mode) { return mode == 3 ? 64 : kKC; }
+
 void rows_to_fragments(std::vector<float>& packed, int Cout, int mode) {
   const bool split = mode != 0;
-  const size_t blk = (size_t)Cout * kKC;
-  std::vector<float> tmp(blk);
-  for (size_t o = 0; o + blk <= packed.size(); o += blk) {
+  const int kc = conv_chunk(mode);
+  const size_t blk = (size_t)Cout * kc;         // input floats per (chunk, tap) block
+  const size_t oblk = (size_t)Cout * kKC;       // output floats per block: Cout / 32 cout blocks of 1024 floats
+  std::vector<float> res(packed.size() / blk * oblk);
+  size_t oo = 0;
+  for (size_t o = 0; o + blk <= packed.size(); o += blk, oo += oblk) {
     const float* in = &packed[o];
     for (int nb = 0; nb < Cout / 32; ++nb) {
-      float* out = &tmp[(size_t)nb * 1024];
+      float* out = &res[oo + (size_t)nb * 1024];
       for (int f = 0; f < 4; ++f)
         for (int l = 0; l < 64; ++l) {
-          const float* row = in + (size_t)(nb * 32 + (l & 31)) * kKC;
+          const float* row = in + (size_t)(nb * 32 + (l & 31)) * kc;
           float* dst = out + (f * 64 + l) * 4;
-          if (split) {
+          if (mode == 3) {
+            uint16_t q[8];
+            for (int j = 0; j < 8; ++j) q[j] = f16_rne(row[16 * f + 8 * (l >> 5) + j]);
+            memcpy(dst, q, sizeof(q));
+          } else if (split) {
             const int s2 = f >> 1, lo = f & 1;
             uint16_t q[8];
             for (int j = 0; j < 8; ++j) {
@@ -161,37 +173,39 @@ void rows_to_fragments(std::vector<float>& packed, int Cout, int mode) {
           }
         }
     }
-    memcpy(&packed[o], tmp.data(), blk * sizeof(float));
   }
+  packed.swap(res);
 }
 
 std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int KW, int c_lo, int C,
                              const std::vector<std::pair<int, int>>& taps, int mode) {
-  const int nt = (int)taps.size();
+  const int nt = (int)taps.size(), kc = conv_chunk(mode);
+  VFX_CHECK(C % kc == 0, "pack_conv: %d input channels do not split into %d-channel chunks", C, kc);
   std::vector<float> out((size_t)C * nt * Cout);
-  for (int ch = 0; ch < C / kKC; ++ch)
+  for (int ch = 0; ch < C / kc; ++ch)
     for (int t = 0; t < nt; ++t)
       for (int n = 0; n < Cout; ++n)
-        for (int cc = 0; cc < kKC; ++cc) {
-          const int c = c_lo + ch * kKC + cc;
-          out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
+        for (int cc = 0; cc < kc; ++cc) {
+          const int c = c_lo + ch * kc + cc;
+          out[(((size_t)ch * nt + t) * Cout + n) * kc + cc] =
               w[(((size_t)n * CinTotal + c) * KH + taps[t].first) * KW + taps[t].second];
         }
   rows_to_fragments(out, Cout, mode);
   return out;
 }
 
-// PyTorch ConvTranspose weight (Cin, Cout, KH, KW) -> [Cin/32][ntaps][Cout][32].
+// PyTorch ConvTranspose weight (Cin, Cout, KH, KW) -> [Cin/chunk][ntaps][Cout][chunk] -> fragment order.
 std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,
                                         const std::vector<std::pair<int, int>>& taps, int mode) {
-  const int nt = (int)taps.size();
+  const int nt = (int)taps.size(), kc = conv_chunk(mode);
+  VFX_CHECK(Cin % kc == 0, "pack_conv_transposed: %d input channels do not split into %d-channel chunks", Cin, kc);
   std::vector<float> out((size_t)Cin * nt * Cout);
-  for (int ch = 0; ch < Cin / kKC; ++ch)
+  for (int ch = 0; ch < Cin / kc; ++ch)
     for (int t = 0; t < nt; ++t)
       for (int n = 0; n < Cout; ++n)
-        for (int cc = 0; cc < kKC; ++cc) {
-          const int c = ch * kKC + cc;
-          out[(((size_t)ch * nt + t) * Cout + n) * kKC + cc] =
+        for (int cc = 0; cc < kc; ++cc) {
+          const int c = ch * kc + cc;
+          out[(((size_t)ch * nt + t) * Cout + n) * kc + cc] =
               w[(((size_t)c * Cout + n) * KH + taps[t].first) * KW + taps[t].second];
         }
   rows_to_fragments(out, Cout, mode);
@@ -272,9 +286,13 @@ static void plan_conv(TapConvParams& p) {
   }
 }
 
+// Channels per stage: 32, except for an activated source of the 16-bit mode -- an fp16 tensor whose 128-byte patch rows
+// hold 64 channels (k_conv, H64).
+int stage_channels(const TapConvParams& p, const TapSeg& S) { return (p.hionly && S.src_act) ? 64 : kKC; }
+
 int count_stages(const TapConvParams& p) {  // per phase, for a phased launch
   int n = 0;
-  for (int s = 0; s < p.nseg; ++s) n += (p.seg[s].C / kKC) * (p.per_tap ? p.seg[s].ntaps : 1);
+  for (int s = 0; s < p.nseg; ++s) n += (p.seg[s].C / stage_channels(p, p.seg[s])) * (p.per_tap ? p.seg[s].ntaps : 1);
   return n;
 }
 
@@ -286,14 +304,16 @@ void build_stages(const TapConvParams& p, const float* ones, const float* zeros,
     // per-tap launches run tap-major: the patch origin (and with it the kernel's cached pixel offsets)
     // then changes ntaps times per block instead of once per stage
     const int nwin = p.per_tap ? S.ntaps : 1;
+    const int kc = stage_channels(p, S);
+    const bool f16src = kc == 64;  // activated fp16 tensor: 2 bytes per element, a 64-channel chunk = 128 bytes = 32 floats
     for (int w = 0; w < nwin; ++w)
-      for (int ch = 0; ch < S.C / kKC; ++ch) {
+      for (int ch = 0; ch < S.C / kc; ++ch) {
         ConvStage st{};
-        st.src = S.src + ch * kKC;
+        st.src = S.src + ch * kKC;  // 128 bytes per chunk in either form
         st.scale = (S.scale ? S.scale : ones) + (S.scale ? ch * kKC : 0);
         st.shift = (S.shift ? S.shift : zeros) + (S.shift ? ch * kKC : 0);
-        st.C = S.C;
-        st.nbytes = (unsigned)((int64_t)p.B * p.in_img_stride * S.C * 4 - (int64_t)ch * kKC * 4);
+        st.C = f16src ? S.C / 2 : S.C;  // pixel stride in floats
+        st.nbytes = (unsigned)((int64_t)p.B * p.in_img_stride * S.C * (f16src ? 2 : 4) - (int64_t)ch * kKC * 4);
         st.flags = S.src_act ? 1 : 0;
         if (S.src_act) {
           st.scale = ones;
@@ -349,11 +369,12 @@ void set_conv1d_geometry(TapConvParams& p, int B, int T, int K, int dil, bool re
 void finish_params(TapConvParams& p) {
   p.total_steps = 0;
   for (int s = 0; s < p.nseg; ++s) {
-    VFX_CHECK(p.seg[s].C % kKC == 0 && p.seg[s].ntaps >= 1 && p.seg[s].ntaps <= kMaxTaps,
+    VFX_CHECK(p.seg[s].C % stage_channels(p, p.seg[s]) == 0 && p.seg[s].ntaps >= 1 && p.seg[s].ntaps <= kMaxTaps,
               "conv: bad segment %d (C=%d ntaps=%d)", s, p.seg[s].C, p.seg[s].ntaps);
     VFX_CHECK(p.seg[s].C <= kIdentityLen, "conv: segment too wide for the identity tables");
-    p.total_steps += p.seg[s].ntaps * (p.seg[s].C / kKC);
+    p.total_steps += p.seg[s].ntaps * (p.seg[s].C / stage_channels(p, p.seg[s]));
   }
+  VFX_CHECK(!(p.hionly && p.out_act) || p.Cout % 8 == 0, "conv: an fp16 activated output needs Cout %% 8 == 0");
   VFX_CHECK((int64_t)p.Hi * p.Wi < (int64_t)1 << 31 && (int64_t)p.Ho * p.Wo < (int64_t)1 << 31, "conv: image too large");
   if (p.in_img_stride == 0) p.in_img_stride = p.in_limit = p.Hi * p.Wi;
   if (p.out_img_stride == 0) {

@@ -62,8 +62,15 @@ namespace vfx {
 // ABL != 0: timing-only ablation builds (-DVFX_ABLATION_BUILD + VFX_ABLATE, wrong results), in the stage loop:
 // bit 0 no patch request, 1 no weight loads, 2 no barrier, 3 constant fragment addresses, 4 no fragment reads,
 // 5 no epilogue, 6 the end-of-stage wait leaves the patch in flight.
-template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false>
+// HI: 16-bit (fp16) operands, one MFMA per product (TapConvParams::hionly).  H64 (with HI): every source of the launch is
+// an ACTIVATED fp16 tensor with 2-byte elements -- a 128-byte patch row holds 64 channels, a stage is a 64-channel
+// chunk, a tap is four K = 16 steps on four fp16 weight fragments (half the stages, barriers and DMA instructions of
+// the 32-channel form, and every fetched byte is an operand).  HI without H64: raw fp32 sources, 32-channel stages,
+// transformed in place to fp16 in the first half of the row, two K = 16 steps per tap.
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false>
 __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
+  static_assert(!H64 || (HI && SPLIT), "H64 is a variant of the 16-bit mode");
+  constexpr bool HI32 = HI && !H64;  // the hi fragments (f[0], f[2]) only
   constexpr int WAVES_N = BN / 32;
   constexpr int WM = BN / 32;  // 32-row blocks per wave (= 4 / WAVES_M)
 
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       // the lane's bytes always land in slot cg: an activated source is fetched pre-swizzled (piece cg ^ key)
       const unsigned piece = praw ? 16u * cg : (unsigned)(cg ^ keyq[q]) << 4;
       // 16-bit mode: only the hi half (pieces 0..3) of an activated row is ever read -- the other lanes fetch nothing
-      const bool need = !HI || praw || piece < 64u;
+      const bool need = !HI32 || praw || piece < 64u;
       const unsigned o = ((okmask & (1u << q)) && need) ? voff[q] + piece : 0xfffffff0u;
       VFX_LDS void* l = (VFX_LDS void*)(lds + dst + (32 * q + 8 * wave_u) * CROW);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
@@ -270,10 +277,11 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       else key[a] = (ABL & 8) ? 0 : ((row >> 1) & 7) << 4;
     }
     if constexpr (SPLIT && HI) {
-      // 16-bit mode: fp16 operands in the hi halves, one MFMA per product
+      // 16-bit mode: fp16 operands, one MFMA per product.  32-channel stages: channels 0..31 in pieces 0..3, fragments
+      // f[0], f[2]; 64-channel stages (H64): pieces 0..7, fragments f[0..3] = k 0..15, 16..31, 32..47, 48..63
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const f16x8 bh = __builtin_bit_cast(f16x8, R.f[2 * s]);
+      for (int s = 0; s < (H64 ? 4 : 2); ++s) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, R.f[H64 ? s : 2 * s]);
         f16x8 ah[WM];
 #pragma unroll
         for (int a = 0; a < WM; ++a) ah[a] = *reinterpret_cast<const f16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   //                 stage's end;
   //   t == NT-1     everything in flight (next taps' weights, the patch) lands before the transform / barrier.
   constexpr int AHEAD = RING - 1;
-  constexpr int WL = HI ? 2 : 4;  // weight loads per tap and wave
+  constexpr int WL = HI32 ? 2 : 4;  // weight loads per tap and wave
   BFrag R0 = {}, R1 = {}, R2 = {};
   const int last = nstages - 1;
   // Cursor state lives in scalar registers; table fields are re-read only when a cursor enters a new stage, and the
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   const float* fw = (const float*)stages[0].wt;
   auto fetch = [&](BFrag& R) __attribute__((always_inline)) {
     if constexpr (ABL & 2) {
-    } else if constexpr (HI) {
+    } else if constexpr (HI32) {
       load_b_asm_hi(R, fw, nb_off);
     } else {
       load_b_asm(R, fw, nb_off);
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       if (t >= TP) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD + CNQ) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
     }
-    if constexpr (HI) use_b_hi(cur_r);
+    if constexpr (HI32) use_b_hi(cur_r);
     else use_b(cur_r);
     compute(cur_r, cur, tap);
     __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of the next tap below the MFMAs of this one (register pressure)
@@ -407,10 +415,10 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   // Ring groups that no fetch has filled yet are defined by copies made AFTER the wait: a copy of a group whose
   // load is still in flight reads stale registers, and since a copy makes the two groups the same value for the
   // compiler, the stale one may end up feeding the first tap.
-  if constexpr (HI) use_b_hi(R0);
+  if constexpr (HI32) use_b_hi(R0);
   else use_b(R0);
   if constexpr (RING == 3) {
-    if constexpr (HI) use_b_hi(R1);
+    if constexpr (HI32) use_b_hi(R1);
     else use_b(R1);
   } else {
     R1 = R0;
@@ -454,15 +462,15 @@ static size_t conv_lds_bytes(int BN, bool hi) {
   return main_bytes + CBM * 4;
 }
 
-template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false>
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false>
 static void launch_one(int grid, hipStream_t stream, const TapConvParams* dparams) {
   const size_t lds = conv_lds_bytes(BN, HI);
   static uint64_t attr_devices = 0;  // one static per instantiation
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI>),
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI>), dim3(grid), dim3(256), lds, stream, dparams);
+  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64>), dim3(grid), dim3(256), lds, stream, dparams);
 }
 
 #ifdef VFX_ABLATION_BUILD
@@ -485,12 +493,14 @@ static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvP
 }
 #endif
 
-template <bool ELU, bool SPLIT, bool HI = false>
+template <bool ELU, bool SPLIT, bool HI = false, bool H64 = false>
 static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams* dparams) {
   switch (BN) {
-    case 128: launch_one<128, ELU, SPLIT, 0, 3, HI>(grid, stream, dparams); break;
-    case 64: launch_one<64, ELU, SPLIT, 0, 3, HI>(grid, stream, dparams); break;
-    default: launch_one<32, ELU, SPLIT, 0, 2, HI>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
+    // H64: a tap is four K = 16 steps (as long as two taps of the 32-channel form), so one tap of look-ahead covers the
+    // same time with a third less ring registers (with three groups the BN = 128 tile spills at three waves per SIMD)
+    case 128: launch_one<128, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64>(grid, stream, dparams); break;
+    case 64: launch_one<64, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64>(grid, stream, dparams); break;
+    default: launch_one<32, ELU, SPLIT, 0, 2, HI, H64>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
   }
 }
 
@@ -520,8 +530,19 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
   if (abl && hp.split && !elu && BN == 128 && launch_ablated(abl, (int)grid, stream, dparams)) return;
 #endif
   if (hp.split && hp.hionly) {
-    if (elu) launch_bn<true, true, true>(BN, (int)grid, stream, dparams);
-    else launch_bn<false, true, true>(BN, (int)grid, stream, dparams);
+    // 16-bit mode: activated sources are fp16 tensors with 64-channel stages, raw fp32 sources keep 32-channel stages;
+    // one launch has one kind (the hand-counted weight waits depend on the loads per tap)
+    int n_act = 0;
+    for (int s = 0; s < hp.nseg; ++s) n_act += hp.seg[s].src_act ? 1 : 0;
+    VFX_CHECK(n_act == 0 || n_act == hp.nseg, "conv: 16-bit launches cannot mix activated and raw sources");
+    if (n_act) {
+      VFX_CHECK(!elu, "conv: an activated source has no prologue");
+      launch_bn<false, true, true, true>(BN, (int)grid, stream, dparams);
+    } else if (elu) {
+      launch_bn<true, true, true>(BN, (int)grid, stream, dparams);
+    } else {
+      launch_bn<false, true, true>(BN, (int)grid, stream, dparams);
+    }
   } else if (hp.split) {
     if (elu) launch_bn<true, true>(BN, (int)grid, stream, dparams);
     else launch_bn<false, true>(BN, (int)grid, stream, dparams);

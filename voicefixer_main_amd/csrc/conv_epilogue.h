@@ -94,7 +94,10 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
       const float slope = p.act_slope;
       const bool elu = p.act_elu != 0;
       // split: the pair's 8 channels live in chunk ncol/32; hi block at +0, lo block at +16 floats, 8 channels = 4 floats
-      const int aoff = SPLIT ? (ncol & ~31) + ((ncol & 31) >> 3) * 4 + (even ? 0 : 16) : ncol;
+      // 16-bit mode: the activated tensor is an fp16 tensor (2 bytes per element, Cout / 2 floats per pixel); the even
+      // lane of a pair stores the pair's 8 consecutive channels (16 bytes) at channel ncol
+      const int aoff = (SPLIT && f16) ? (ncol >> 1) : SPLIT ? (ncol & ~31) + ((ncol & 31) >> 3) * 4 + (even ? 0 : 16) : ncol;
+      const int64_t astride = (SPLIT && f16) ? (Cout >> 1) : Cout;
 #pragma unroll
       for (int q = 0; q < NPASS; ++q) {
         ce_f32x4 u;
@@ -130,7 +133,7 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
           o = u;
         }
         // 16-bit mode: the lo half (odd lanes) is never read by a consumer -- not written either
-        if (opix[q] >= 0 && !(SPLIT && f16 && !even)) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * Cout + aoff) = o;
+        if (opix[q] >= 0 && !(SPLIT && f16 && !even)) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * astride + aoff) = o;
       }
     }
   }

@@ -91,8 +91,11 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
     const bool split = h->cfg.precision != 0;
     std::vector<std::pair<int, int>> taps = {{0, 0}, {0, 1}, {0, 2}};
     const int pmode = h->cfg.precision == 2 ? 2 : (int)split;
+    // two-launch form, 16-bit mode: h travels as an activated fp16 tensor (64-channel stages) when C allows it
+    const bool h_f16 = !fused && h->cfg.precision == 2 && C % 64 == 0;
+    const bool h_act = !(h->cfg.precision == 2 && !h_f16);
     float* dw1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, pmode));
-    float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, pmode));
+    float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, h_f16 ? 3 : pmode));
     float* db1 = sc.blob.upload(b1, C);
     float* db2 = sc.blob.upload(b2, C);
     if (fused) {
@@ -123,15 +126,20 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       fill_seg(p1.seg[0], x, C, nullptr, nullptr, ACT_LEAKY, slope, sc.blob);
       p1.seg[0].wt = dw1;
       p1.bias = db1;
-      p1.out_act = hbuf;  // activated with conv2's prologue
-      p1.act_slope = slope;
+      if (h_act) {
+        p1.out_act = hbuf;  // activated with conv2's prologue
+        p1.act_slope = slope;
+      } else {
+        p1.out = hbuf;      // raw: conv2 applies the LeakyReLU itself
+        p1.act_slope = 1.f;
+      }
       run_one(h, p1, sc.blob, s);
       TapConvParams p2{};
       set_conv1d_geometry(p2, B, T, 3, 1, false);
       p2.Cout = C;
       p2.nseg = 1;
-      fill_seg(p2.seg[0], hbuf, C, nullptr, nullptr, ACT_NONE, 1.f, sc.blob);
-      p2.seg[0].src_act = 1;
+      fill_seg(p2.seg[0], hbuf, C, nullptr, nullptr, h_act ? ACT_NONE : ACT_LEAKY, h_act ? 1.f : slope, sc.blob);
+      p2.seg[0].src_act = h_act ? 1 : 0;
       p2.seg[0].wt = dw2;
       p2.bias = db2;
       p2.residual = x;

@@ -266,30 +266,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
   // fetch of the chunk's last tap) request the next chunk's patch; wait for tap g; MFMAs.  Every chunk ends
   // with vmcnt(0), so only fetches issued inside the chunk need a counted wait: they all precede the patch
   // request, which is therefore never drained early.
-  // Two chunks (C = 64): both patches are requested up front -- the block's latency chain has ONE HBM round trip in
-  // front of conv1 instead of two.  The second request is older than every weight fetch of chunk 0, so the counted
-  // weight waits there need no allowance for it (vmcnt retires in order).
-  constexpr bool UPFRONT = NCH == 2;
+  // (Requesting both patches of a two-chunk block up front was measured: -3 % on the C = 64 stack -- the stack moves
+  // ~5 GB per layer through the fabric at ~4.9 TB/s, it is bandwidth-, not latency-bound.)
 #pragma unroll
   for (int g = 0; g < AHEAD; ++g) fetch(g);
   issue_patch(0, 0);
-  if constexpr (UPFRONT) {
-    issue_patch(1, CPATCH);
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NG) : "memory");  // the first AHEAD taps and patch 0 have landed; patch 1 may be in flight
-    if constexpr (HI) {
-      use_b_hi(R0);
-      use_b_hi(R1);
-    } else {
-      use_b(R0);
-      use_b(R1);
-    }
-  } else {
-    drain();
-  }
+  drain();
   transform_patch(0, 0);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const bool has_dma = !UPFRONT && c + 1 < NCH;
+    const bool has_dma = c + 1 < NCH;
     __syncthreads();  // patch c is visible; the other buffer is free
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -306,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
       __builtin_amdgcn_sched_barrier(0);
     }
     drain();
-    if (c + 1 < NCH) transform_patch(((c + 1) & 1) * CPATCH, c + 1);
+    if (has_dma) transform_patch(((c + 1) & 1) * CPATCH, c + 1);
   }
 
   __syncthreads();  // every wave is done reading the patch buffers that h overlays

@@ -151,8 +151,9 @@ struct TapConvParams {
   float* out;            // raw fp32 output (B, Ho, Wo, Cout) or nullptr
   // Optional ACTIVATED output for a tensor whose only consumer is the next convolution: the epilogue
   // applies that consumer's prologue (per-channel affine, LeakyReLU / ELU) once per element and stores
-  // the MFMA operand form, same size as fp32: per pixel and 32-channel chunk [32 hi bf16 | 32 lo bf16]
-  // in split-bf16 mode, 32 activated floats in fp32 mode.  The consumer stages it by plain copy.
+  // the MFMA operand form: per pixel and 32-channel chunk [32 hi bf16 | 32 lo bf16] in split-bf16 mode and 32
+  // activated floats in fp32 mode (same size as fp32); in the 16-bit mode (hionly) an fp16 tensor, 2 bytes per
+  // element, channels in natural order.  The consumer stages it by plain copy (LDS-DMA).
   float* out_act;
   const float* act_scale;  // [Cout] or nullptr (=1)
   const float* act_shift;  // [Cout] or nullptr (=0)
@@ -359,6 +360,7 @@ struct VocConvW {
   float* bias = nullptr;  // [cout]; transposed convs: repeated once per output phase ([stride][cout])
   std::vector<float*> w_phase;
   int cin = 0, cout = 0;
+  int mode = 0;  // pack_conv mode the weights were packed with (follows the form of the source tensor in the plan)
 };
 
 struct VocoderWeights {
@@ -371,8 +373,11 @@ struct VocoderWeights {
   int final_c = 0;
 };
 
-// Conv weights -> MFMA fragment order [C/32][ntaps][Cout/32][1024 floats] (conv.hip); `split`
-// selects the split-bf16 (hi | lo) or the fp32 fragment layout.
+// Conv weights -> MFMA fragment order [C/chunk][ntaps][Cout/32][1024 floats] (conv.hip); mode: 0 fp32, 1 split-bf16
+// (hi | lo), 2 fp16 in the hi fragments (32-channel chunks, raw sources of the 16-bit mode), 3 fp16 with 64-channel
+// chunks (activated fp16 sources of the 16-bit mode); conv_chunk(mode) = input channels per chunk.
+int conv_chunk(int mode);
+int stage_channels(const TapConvParams& p, const TapSeg& S);
 std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int KW, int c_lo, int C,
                              const std::vector<std::pair<int, int>>& taps, int mode);
 std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,

@@ -29,8 +29,22 @@ const HostTensor& staged(vfx_handle* h, const std::string& name) {
   return it->second;
 }
 
+// Weight packing mode (pack_conv) of a convolution of the vocoder: in the 16-bit mode a convolution that reads an
+// ACTIVATED tensor (fp16, 64-channel stages) and one that reads a raw fp32 tensor (32-channel stages) use different
+// fragment orders, so the mode follows the plan (build_vocoder): which tensors exist in activated form.
+int pack_mode(const vfx_config& cfg, bool src_act) {
+  if (cfg.precision == 2) return src_act ? 3 : 2;
+  return cfg.precision != 0 ? 1 : 0;
+}
+
+// HBM-bound stacks (C = 64, 128) run each layer as ONE fused launch on the raw trunk (resblock.hip); the wide stacks
+// run two launches per layer on a trunk kept in both forms.  `VFX_NO_FUSE` forces the latter (A/B runs).
+bool stack_fused(const vfx_config& cfg, int channels) {
+  return cfg.precision != 0 && resblock_supported(channels) && !getenv("VFX_NO_FUSE");
+}
+
 // Conv1d weight (Cout, Cin, K) -> packed with taps k = 0..K-1
-VocConvW load_conv1d(vfx_handle* h, const std::string& p, int cin, int cout, int K) {
+VocConvW load_conv1d(vfx_handle* h, const std::string& p, int cin, int cout, int K, bool src_act) {
   const HostTensor& w = staged(h, p + ".weight");
   VFX_CHECK(w.shape == std::vector<int64_t>({cout, cin, K}), "vocoder tensor '%s.weight' has an unexpected shape", p.c_str());
   std::vector<std::pair<int, int>> taps;
@@ -38,7 +52,8 @@ VocConvW load_conv1d(vfx_handle* h, const std::string& p, int cin, int cout, int
   VocConvW c;
   c.cin = cin;
   c.cout = cout;
-  c.w = h->blob.upload(pack_conv(w.data.data(), cout, cin, 1, K, 0, cin, taps, h->cfg.precision == 2 ? 2 : (h->cfg.precision != 0)));
+  c.mode = pack_mode(h->cfg, src_act);
+  c.w = h->blob.upload(pack_conv(w.data.data(), cout, cin, 1, K, 0, cin, taps, c.mode));
   const HostTensor& b = staged(h, p + ".bias");
   VFX_CHECK((int)b.data.size() == cout, "vocoder tensor '%s.bias' has an unexpected shape", p.c_str());
   c.bias = h->blob.upload(b.data);
@@ -65,10 +80,10 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
   char name[96];
   for (int i = 0; i < cfg.voc_cond_layers; ++i) {
     snprintf(name, sizeof(name), "condnet.%d", 2 * i);
-    W->cond.push_back(load_conv1d(h, name, cin, cfg.voc_cond_channels, 3));
+    W->cond.push_back(load_conv1d(h, name, cin, cfg.voc_cond_channels, 3, /*src_act=*/i > 0));  // the first reads the raw mel
     cin = cfg.voc_cond_channels;
   }
-  W->pre = load_conv1d(h, "generator.1", cin, cfg.voc_channels, 7);
+  W->pre = load_conv1d(h, "generator.1", cin, cfg.voc_channels, 7, /*src_act=*/true);
   int c = cfg.voc_channels, idx = 3;
   for (int st = 0; st < cfg.voc_n_stages; ++st) {
     const int s = cfg.voc_scales[st], pad = s / 2 + s % 2;
@@ -78,10 +93,12 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
     VocConvW up;
     up.cin = c;
     up.cout = c / 2;
+    // the upsampler reads the activated trunk, unless the stack in front of it is fused (raw trunk only)
+    up.mode = pack_mode(cfg, st == 0 || !stack_fused(cfg, c));
     for (int r = 0; r < s; ++r) {
       std::vector<std::pair<int, int>> taps;
       for (auto& ek : phase_taps(s, pad, r)) taps.push_back({0, ek.second});
-      up.w_phase.push_back(h->blob.upload(pack_conv_transposed(w.data.data(), c, c / 2, 1, 2 * s, taps, h->cfg.precision == 2 ? 2 : (h->cfg.precision != 0))));
+      up.w_phase.push_back(h->blob.upload(pack_conv_transposed(w.data.data(), c, c / 2, 1, 2 * s, taps, up.mode)));
     }
     {  // the phased launch sees the output as (B, T, stride * cout): one bias copy per phase
       const std::vector<float>& b = staged(h, std::string(name) + ".bias").data;
@@ -97,7 +114,9 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
       char a[96], b[96];
       snprintf(a, sizeof(a), "generator.%d.res_layers.%d.1", idx + 1, i);
       snprintf(b, sizeof(b), "generator.%d.res_layers.%d.3", idx + 1, i);
-      stack.push_back({load_conv1d(h, a, c, c, 3), load_conv1d(h, b, c, c, 3)});
+      // unfused layers read the activated trunk / the activated h; the fused kernel transforms raw patches itself
+      const bool act = !stack_fused(cfg, c);
+      stack.push_back({load_conv1d(h, a, c, c, 3, act), load_conv1d(h, b, c, c, 3, act)});
     }
     W->res.push_back(stack);
     idx += 3;
@@ -141,6 +160,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
   // A tensor between two convolutions exists in up to two forms: raw fp32 (residual adds,
   // non-GEMM consumers) and ACTIVATED for its consumer convolution (that consumer's prologue applied once by the
   // producer's epilogue, MFMA operand form, staged by the DMA engine with no arithmetic).
+  // floats an activated tensor of n elements occupies: fp16 (2 bytes per element) in the 16-bit mode
+  auto act_floats = [&](int64_t n) -> int64_t { return cfg.precision == 2 ? (n + 1) / 2 : n; };
   constexpr size_t kNone = ~size_t(0);
   struct Forms {
     size_t raw = kNone, act = kNone;
@@ -161,12 +182,13 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     p.bias = cw.bias;
     p.residual = residual ? rel_ptr(*residual) : nullptr;
     p.act_slope = 1.f;
+    VFX_CHECK(cw.mode == pack_mode(cfg, src_act), "vocoder plan: weights of a %d -> %d convolution are packed for another source form", cw.cin, cw.cout);
     if (want_raw) {
       out.raw = pb.alloc_f((int64_t)B * Tlen * cw.cout);
       p.out = const_cast<float*>(rel_ptr(out.raw));
     }
     if (next_act != ACT_NONE) {
-      out.act = pb.alloc_f((int64_t)B * Tlen * cw.cout);
+      out.act = pb.alloc_f(act_floats((int64_t)B * Tlen * cw.cout));
       p.out_act = const_cast<float*>(rel_ptr(out.act));
       p.act_slope = next_slope;
       p.act_elu = next_act == ACT_ELU;
@@ -204,14 +226,13 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     const int s = cfg.voc_scales[st], pad = s / 2 + s % 2;
     const VocConvW& up = W->up[st];
     const int Tout = Tlen * s;
-    // HBM-bound stacks (C = 64, 128) run each layer as ONE fused launch on the raw trunk (resblock.hip); the wide
-    // stacks run two launches per layer on a trunk kept in both forms.  `VFX_NO_FUSE` forces the latter (A/B runs).
-    const bool fuse = cfg.precision != 0 && resblock_supported(up.cout) && !getenv("VFX_NO_FUSE");
+    const bool fuse = stack_fused(cfg, up.cout);
     const bool last_stage = st + 1 == cfg.voc_n_stages;
     Forms y;
     y.raw = pb.alloc_f((int64_t)B * Tout * up.cout);
-    if (!fuse) y.act = pb.alloc_f((int64_t)B * Tout * up.cout);
+    if (!fuse) y.act = pb.alloc_f(act_floats((int64_t)B * Tout * up.cout));
     const bool up_src_act = cur.act != kNone;  // the producer already applied LeakyReLU(up_slope)
+    VFX_CHECK(up.mode == pack_mode(cfg, up_src_act), "vocoder plan: upsampler %d is packed for another source form", st);
     {
       // ConvTranspose1d(k = 2s, stride s) as ONE phased launch: output phase r (samples s*q + r) is a 2-tap
       // convolution of the input, and (B, Tlen * s, cout) viewed as (B, Tlen, s * cout) makes the phases plain cout
