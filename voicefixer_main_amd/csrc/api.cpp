@@ -863,14 +863,7 @@ int vfx_chunk_ola(vfx_handle* h, const float* frames, const float* window, float
 int vfx_istft(vfx_handle* h, const float* re, const float* im, int B, int T, int L, float* wav, void* stream) {
   VFX_API_BEGIN_H(h)
   VFX_CHECK(h && re && im && wav && B > 0 && T > 0 && L > 0, "bad argument");
-  const size_t need = (size_t)B * T * h->cfg.n_fft * sizeof(float);
-  if (need > h->arena_bytes) h->plans.clear();  // plans hold absolute pointers into the old arena
-  // reuse the arena as the frame buffer (no plan is running concurrently: single stream, single thread)
-  Plan tmp;
-  tmp.arena_bytes = need;
-  bind_plan(h, tmp);
-  launch_istft(h->fe, re, im, B, T, L, h->cfg.hop, reinterpret_cast<float*>(h->arena), wav,
-               static_cast<hipStream_t>(stream));
+  launch_istft(h->fe, re, im, B, T, L, h->cfg.hop, wav, static_cast<hipStream_t>(stream));
   VFX_API_END
 }
 
@@ -1024,12 +1017,11 @@ static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, 
     nm["sin"] = pb.alloc_f(nsp);
     nm["re"] = pb.alloc_f(nsp);
     nm["im"] = pb.alloc_f(nsp);
-    nm["frames"] = pb.alloc_f((size_t)B * T * h->cfg.n_fft);
     build_unet_spec(pb, B, T, ext(0), arena_buf(nm["cos"]), arena_buf(nm["sin"]), arena_buf(nm["re"]), arena_buf(nm["im"]));
   });
   debug_poison(*plan, stream);
   const size_t off_cos = plan->named["cos"], off_sin = plan->named["sin"], off_re = plan->named["re"],
-               off_im = plan->named["im"], off_frames = plan->named["frames"];
+               off_im = plan->named["im"];
   hipStream_t s = static_cast<hipStream_t>(stream);
   char* base = h->arena;
   float* cosb = reinterpret_cast<float*>(base + off_cos);
@@ -1039,7 +1031,7 @@ static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, 
   RunCtx ctx{s, {const_cast<float*>(sp)}, h->d_flags, &h->prof};
   plan->run(ctx);
   launch_istft(h->fe, reinterpret_cast<float*>(base + off_re), reinterpret_cast<float*>(base + off_im), B, T, L,
-               h->cfg.hop, reinterpret_cast<float*>(base + off_frames), wav_out, s);
+               h->cfg.hop, wav_out, s);
   VFX_API_END
 }
 

@@ -220,8 +220,8 @@ struct FrontEndTables {
 void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, int T, float* mel, float* sp,
                      float* cosp, float* sinp, int log10_mel, int hop, float eps, hipStream_t stream);
 void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, float* mel, hipStream_t stream);
-void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop,
-                  float* frames_ws, float* wav, hipStream_t stream);
+void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop, float* wav,
+                  hipStream_t stream);
 
 void launch_prep_logmel(const float* mel_linear, int B, int T, int Tpad, float* x, int* flags, hipStream_t s);
 void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s);
