@@ -36,7 +36,11 @@ enum { VFX_MODEL_UNET_MEL = 0, VFX_MODEL_UNET_SPEC = 1, VFX_MODEL_VOCODER = 2,
        VFX_MODEL_FRONTEND = 3 /* buffers of f_helper / mel: "mel.fb" (1025,128) */ };
 
 /* sticky device-side flags returned by vfx_take_flags */
-enum { VFX_FLAG_NEGATIVE_INPUT = 1 /* to_log saw a negative value (pytorch_util.py:158) */ };
+enum {
+  VFX_FLAG_NEGATIVE_INPUT = 1, /* to_log saw a negative value (pytorch_util.py:158) */
+  VFX_FLAG_F16_SATURATED = 2   /* precision 2: an activation of the vocoder left the fp16 range (|x| > 65504) and was
+                                  clamped -- the result of that call is not trustworthy; re-run it with precision 1 */
+};
 
 typedef struct vfx_config {
   /* front-end: config/vctk_base_voicefixer_unet.json:68-78 */

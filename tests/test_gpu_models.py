@@ -150,3 +150,75 @@ def test_fp16_vocoder_mode(unet_sd, voc_sd):
     assert res["restore_sisdr_db"] > 50.0, res
     assert res["restore_out_logmel_l1"] < 1e-3, res         # log-mel of the restored waveform: the north-star bar
     assert res["vocoder_sisdr_db_split"] > 60.0, res
+
+
+def _rescaled_vocoder(voc_sd, s):
+    """The same function with an internal tensor s times larger: the k7 convolution in front of the first upsampler
+    (weights and bias) times s, the upsampler's weights divided by s (LeakyReLU is positively homogeneous)."""
+    sd = {k: v.clone() for k, v in voc_sd.items()}
+    sd["generator.1.weight"] *= s
+    sd["generator.1.bias"] *= s
+    sd["generator.3.layer.weight"] /= s
+    return sd
+
+
+def test_fp16_vocoder_dynamic_range_flag_and_rerun(unet_sd, voc_sd):
+    """fp16 operands have 5 exponent bits: the 16-bit vocoder (precision 2) must hold its waveform bar over a wide range
+    of activation magnitudes, and must SAY so when an activation leaves the fp16 range instead of clamping silently:
+    the kernels raise VFX_FLAG_F16_SATURATED and the model-level call re-runs on split-bf16 operands.  Also run: weights
+    WITHOUT the x0.25 damping of the residual branches that the other tests' synthetic vocoder uses.  Figures go to
+    gpurun_out/fp16_robustness.json."""
+    import json
+    import os
+    import warnings
+    from oracle import vocoder as voc
+    from voicefixer_main_amd import _lib, models, synth
+    from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_VOCODER
+    mel = _mel_input(2, 40, seed=3)
+    mel_t = torch.from_numpy(mel[:, 0])
+    res = {}
+    eng = Engine("cuda:0", config={"precision": 2})
+    eng.load_state_dict(MODEL_UNET_MEL, unet_sd)
+    ref0 = voc.vocoder(voc_sd, torch.from_numpy(mel)).numpy()[:, 0]
+    for name, s in (("x1", 1.0), ("up60dB", 1e3), ("down60dB", 1e-3), ("down100dB", 1e-5)):
+        eng.load_state_dict(MODEL_VOCODER, _rescaled_vocoder(voc_sd, s))
+        got = eng.vocoder(mel_t).cpu().numpy()
+        flags = eng.take_flags()
+        res["sisdr_db_" + name] = _sisdr(got, ref0)
+        res["flags_" + name] = flags
+        assert flags == 0, (name, flags)
+    assert res["sisdr_db_x1"] > 50 and res["sisdr_db_up60dB"] > 50 and res["sisdr_db_down60dB"] > 50, res
+    # beyond the range: flagged, and the model-level call answers with the split-bf16 result
+    big = _rescaled_vocoder(voc_sd, 3e5)
+    eng.load_state_dict(MODEL_VOCODER, big)
+    clamped = eng.vocoder(mel_t).cpu().numpy()
+    flags = eng.take_flags()
+    res["sisdr_db_up110dB_clamped"] = _sisdr(clamped, ref0)
+    assert flags & _lib.FLAG_F16_SATURATED, flags
+    m = models.VoiceFixer(None, channels=1, engine=eng)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = m.vocoder(torch.from_numpy(mel).cuda())[:, 0].cpu().numpy()
+    assert any("fp16 range" in str(x.message) for x in w)
+    res["sisdr_db_up110dB_rerun"] = _sisdr(out, ref0)
+    assert res["sisdr_db_up110dB_rerun"] > 70, res
+    assert eng.take_flags() == 0
+    # undamped residual branches (every ResStack conv at full Kaiming-uniform gain): larger, growing residual stream
+    gen = torch.Generator().manual_seed(5)
+    und = {k: v.clone() for k, v in voc_sd.items()}
+    for k in und:
+        if ".res_layers." in k and k.endswith(".3.weight"):
+            und[k] = und[k] * 4.0          # undo synth.make_vocoder_state_dict's gain = 0.25
+    ref_u = voc.vocoder(und, torch.from_numpy(mel)).numpy()[:, 0]
+    res["undamped_ref_peak"] = float(np.abs(ref_u).max())
+    for prec in (2, 1):
+        e = Engine("cuda:0", config={"precision": prec})
+        e.load_state_dict(MODEL_VOCODER, und)
+        got = e.vocoder(mel_t).cpu().numpy()
+        res["undamped_sisdr_db_p%d" % prec] = _sisdr(got, ref_u)
+        res["undamped_flags_p%d" % prec] = e.take_flags()
+    assert res["undamped_flags_p2"] == 0 and res["undamped_sisdr_db_p2"] > 45 and res["undamped_sisdr_db_p1"] > 60, res
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/fp16_robustness.json", "w") as f:
+        json.dump({k: float(v) for k, v in res.items()}, f, indent=1)
+    print(res)

@@ -559,6 +559,7 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     if (p.residual) p.residual = rebase(p.residual);
     if (p.out) p.out = const_cast<float*>(rebase(p.out));
     if (p.out_act) p.out_act = const_cast<float*>(rebase(p.out_act));
+    p.flags = h->d_flags;
     const size_t pidx = &p - abs.data();
     if (p.nphase > 1) {  // one stage table per phase, built from that phase's segment on the common patch geometry
       const std::vector<TapSeg>& segs = plan.phase_segs.at(pidx);
@@ -585,6 +586,7 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     for (auto& q : rb) {
       q.x = rebase(q.x);
       q.y = const_cast<float*>(rebase(q.y));
+      q.flags = h->d_flags;
     }
     if (!plan.dev_rb) plan.dev_rb = static_cast<ResBlockParams*>(plan.blob.alloc(rb.size() * sizeof(ResBlockParams)));
     VFX_HIP(hipMemcpy(plan.dev_rb, rb.data(), rb.size() * sizeof(ResBlockParams), hipMemcpyHostToDevice));

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     const float pslope = S.slope;
     char* row0 = lds + dst + lr * CROW;
     f32x4 raw[CNQ];
+    bool f16_sat = false;  // 16-bit mode: a value left the fp16 range and was clamped (reported per patch: no loop-carried state)
 #pragma unroll
     for (int q = 0; q < CNQ; ++q)
       if (q < 4 || q < nq) raw[q] = *reinterpret_cast<const f32x4*>(row0 + 32 * q * CROW + 16 * cg);
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
         if constexpr (SPLIT && HI) {
           // fp16 values of channels 4cg..4cg+3 in the hi half of the row: piece cg>>1, half cg&1 (lo pieces unused)
           *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ keyq[q]) << 4) + 8 * (cg & 1)) =
-              make_uint2(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]));
+              make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
         } else if constexpr (SPLIT) {
           // v = hi + lo with hi = bf16(v), lo = bf16(v - hi); logical row layout [32 hi | 32 lo]
           const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
           *reinterpret_cast<f32x4*>(rowp + ((cg ^ keyq[q]) << 4)) = v;
         }
       }
+    if constexpr (SPLIT && HI) report_f16_saturation(f16_sat, p.flags);
   };
 
   // `tap` = ConvStage::poff entry: patch row offset of the tap in bits 0..15, its column shift in 16..23, row shift in 24..31

@@ -19,6 +19,16 @@ __device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
+// The same, recording whether the clamp changed a value (VFX_FLAG_F16_SATURATED).
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b, bool& sat) {
+  sat = sat | (__builtin_fabsf(a) > 65504.f) | (__builtin_fabsf(b) > 65504.f);
+  return pack_f16x2(a, b);
+}
+// One atomic per wave that saw a clamp (rare path).
+__device__ __forceinline__ void report_f16_saturation(bool sat, int* flags) {
+  if (__any(sat) && flags && (threadIdx.x & 63) == 0) atomicOr(flags, VFX_FLAG_F16_SATURATED);
+}
+
 constexpr int CBM = 128;                     // pixels per tile
 constexpr int CROW = 128;                    // bytes per patch row (32 channels)
 constexpr int CNQ = kPatchMaxRows / 32;      // patch row groups (one DMA instruction / register group each)

@@ -88,6 +88,7 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
         if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out + (int64_t)opix[q] * Cout + ncol) = val[q];
     }
     if (p.out_act) {
+      bool f16_sat = false;  // 16-bit mode: an activation left the fp16 range and was clamped (VFX_FLAG_F16_SATURATED)
       ce_f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
       if (p.act_scale) asc = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_scale + ncol);
       if (p.act_shift) ash = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_shift + ncol);
@@ -115,6 +116,7 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
             h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(c01, ce_f16x2));
             h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(c23, ce_f16x2));
             l01 = l23 = 0u;
+            f16_sat = f16_sat | (c01[0] != u[0]) | (c01[1] != u[1]) | (c23[0] != u[2]) | (c23[1] != u[3]);  // clamped
           } else {
             h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[0], u[1]}, ce_bf16x2));
             h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[2], u[3]}, ce_bf16x2));
@@ -134,6 +136,9 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
         }
         // 16-bit mode: the lo half (odd lanes) is never read by a consumer -- not written either
         if (opix[q] >= 0 && !(SPLIT && f16 && !even)) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * astride + aoff) = o;
+      }
+      if constexpr (SPLIT) {
+        if (f16 && __any(f16_sat) && p.flags && (tid & 63) == 0) atomicOr(p.flags, VFX_FLAG_F16_SATURATED);
       }
     }
   }

@@ -23,6 +23,7 @@ void fill_seg(TapSeg& S, const float* x, int Cin, const float* scale, const floa
 void run_one(vfx_handle* h, TapConvParams& p, DeviceBlob& blob, hipStream_t s) {
   p.split = h->cfg.precision != 0;
   p.hionly = h->cfg.precision == 2;
+  p.flags = h->d_flags;
   finish_params(p);
   std::vector<ConvStage> st(p.nstages);
   build_stages(p, h->d_ones, h->d_zeros, st.data());
@@ -112,6 +113,7 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       rp.T = T;
       rp.C = C;
       rp.hionly = h->cfg.precision == 2;
+      rp.flags = h->d_flags;
       rp.dil = dil;
       plan_resblock(rp);
       ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));

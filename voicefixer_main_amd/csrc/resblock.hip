@@ -164,6 +164,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
       psh = *(const VFX_GLOBAL f32x4*)(p.sh1 + c * kKC + 4 * cg);
     }
     f32x4 raw[NG];
+    bool f16_sat = false;  // 16-bit mode: a value left the fp16 range and was clamped (reported per patch)
 #pragma unroll
     for (int q = 0; q < NG; ++q)
       if (q * RG < 128 || q < nq) raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
         }
         if constexpr (HI) {  // fp16 in the hi half only
           *reinterpret_cast<uint2*>(row0 + RG * q * CROW + (((cg >> 1) ^ key_l) << 4) + 8 * (cg & 1)) =
-              make_uint2(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]));
+              make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
           continue;
         }
         const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
         *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ key_l) << 4) + half) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ key_l) << 4) + half) = make_uint2(l01, l23);
       }
+    if constexpr (HI) report_f16_saturation(f16_sat, p.flags);
   };
 
   // ---- MFMA step: 32 channels of one tap; A rows `row[a]` of an LDS image with `stride` bytes per row ------
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
   // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------
   // Lane (l31, lh) of M block a holds h pixel m = (wm*WM + a)*32 + l31 and, in registers 4j .. 4j+3, channels
   // wn*32 + 8j + 4lh .. +3: their 4 hi bf16 are half `lh` of piece j of the pixel's chunk row, the 4 lo of piece j+4.
+  bool f16_sat = false;  // 16-bit mode: a value of h left the fp16 range and was clamped
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
     const int m = (wm * WM + a) * 32 + l31;
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
         acc[a][4 * j + e] = 0.f;
       }
       if constexpr (HI) {
-        *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1]), pack_f16x2(u[2], u[3]));
+        *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1], f16_sat), pack_f16x2(u[2], u[3], f16_sat));
         continue;
       }
       const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u[0], u[1]}, bf16x2));
@@ -333,6 +336,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
       *reinterpret_cast<uint2*>(rowp + (((j + 4) ^ key) << 4)) = make_uint2(l01, l23);
     }
   }
+  if constexpr (HI) report_f16_saturation(f16_sat, p.flags);
   __syncthreads();  // h is complete
 
   // ---- phase 3: conv2 from the resident h ------------------------------------------------------------------

@@ -159,6 +159,7 @@ struct TapConvParams {
   const float* act_shift;  // [Cout] or nullptr (=0)
   float act_slope;         // LeakyReLU slope in [0, 1] (1 = identity)
   int act_elu;             // 1: ELU instead of LeakyReLU
+  int* flags;              // the handle's sticky device flags (VFX_FLAG_F16_SATURATED); may be NULL
 };
 
 // One fused TFGAN ResStack layer (resblock.hip): y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2.
@@ -178,6 +179,7 @@ struct ResBlockParams {
   int PW, P;        // x patch: PH x PW pixels, P <= kPatchMaxRows
   int poff[3];      // patch row offset of conv1's taps
   int hionly;       // fp16 operands in the hi halves only, cf. TapConvParams::hionly
+  int* flags;       // the handle's sticky device flags (VFX_FLAG_F16_SATURATED); may be NULL
   // 2-D ConvBlockRes mode (plan_block2d): x, y are (B, H, W, C), both convolutions 3x3, folded BatchNorm affines
   int geo2d, H, W;
   const float* sc1;  // bn1 scale / shift [C]: prologue of conv1

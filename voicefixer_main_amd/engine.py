@@ -52,8 +52,13 @@ class Engine:
         _lib.check(self.lib.vfx_create(idx, ctypes.byref(self.cfg), ctypes.byref(h)), "vfx_create")
         self.h = h
         self.loaded = set()
+        self._state = {}        # model id -> (state_dict, prefix) as loaded, for the stricter-arithmetic twin
+        self._strict = None
 
     def close(self):
+        if getattr(self, "_strict", None) is not None:
+            self._strict.close()
+            self._strict = None
         if getattr(self, "h", None):
             self.lib.vfx_destroy(self.h)
             self.h = None
@@ -96,6 +101,26 @@ class Engine:
             raise RuntimeError("no tensors with prefix %r in the state_dict" % prefix)
         _lib.check(self.lib.vfx_finalize_weights(self.h, model), "vfx_finalize_weights")
         self.loaded.add(model)
+        self._state[model] = (state_dict, prefix)
+        if self._strict is not None:
+            self._strict.load_state_dict(model, state_dict, prefix)
+
+    @property
+    def precision(self):
+        return int(self.cfg.precision)
+
+    def strict_twin(self):
+        """A second handle on the same device with the same weights in split-bf16 arithmetic (precision 1): what a call
+        is re-run on when the 16-bit vocoder reports a clamped activation (VFX_FLAG_F16_SATURATED)."""
+        if self._strict is None:
+            cfg = {f[0]: getattr(self.cfg, f[0]) for f in self.cfg._fields_}
+            cfg = {k: (list(v) if hasattr(v, "__len__") else v) for k, v in cfg.items()}
+            cfg["precision"] = 1
+            twin = Engine(self.device, config=cfg)
+            for model, (sd, prefix) in self._state.items():
+                twin.load_state_dict(model, sd, prefix)
+            self._strict = twin
+        return self._strict
 
     def set_mel_filterbank(self, fb):
         self.load_state_dict(MODEL_FRONTEND, {"mel.fb": fb})

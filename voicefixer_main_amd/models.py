@@ -154,9 +154,27 @@ class Vocoder:
 
     def __call__(self, mel, cuda=None):
         assert mel.size()[-1] == 128
-        return self.engine.vocoder(mel[:, 0])[:, None]
+        out = self.engine.vocoder(mel[:, 0])
+        if self.engine.precision == 2:
+            out = _rerun_if_saturated(self.engine, out, lambda e: e.vocoder(mel[:, 0]))
+        return out[:, None]
 
     forward = __call__
+
+
+def _rerun_if_saturated(engine, out, call):
+    """16-bit vocoder (precision 2): an activation beyond the fp16 range is clamped by the kernels and reported through
+    a sticky device flag.  Such a call is re-run on the split-bf16 twin of the engine, so the mode is never silently
+    wrong on weights whose activations do not fit fp16 (costs one device sync per call, like `to_log`'s assert)."""
+    import warnings
+    from . import _lib
+    flags = engine.take_flags()
+    if flags & _lib.FLAG_NEGATIVE_INPUT:
+        raise AssertionError("to_log: input has negative values")
+    if flags & _lib.FLAG_F16_SATURATED:
+        warnings.warn("16-bit vocoder: an activation left the fp16 range; this call is re-run with split-bf16 operands")
+        out = call(engine.strict_twin())
+    return out
 
 
 def fold_weight_norm(sd):
@@ -338,7 +356,10 @@ class VoiceFixer(_Base):
     def restore(self, wav, unify_energy=False):
         """Fused handler() segment body: wav (B,1,L) or (B,L) -> restored wav of the same shape."""
         squeeze = wav.dim() == 3
-        out = self.engine.restore_gsr(wav[:, 0] if squeeze else wav, unify_energy=unify_energy)
+        x = wav[:, 0] if squeeze else wav
+        out = self.engine.restore_gsr(x, unify_energy=unify_energy)
+        if self.engine.precision == 2:
+            out = _rerun_if_saturated(self.engine, out, lambda e: e.restore_gsr(x, unify_energy=unify_energy))
         return out[:, None] if squeeze else out
 
 
