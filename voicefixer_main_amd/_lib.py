@@ -9,7 +9,7 @@ import subprocess
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvfx.so")
+LIB_PATH = os.environ.get("VFX_LIB_PATH") or os.path.join(HERE, "libvfx.so")   # VFX_LIB_PATH: ablation builds (scripts/)
 CSRC = os.path.join(HERE, "csrc")
 
 VFX_MAX_STAGES = 8

@@ -586,6 +586,8 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     for (auto& q : rb) {
       q.x = rebase(q.x);
       q.y = const_cast<float*>(rebase(q.y));
+      if (q.xa) q.xa = rebase(q.xa);
+      if (q.ya) q.ya = const_cast<float*>(rebase(q.ya));
       q.flags = h->d_flags;
     }
     if (!plan.dev_rb) plan.dev_rb = static_cast<ResBlockParams*>(plan.blob.alloc(rb.size() * sizeof(ResBlockParams)));
@@ -1149,7 +1151,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       for (int s2 = 0; s2 < d.nseg; ++s2) K += d.seg[s2].ntaps * d.seg[s2].C;
       char kname[64];
       if (d.nseg == 0) {  // fused ResStack layer
-        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.Cout == 128 ? 8 : 4, d.hionly ? " f16" : "");
+        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.Cout >= 128 ? 8 : 4, d.hionly ? " f16" : "");
       } else {
         bool elu = false;
         for (int s2 = 0; s2 < d.nseg; ++s2) elu = elu || d.seg[s2].act == ACT_ELU;

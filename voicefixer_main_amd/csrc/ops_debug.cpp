@@ -99,7 +99,54 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
     float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, h_f16 ? 3 : pmode));
     float* db1 = sc.blob.upload(b1, C);
     float* db2 = sc.blob.upload(b2, C);
-    if (fused) {
+    if (fused && h->cfg.precision == 2 && resblock_act_supported(C)) {
+      // wide fused layer of the 16-bit mode: conv1 reads xa = fp16(LeakyReLU(x)), built here on the host
+      std::vector<float> hx((size_t)B * T * C);
+      VFX_HIP(hipMemcpy(hx.data(), x, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
+      std::vector<_Float16> ha(hx.size());
+      for (size_t i = 0; i < hx.size(); ++i) {
+        const float v = hx[i] > 0.f ? hx[i] : hx[i] * slope;
+        ha[i] = (_Float16)std::min(std::max(v, -65504.f), 65504.f);
+      }
+      void* dxa = sc.blob.alloc(ha.size() * sizeof(_Float16));
+      VFX_HIP(hipMemcpy(dxa, ha.data(), ha.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+      float* dya = static_cast<float*>(sc.blob.alloc(ha.size() * sizeof(_Float16)));
+      ResBlockParams rp{};
+      rp.asrc = 1;
+      rp.tile_m = resblock_act_tile();
+      rp.x = x;
+      rp.xa = static_cast<const float*>(dxa);
+      rp.y = y;
+      rp.ya = dya;
+      rp.act_slope = slope;
+      rp.w1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, 3));
+      rp.w2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, 3));
+      rp.b1 = db1;
+      rp.b2 = db2;
+      rp.slope = slope;
+      rp.B = B;
+      rp.T = T;
+      rp.C = C;
+      rp.hionly = 1;
+      rp.flags = h->d_flags;
+      rp.dil = dil;
+      plan_resblock(rp);
+      ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
+      VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
+      launch_resblock(rp, d, s);
+      // ya must be fp16(LeakyReLU(y)): checked here so that the test sees a failure as an error of the call
+      VFX_HIP(hipStreamSynchronize(s));
+      std::vector<float> hy(hx.size());
+      std::vector<_Float16> hya(hx.size());
+      VFX_HIP(hipMemcpy(hy.data(), y, hy.size() * sizeof(float), hipMemcpyDeviceToHost));
+      VFX_HIP(hipMemcpy(hya.data(), dya, hya.size() * sizeof(_Float16), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < hy.size(); ++i) {
+        const float v = hy[i] > 0.f ? hy[i] : hy[i] * slope;
+        const _Float16 e = (_Float16)std::min(std::max(v, -65504.f), 65504.f);
+        VFX_CHECK((float)e == (float)hya[i], "vfx_op_resblock: activated output differs from fp16(LeakyReLU(y)) at element %zu (%g vs %g)",
+                  i, (double)(float)hya[i], (double)(float)e);
+      }
+    } else if (fused) {
       VFX_CHECK(split && resblock_supported(C), "vfx_op_resblock: the fused kernel needs precision 1 or 2 and C = 64 or 128");
       ResBlockParams rp{};
       rp.x = x;

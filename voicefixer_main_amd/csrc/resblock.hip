@@ -64,6 +64,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
   constexpr int NT1 = KT * NCH;       // taps of conv1 (chunk-major); conv2 has as many
   constexpr int LDO = C + 4;          // staged output row (floats)
   constexpr int OTAB_OFF = CBM * LDO * 4;
+  // The residual: the epilogue's re-read of x finds its lines evicted from L2 (the HBM-bound C = 64 stack moves 5.0 GB per
+  // layer through the fabric against 3.64 GB of tensors, a fifth of it this re-read).  Where registers allow (C = 64: 3
+  // waves per SIMD, 168 VGPRs) every thread keeps the raw values it fetched for the patch (48 registers) and adds them to
+  // the staged conv2 result in LDS: x is read from memory once.
+  constexpr bool KEEPRES = HI && !G2 && C == 64 && NW == 4;  // (split-bf16 mode: 168 VGPRs are not enough, it keeps the re-read)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = reinterpret_cast<char*>(smem);
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
     }
   };
   const int nq = (P + RG - 1) / RG;
+  f32x4 keep[KEEPRES ? NCH : 1][KEEPRES ? NG : 1];  // raw x of this thread's patch pixels, all chunks
   auto transform_patch = [&](int dst, int c) __attribute__((always_inline)) {
     char* row0 = lds + dst + lr * CROW;
     f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};  // 2-D mode: bn1 of this thread's 4 channels
@@ -167,7 +173,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
     bool f16_sat = false;  // 16-bit mode: a value left the fp16 range and was clamped (reported per patch)
 #pragma unroll
     for (int q = 0; q < NG; ++q)
-      if (q * RG < 128 || q < nq) raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
+      if (q * RG < 128 || q < nq) {
+        raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
+        if constexpr (KEEPRES) keep[c][q] = raw[q];
+      }
 #pragma unroll
     for (int q = 0; q < NG; ++q)
       if (q * RG < 128 || q < nq) {
@@ -201,12 +210,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
   };
 
   // ---- MFMA step: 32 channels of one tap; A rows `row[a]` of an LDS image with `stride` bytes per row ------
-  auto mma = [&](const BFrag& R, const char* img_base, int stride, const int (&row)[WM]) __attribute__((always_inline)) {
+  // `chunk` >= 0: the image is h (rows of NCH 128-byte chunks): chunk c of row r sits at chunk position c ^ (r & 1).  A row
+  // stride that is a multiple of 256 bytes puts every row on the same half of the 64 LDS banks, and rows r, r + 1 share
+  // their swizzle key: without the parity swap the fragment reads of conv2 are 2-way bank conflicts (measured: a third of
+  // the LDS cycles of the kernel).  Patch rows (128-byte stride) alternate halves by themselves: chunk = -1.
+  auto mma = [&](const BFrag& R, const char* img_base, int stride, const int (&row)[WM], int chunk) __attribute__((always_inline)) {
     const char* base[WM];
     int key[WM];
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
       base[a] = img_base + row[a] * stride;
+      if (chunk >= 0) base[a] += (NCH > 1 ? (chunk ^ (row[a] & 1)) : chunk) * CROW;
       key[a] = swz_key(row[a]);
     }
     if constexpr (HI) {
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
       int rows[WM];
 #pragma unroll
       for (int a = 0; a < WM; ++a) rows[a] = arow1[a] + (G2 ? p.poff9[k] : p.poff[k]);
-      mma(ring(g), lds + (c & 1) * CPATCH, CROW, rows);
+      mma(ring(g), lds + (c & 1) * CPATCH, CROW, rows, -1);
       __builtin_amdgcn_sched_barrier(0);
     }
     drain();
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
     const int m = (wm * WM + a) * 32 + l31;
-    char* rowp = lds + H_OFF + m * HROW + wn * CROW + 8 * lh;
+    char* rowp = lds + H_OFF + m * HROW + (NCH > 1 ? (wn ^ (m & 1)) : wn) * CROW + 8 * lh;  // chunk parity swap: see mma()
     const int key = (m >> 1) & 7;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
         const int r = arow2[a] + (G2 ? p.hoff9[k] : k - 1);
         rows[a] = r < 0 ? 0 : (r > CBM - 1 ? CBM - 1 : r);  // clamped rows only feed outputs that are masked anyway
       }
-      mma(ring(g), lds + H_OFF + c * CROW, HROW, rows);
+      mma(ring(g), lds + H_OFF, HROW, rows, c);
       __builtin_amdgcn_sched_barrier(0);
     }
   drain();
@@ -383,6 +397,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
           f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
     }
   __syncthreads();
+  if constexpr (KEEPRES) {
+    // + x from the registers: patch pixel pr is the input sample of h pixel m = pr - d (1-D) or, folded, of the pixel one
+    // patch row up -- every staged (row, 4 channels) is touched by exactly one thread
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const int pr = lr + RG * q;
+      int m;
+      if (p.fold) {
+        const int pi = pr / PW, pj = pr - pi * PW;
+        m = (pi >= 1 && pi <= TH) ? (pi - 1) * W1 + pj : -1;
+      } else {
+        m = pr - d;
+      }
+      if (pr < P && m >= 0 && m < CBM) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          f32x4* s4 = reinterpret_cast<f32x4*>(smem + m * LDO + c * 32 + 4 * cg);
+          *s4 = *s4 + keep[c][q];
+        }
+      }
+    }
+    __syncthreads();
+  }
   {
     constexpr int V = C / 4, RPP = NTHR / V, NPASS = CBM / RPP;
     const int c4 = tid % V, r0 = tid / V;
@@ -396,7 +433,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
     }
 #pragma unroll
     for (int q = 0; q < NPASS; ++q)
-      res[q] = *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * C + 4 * c4);
+      res[q] = KEEPRES ? f32x4{0.f, 0.f, 0.f, 0.f}  // already added in LDS
+                       : *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * C + 4 * c4);
 #pragma unroll
     for (int q = 0; q < NPASS; ++q)
       if (opix[q] >= 0) *(VFX_GLOBAL f32x4*)(p.y + (int64_t)opix[q] * C + 4 * c4) = val[q] + res[q];
@@ -459,24 +497,28 @@ void plan_block2d(ResBlockParams& p) {
 
 // Fills the tile geometry of a fused ResStack layer (B, T, C, dil must be set).
 void plan_resblock(ResBlockParams& p) {
-  VFX_CHECK(resblock_supported(p.C), "resblock: C=%d is not supported", p.C);
+  VFX_CHECK(p.asrc ? resblock_act_supported(p.C) : resblock_supported(p.C), "resblock: C=%d is not supported", p.C);
   const int d = p.dil;
-  if (128 + 2 * d <= kPatchMaxRows) {
+  const int MT = p.tile_m ? p.tile_m : CBM;  // h positions per tile (resblock_act: 64 or 128)
+  const int PR = MT + 64;                    // patch rows per buffer (= kPatchMaxRows for MT = 128)
+  VFX_CHECK(MT == 64 || MT == 128, "resblock: tile of %d positions", MT);
+  p.tile_m = MT;
+  if (MT + 2 * d <= PR) {
     p.fold = 0;
     p.TH = 1;
-    p.W1 = 128;
-    p.TWo = 126;
+    p.W1 = MT;
+    p.TWo = MT - 2;
     p.tiles_h = 1;
     p.tiles_w = (p.T + p.TWo - 1) / p.TWo;
-    p.PW = 128 + 2 * d;
+    p.PW = MT + 2 * d;
     p.P = p.PW;
     for (int k = 0; k < 3; ++k) p.poff[k] = k * d;
   } else {
-    // rows of d samples; h tile TH x (TW + 2) <= 128 pixels, x patch (TH + 2) x (TW + 2) <= kPatchMaxRows
+    // rows of d samples; h tile TH x (TW + 2) <= MT pixels, x patch (TH + 2) x (TW + 2) <= PR
     p.fold = 1;
     const int TW = d >= 16 ? 16 : d;
     p.W1 = TW + 2;
-    p.TH = std::min(128 / p.W1, kPatchMaxRows / p.W1 - 2);
+    p.TH = std::min(MT / p.W1, PR / p.W1 - 2);
     p.TWo = TW;
     const int rows = (p.T + d - 1) / d;
     p.tiles_h = (rows + p.TH - 1) / p.TH;
@@ -485,11 +527,15 @@ void plan_resblock(ResBlockParams& p) {
     p.P = (p.TH + 2) * p.W1;
     for (int k = 0; k < 3; ++k) p.poff[k] = k * p.W1;
   }
-  VFX_CHECK(p.P <= kPatchMaxRows && p.TH * p.W1 <= CBM && p.TH >= 1, "resblock: bad tile geometry (dil=%d)", d);
+  VFX_CHECK(p.P <= PR && p.TH * p.W1 <= MT && p.TH >= 1, "resblock: bad tile geometry (dil=%d)", d);
   VFX_CHECK((int64_t)p.B * p.T * p.C * 4 < ((int64_t)1 << 32) - 4096, "resblock: tensor exceeds 4 GiB");
 }
 
 void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
+  if (hp.asrc) {
+    launch_resblock_act(hp, dparams, stream);
+    return;
+  }
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock: bad grid");
   if (hp.geo2d) {

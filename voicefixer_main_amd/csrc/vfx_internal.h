@@ -180,6 +180,14 @@ struct ResBlockParams {
   int poff[3];      // patch row offset of conv1's taps
   int hionly;       // fp16 operands in the hi halves only, cf. TapConvParams::hionly
   int* flags;       // the handle's sticky device flags (VFX_FLAG_F16_SATURATED); may be NULL
+  // Wide stacks of the 16-bit mode (resblock_act.hip, C = 256): the trunk travels in two forms -- conv1 reads the
+  // activated fp16 tensor xa = fp16(LeakyReLU(x)) (2 bytes per element), x stays the raw residual; besides y the kernel
+  // writes ya = fp16(LeakyReLU(y, act_slope)) for the next consumer (NULL: not needed).  Weights: pack_conv mode 3.
+  int asrc;
+  int tile_m;       // h positions per tile: 0 = 128 (k_resblock); resblock_act: 64 or 128 (resblock_act_tile())
+  const float* xa;
+  float* ya;
+  float act_slope;
   // 2-D ConvBlockRes mode (plan_block2d): x, y are (B, H, W, C), both convolutions 3x3, folded BatchNorm affines
   int geo2d, H, W;
   const float* sc1;  // bn1 scale / shift [C]: prologue of conv1
@@ -190,6 +198,9 @@ struct ResBlockParams {
   int hoff9[9];      // conv2: h row offset of tap (dy, dx)
 };
 bool resblock_supported(int C);
+bool resblock_act_supported(int C);
+int resblock_act_tile();
+void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 bool block2d_supported(int C);
 void plan_resblock(ResBlockParams& p);
 void plan_block2d(ResBlockParams& p);

@@ -227,6 +227,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     const VocConvW& up = W->up[st];
     const int Tout = Tlen * s;
     const bool fuse = stack_fused(cfg, up.cout);
+    // 16-bit mode, C = 256: fused as well, on the two-form trunk (resblock_act.hip); `VFX_NO_FUSE_ACT`: two launches
+    const bool fuse_act = !fuse && cfg.precision == 2 && resblock_act_supported(up.cout) && !getenv("VFX_NO_FUSE_ACT");
     const bool last_stage = st + 1 == cfg.voc_n_stages;
     Forms y;
     y.raw = pb.alloc_f((int64_t)B * Tout * up.cout);
@@ -307,6 +309,36 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         free_forms(cur);
         cur = Forms{};
         cur.raw = y2;
+      } else if (fuse_act) {
+        // one launch per layer on the trunk in both forms: conv1 reads the activated fp16 trunk, the residual is the raw
+        // one; the next trunk is written raw and -- unless it only feeds the vocoder tail -- activated for its consumer
+        // (the next layer: LeakyReLU(res_slope); the next upsampler: LeakyReLU(up_slope))
+        const bool last_layer = li + 1 == nlayers;
+        Forms y2;
+        y2.raw = pb.alloc_f((int64_t)B * Tlen * up.cout);
+        if (!(last_layer && last_stage)) y2.act = pb.alloc_f(act_floats((int64_t)B * Tlen * up.cout));
+        VFX_CHECK(layer.first.mode == 3 && layer.second.mode == 3, "vocoder plan: the fused wide layer needs fp16 64-channel weights");
+        ResBlockParams rp{};
+        rp.asrc = 1;
+        rp.tile_m = resblock_act_tile();
+        rp.x = rel_ptr(cur.raw);
+        rp.xa = rel_ptr(cur.act);
+        rp.y = const_cast<float*>(rel_ptr(y2.raw));
+        rp.ya = y2.act != kNone ? const_cast<float*>(rel_ptr(y2.act)) : nullptr;
+        rp.act_slope = last_layer ? cfg.voc_up_slope : cfg.voc_res_slope;
+        rp.w1 = layer.first.w;
+        rp.w2 = layer.second.w;
+        rp.b1 = layer.first.bias;
+        rp.b2 = layer.second.bias;
+        rp.slope = cfg.voc_res_slope;
+        rp.B = B;
+        rp.T = Tlen;
+        rp.C = up.cout;
+        rp.dil = dil;
+        rp.hionly = 1;
+        pb.add_resblock(rp);
+        free_forms(cur);
+        cur = y2;
       } else {
         // conv1 reads the activated trunk and writes h activated for conv2; conv2 adds the raw trunk and writes the
         // next trunk: both forms inside the stack, after its last layer only what the consumer reads (the next
