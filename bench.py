@@ -166,8 +166,9 @@ def cpu_baseline(kind, clips, n_clips, threads):
 # ---------------------------------------------------------------------------------------------------------
 def measure_conv_roofline(eng, step, args, traffic):
     """HIP events around every convolution launch (on the launch stream) over K more steps of the same workload;
-    per-kernel totals come from the per-launch table libvfx writes (VFX_PROFILE_DUMP).  The roofline object describes
-    the kernel with the largest share of GPU time; achieved = algorithmic flops of its launches / their durations."""
+    per-kernel totals come from the per-launch table libvfx writes (VFX_PROFILE_DUMP: duration, algorithmic flops and
+    algorithmic HBM bytes of every launch).  The roofline object describes the kernel with the largest share of GPU time
+    against the roofline that bounds it (its algorithmic intensity vs the ridge of the chip); both lines are reported."""
     import csv
     keep = os.environ.get("VFX_PROFILE_DUMP")   # a caller-provided path keeps the per-launch table
     dump = keep or tempfile.NamedTemporaryFile(prefix="vfx_convs_", suffix=".csv", delete=False).name
@@ -184,27 +185,40 @@ def measure_conv_roofline(eng, step, args, traffic):
     per = {}
     for r in rows:
         k = r["kernel"].replace(";", ",")
-        t = per.setdefault(k, [0, 0.0, 0.0])
+        t = per.setdefault(k, [0, 0.0, 0.0, 0.0])
         t[0] += 1
         t[1] += float(r["ms"])
         t[2] += float(r["tflops"]) * float(r["ms"]) * 1e9   # flops of the launch
+        t[3] += float(r.get("bytes", 0) or 0)               # algorithmic HBM bytes of the launch
     dom = max(per, key=lambda k: per[k][1])
-    cnt, kms, kfl = per[dom]
+    cnt, kms, kfl, kby = per[dom]
     tflops = kfl / (kms * 1e-3) / 1e12
+    gbs = kby / (kms * 1e-3) / 1e9
     split = args.precision >= 1
     peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     plain = "f16" in dom.split(">")[-1]      # a 16-bit launch of the precision-2 vocoder: one MFMA per product
     per_product = 1 if (plain or not split) else 3
     tr = (traffic or {}).get("kernels", {}).get(dom)
-    return {
-        "bound": "mfma",
+    # Which roofline bounds the kernel: its algorithmic intensity (flops the MFMA pipe must issue per algorithmic HBM
+    # byte) against the ridge of the chip, peak MFMA rate / peak HBM rate.
+    intensity = kfl * per_product / max(kby, 1.0)
+    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+    hbm_bound = intensity < ridge
+    mfma_line = {"achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+                 # achieved counts ALGORITHMIC flops (2*M*N*K once); in split-bf16 mode the kernel issues 3 bf16 MFMAs per
+                 # product, so `frac` is bounded by 1/3 and mfma_issue_frac is the share of the MFMA pipe actually used
+                 "mfma_issue_frac": round(tflops * per_product / peak, 4)}
+    hbm_line = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "algorithmic_bytes_per_launch": round(kby / max(cnt, 1))}
+    head = dict(hbm_line if hbm_bound else mfma_line)
+    return dict({
+        "bound": "hbm" if hbm_bound else "mfma",
         "kernel": "%s (%s)" % (dom, "1 x v_mfma_f32_32x32x16_f16 per product (fp16 operands), fp32 accumulate" if plain
                                else "3 x v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
                                if split else "v_mfma_f32_32x32x2_f32"),
-        "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
-        # achieved counts ALGORITHMIC flops (2*M*N*K once); in split-bf16 mode the kernel issues 3 bf16 MFMAs per
-        # product, so `frac` is bounded by 1/3 and mfma_issue_frac is the share of the MFMA pipe actually used
-        "mfma_issue_frac": round(tflops * per_product / peak, 4),
+    }, **head, **{
+        "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+        "mfma_roofline": mfma_line, "hbm_roofline": hbm_line,
         "traffic": tr["bytes_per_launch"] if tr else None,
         "traffic_unit": "HBM bytes per launch: 2 * FETCH_SIZE + WRITE_SIZE of this run's rocprofv3 PMC passes",
         "traffic_detail": tr,
@@ -216,11 +230,12 @@ def measure_conv_roofline(eng, step, args, traffic):
         "share_of_conv_time": round(kms / max(ms, 1e-9), 4),
         "all_conv_kernels": {k: {"launches_per_step": v[0] // steps, "ms_per_step": round(v[1] / steps, 3),
                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                                 "algorithmic_gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1),
                                  "hbm_bytes_per_launch": ((traffic or {}).get("kernels", {}).get(k) or {}).get("bytes_per_launch")}
                              for k, v in sorted(per.items())},
         "all_conv_ms_per_step": round(ms / steps, 3),
         "all_conv_algorithmic_gflop_per_step": round(fl / steps / 1e9, 1),
-    }
+    })
 
 
 def measure_hbm_stages(eng, B, L, reps=20):

@@ -2,6 +2,7 @@
 
 k_conv<BN, ELU, SPLIT, ABL, RING, HI>  ->  "k_conv<BN, ELU, SPLIT>" (+ " f16" for the 16-bit launches of precision 2)
 k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
+k_resblock_act<C, NW, MT>              ->  "k_resblock<C, NW> f16"
 """
 import re
 
@@ -14,6 +15,8 @@ def short(n, width=40):
     if name == "k_conv" and len(args) >= 3:
         hi = len(args) >= 6 and args[5] == "true"
         return "k_conv<%s, %s, %s>%s" % (args[0], args[1], args[2], " f16" if hi else "")
+    if name == "k_resblock_act" and len(args) >= 2:      # the fused wide layer of the 16-bit mode
+        return "k_resblock<%s, %s> f16" % (args[0], args[1])
     if name == "k_resblock" and len(args) >= 2:
         hi = len(args) >= 3 and args[2] == "true"
         return "k_resblock<%s, %s>%s" % (args[0], args[1], " f16" if hi else "")

@@ -433,16 +433,47 @@ static void debug_scan(const Plan* pl, const char* what, size_t idx, const float
                    (long long)bad, (long long)n);
 }
 
+// Algorithmic HBM bytes of a launch (SURVEY.md section 8d accounting: every tensor the launch must read or write,
+// once): sources, residual, outputs; weights are L2-resident and not counted.
+static double conv_algo_bytes(const TapConvParams& q) {
+  const double in_px = (double)q.B * q.in_img_stride, out_px = (double)q.B * q.out_img_stride;
+  double b = 0;
+  if (q.nphase > 1) {
+    b += in_px * q.seg[0].C * ((q.hionly && q.seg[0].src_act) ? 2.0 : 4.0);  // the phases share one source
+  } else {
+    for (int s2 = 0; s2 < q.nseg; ++s2) b += in_px * q.seg[s2].C * ((q.hionly && q.seg[s2].src_act) ? 2.0 : 4.0);
+  }
+  if (q.residual) b += out_px * q.Cout * 4.0;
+  if (q.out) b += out_px * q.Cout * 4.0;
+  if (q.out_act) b += out_px * q.Cout * (q.hionly ? 2.0 : 4.0);
+  return b;
+}
+static double resblock_algo_bytes(const ResBlockParams& q) {
+  const double n = (double)q.B * (q.geo2d ? (double)q.H * q.W : (double)q.T) * q.C;
+  return n * 8.0 + (q.asrc ? n * 2.0 + (q.ya ? n * 2.0 : 0.0) : 0.0);  // x in, y out (+ the fp16 forms of the two-form trunk)
+}
+
 void PlanBuilder::add_conv(TapConvParams p) {
   p.split = h->cfg.precision != 0;
   finish_params(p);
+  p.ksplit = choose_ksplit(p);
+  size_t ws_off = ~size_t(0);
+  if (p.ksplit > 1) {  // the partial tiles live in the arena for the duration of this op
+    ws_off = alloc_f((int64_t)p.ksplit * p.B * p.out_img_stride * p.Cout);
+    p.ws = const_cast<float*>(rel_ptr(ws_off));
+  } else {
+    p.ksplit = 0;
+  }
   const size_t idx = plan->host_params.size();
   plan->host_params.push_back(p);
   plan->conv_flops += conv_flops(p);
   plan->n_conv += 1;
   Plan* pl = plan;
   plan->ops.push_back([pl, idx](const RunCtx& c) {
-    auto launch = launch_conv;
+    auto launch = [pl, idx](const TapConvParams& hp, const TapConvParams* dp, hipStream_t st) {
+      launch_conv(hp, dp, st);
+      if (hp.ksplit > 1) launch_splitk_reduce(pl->abs_params[idx], st);  // the same stream: ordered behind the partial tiles
+    };
     if (c.prof && c.prof->enabled) {
       hipEvent_t a, b;
       VFX_HIP(hipEventCreate(&a));
@@ -452,6 +483,7 @@ void PlanBuilder::add_conv(TapConvParams p) {
       VFX_HIP(hipEventRecord(b, c.stream));
       c.prof->events.push_back({a, b});
       c.prof->flops.push_back(conv_flops(pl->host_params[idx]));
+      c.prof->bytes.push_back(conv_algo_bytes(pl->host_params[idx]));
       c.prof->bn.push_back(pl->host_params[idx].Cout);
       c.prof->desc.push_back(pl->host_params[idx]);
     } else {
@@ -466,6 +498,7 @@ void PlanBuilder::add_conv(TapConvParams p) {
       debug_scan(pl, "conv out_act", idx, q.out_act, n, q.M, q.Cout, K, c.stream);
     }
   });
+  if (ws_off != ~size_t(0)) free(ws_off);
 }
 
 void PlanBuilder::add_conv_phased(TapConvParams p, const std::vector<TapSeg>& phases) {
@@ -505,6 +538,7 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
       VFX_HIP(hipEventRecord(b, c.stream));
       c.prof->events.push_back({a, b});
       c.prof->flops.push_back(resblock_flops(hp));
+      c.prof->bytes.push_back(resblock_algo_bytes(hp));
       c.prof->bn.push_back(hp.C);
       TapConvParams d{};
       d.M = hp.B * hp.T;
@@ -559,6 +593,7 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     if (p.residual) p.residual = rebase(p.residual);
     if (p.out) p.out = const_cast<float*>(rebase(p.out));
     if (p.out_act) p.out_act = const_cast<float*>(rebase(p.out_act));
+    if (p.ws) p.ws = const_cast<float*>(rebase(p.ws));
     p.flags = h->d_flags;
     const size_t pidx = &p - abs.data();
     if (p.nphase > 1) {  // one stage table per phase, built from that phase's segment on the common patch geometry
@@ -581,6 +616,7 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     plan.dev_params = static_cast<TapConvParams*>(plan.blob.alloc(abs.size() * sizeof(TapConvParams)));
   if (!abs.empty())
     VFX_HIP(hipMemcpy(plan.dev_params, abs.data(), abs.size() * sizeof(TapConvParams), hipMemcpyHostToDevice));
+  plan.abs_params = abs;  // host copy with absolute pointers (split-K reduce launches)
   if (!plan.host_rb.empty()) {
     std::vector<ResBlockParams> rb = plan.host_rb;
     for (auto& q : rb) {
@@ -1128,6 +1164,7 @@ int vfx_profile_begin(vfx_handle* h) {
   h->prof.enabled = true;
   h->prof.events.clear();
   h->prof.flops.clear();
+  h->prof.bytes.clear();
   h->prof.bn.clear();
   VFX_API_END
 }
@@ -1141,7 +1178,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
   double ms = 0, fl = 0;
   FILE* dump = nullptr;
   if (const char* path = getenv("VFX_PROFILE_DUMP")) dump = fopen(path, "w");
-  if (dump) fprintf(dump, "idx,kernel,M,Cout,K,nseg,ntaps0,C0,Wi,sw,ms,tflops\n");
+  if (dump) fprintf(dump, "idx,kernel,M,Cout,K,nseg,ntaps0,C0,Wi,sw,ms,tflops,bytes\n");
   for (size_t i = 0; i < h->prof.events.size(); ++i) {
     float t = 0.f;
     VFX_HIP(hipEventElapsedTime(&t, h->prof.events[i].first, h->prof.events[i].second));
@@ -1158,8 +1195,8 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
         snprintf(kname, sizeof(kname), "k_conv<%d; %s; %s>%s", conv_block_n(d), elu ? "true" : "false", d.split ? "true" : "false",
                  d.hionly ? " f16" : "");
       }
-      fprintf(dump, "%zu,%s,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i, kname, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C,
-              d.Wi, d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12);
+      fprintf(dump, "%zu,%s,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f,%.0f\n", i, kname, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C,
+              d.Wi, d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12, h->prof.bytes[i]);
     }
     ms += t;
     fl += h->prof.flops[i];
@@ -1173,6 +1210,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
   if (total_flops) *total_flops = fl;
   h->prof.events.clear();
   h->prof.flops.clear();
+  h->prof.bytes.clear();
   h->prof.bn.clear();
   h->prof.enabled = false;
   VFX_API_END

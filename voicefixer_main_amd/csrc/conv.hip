@@ -85,7 +85,6 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   // The stage table is read-only for the whole launch: address it in the constant address space so
   // that every descriptor field is a scalar load.
   typedef const ConvStage VFX_CONST* StageTab;
-  const int nstages = p.nstages;
   const int tid = threadIdx.x;
   const int n_tiles = p.Cout / BN;
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only), so
@@ -97,11 +96,16 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  // split-K: block (tile, ks) walks stage range ks of the launch (TapConvParams::ksplit)
+  const int KS = p.ksplit > 1 ? p.ksplit : 1;
+  const int ks = tile % KS;
+  tile /= KS;
   const int n0 = (tile % n_tiles) * BN;
   // phased launch: this block's couts belong to phase n0 / cout_phase -- own stage table, own weight tensor
   const int phase = p.nphase > 1 ? n0 / p.cout_phase : 0;
   const int n0w = p.nphase > 1 ? n0 - phase * p.cout_phase : n0;  // first cout inside the phase's weight tensor
-  const StageTab stages = (StageTab)(uintptr_t)p.stages + phase * nstages;
+  const int st_lo = (int)((int64_t)ks * p.nstages / KS), st_hi = (int)((int64_t)(ks + 1) * p.nstages / KS);
+  const StageTab stages = (StageTab)(uintptr_t)p.stages + phase * p.nstages + st_lo;
   int mt = tile / n_tiles;  // spatial tile: (image, tile row, tile col), col fastest
   const int tj = mt % p.tiles_w;
   mt /= p.tiles_w;
@@ -351,6 +355,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   constexpr int AHEAD = RING - 1;
   constexpr int WL = HI32 ? 2 : 4;  // weight loads per tap and wave
   BFrag R0 = {}, R1 = {}, R2 = {};
+  const int nstages = st_hi - st_lo;  // stages of this block
   const int last = nstages - 1;
   // Cursor state lives in scalar registers; table fields are re-read only when a cursor enters a new stage, and the
   // tap descriptor of the next step is loaded at the end of the current one (no scalar-load latency inside a step).
@@ -454,7 +459,8 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       for (int r = 0; r < 16; ++r) keep += acc[a][0][r];
     if (keep == 12345.678f) p.out_act[tid] = keep;  // keeps the accumulators live
   } else {
-    conv_epilogue<BN, WM, 1, WAVES_N, SPLIT, EPI_HALVES>(p, smem, otab, acc, n0);
+    float* partial = KS > 1 ? p.ws + (int64_t)ks * ((int64_t)p.B * p.out_img_stride * p.Cout) : nullptr;
+    conv_epilogue<BN, WM, 1, WAVES_N, SPLIT, EPI_HALVES>(p, smem, otab, acc, n0, partial);
   }
 }
 
@@ -525,7 +531,9 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
     for (int s = 0; s < hp.nseg; ++s)
       VFX_CHECK(hp.seg[s].act == ACT_ELU, "conv: ELU cannot be mixed with other prologues in one launch");
   const int BN = conv_block_n(hp);
-  const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w * (hp.Cout / BN);
+  const int KS = hp.ksplit > 1 ? hp.ksplit : 1;
+  VFX_CHECK(KS == 1 || (hp.ws && hp.nphase <= 1 && !hp.hionly && KS <= hp.nstages), "conv: bad split-K launch");
+  const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w * (hp.Cout / BN) * KS;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "conv: bad grid");
 #ifdef VFX_ABLATION_BUILD
   static const int abl = getenv("VFX_ABLATE") ? atoi(getenv("VFX_ABLATE")) : 0;
@@ -552,6 +560,95 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
     if (elu) launch_bn<true, false>(BN, (int)grid, stream, dparams);
     else launch_bn<false, false>(BN, (int)grid, stream, dparams);
   }
+  VFX_HIP(hipGetLastError());
+}
+
+// Split-K decision: depends on the geometry of ONE clip (never on B), so that a clip's result does not depend on the batch it
+// is restored in.  Parallelism of a clip = spatial tiles x 32-cout blocks; below ~128 the launch is cut into up to 8
+// stage ranges of at least 3 stages (27 taps of a 3x3 convolution) each.
+int choose_ksplit(const TapConvParams& p) {
+  if (p.hionly || p.nphase > 1 || p.per_tap || getenv("VFX_NO_SPLITK")) return 1;
+  // the reduce pass rewrites the whole output tensor: only launches that own all of it (not the parity classes of a
+  // transposed convolution, whose launches interleave their pixels)
+  if (p.sh != 1 || p.sw != 1 || p.oh0 != 0 || p.ow0 != 0 || p.Hg != p.Ho || p.Wg != p.Wo) return 1;
+  const int par = p.tiles_h * p.tiles_w * (p.Cout / 32);
+  int s = std::min(8, std::min(p.nstages / 3, 128 / std::max(par, 1)));
+  int pow2 = 1;
+  while (pow2 * 2 <= s) pow2 *= 2;
+  return pow2;
+}
+
+// Sum of the split-K slices (in slice order) + the epilogue of conv_epilogue.h: bias, residual, raw output and / or the
+// activated output for the consumer convolution.  One thread = 8 consecutive channels of one pixel (in split-bf16 mode
+// exactly the 16-byte hi block and the 16-byte lo block of an 8-channel group).
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, int KS, int64_t slice, int64_t ngroups, int Cout,
+                                                        const float* __restrict__ bias, const float* __restrict__ residual,
+                                                        float* __restrict__ out, float* __restrict__ out_act,
+                                                        const float* __restrict__ asc, const float* __restrict__ ash, float slope,
+                                                        int elu) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ngroups) return;
+  const int gpp = Cout >> 3;  // 8-channel groups per pixel
+  const int64_t pix = idx / gpp;
+  const int ch = (int)(idx - pix * gpp) * 8;
+  const int64_t e = pix * Cout + ch;
+  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < KS; ++s) {
+    v0 += *(const VFX_GLOBAL f32x4*)(ws + s * slice + e);
+    v1 += *(const VFX_GLOBAL f32x4*)(ws + s * slice + e + 4);
+  }
+  if (bias) {
+    v0 += *(const VFX_GLOBAL f32x4*)(bias + ch);
+    v1 += *(const VFX_GLOBAL f32x4*)(bias + ch + 4);
+  }
+  if (residual) {
+    v0 += *(const VFX_GLOBAL f32x4*)(residual + e);
+    v1 += *(const VFX_GLOBAL f32x4*)(residual + e + 4);
+  }
+  if (out) {
+    *(VFX_GLOBAL f32x4*)(out + e) = v0;
+    *(VFX_GLOBAL f32x4*)(out + e + 4) = v1;
+  }
+  if (out_act) {
+    float u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = i < 4 ? v0[i] : v1[i - 4];
+      const float t = x * (asc ? asc[ch + i] : 1.f) + (ash ? ash[ch + i] : 0.f);
+      u[i] = elu ? (t > 0.f ? t : expm1f(t)) : fmaxf(t, t * slope);
+    }
+    if constexpr (SPLIT) {
+      unsigned hi[4], lo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u[2 * i], u[2 * i + 1]}, bf16x2));
+        const f32x2 r = {u[2 * i] - __builtin_bit_cast(float, h << 16), u[2 * i + 1] - __builtin_bit_cast(float, h & 0xffff0000u)};
+        hi[i] = h;
+        lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+      }
+      // operand form of a 32-channel chunk: [32 hi bf16 | 32 lo bf16]; this group's 8 hi values are 4 floats at g * 4
+      float* base = out_act + pix * Cout + (ch & ~31) + ((ch & 31) >> 3) * 4;
+      *(VFX_GLOBAL u32x4*)(base) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+      *(VFX_GLOBAL u32x4*)(base + 16) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    } else {
+      *(VFX_GLOBAL f32x4*)(out_act + e) = f32x4{u[0], u[1], u[2], u[3]};
+      *(VFX_GLOBAL f32x4*)(out_act + e + 4) = f32x4{u[4], u[5], u[6], u[7]};
+    }
+  }
+}
+
+void launch_splitk_reduce(const TapConvParams& hp, hipStream_t stream) {
+  const int64_t npix = (int64_t)hp.B * hp.out_img_stride;
+  const int64_t ngroups = npix * (hp.Cout / 8);
+  const int64_t slice = npix * hp.Cout;
+  const unsigned grid = (unsigned)((ngroups + 255) / 256);
+  if (hp.split)
+    hipLaunchKernelGGL(k_splitk_reduce<true>, dim3(grid), dim3(256), 0, stream, hp.ws, hp.ksplit, slice, ngroups, hp.Cout, hp.bias,
+                       hp.residual, hp.out, hp.out_act, hp.act_scale, hp.act_shift, hp.act_slope, hp.act_elu);
+  else
+    hipLaunchKernelGGL(k_splitk_reduce<false>, dim3(grid), dim3(256), 0, stream, hp.ws, hp.ksplit, slice, ngroups, hp.Cout, hp.bias,
+                       hp.residual, hp.out, hp.out_act, hp.act_scale, hp.act_shift, hp.act_slope, hp.act_elu);
   VFX_HIP(hipGetLastError());
 }
 

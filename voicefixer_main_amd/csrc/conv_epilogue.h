@@ -29,7 +29,9 @@ typedef _Float16 ce_f16x2 __attribute__((ext_vector_type(2)));
 
 template <int BN, int WM, int WN, int WAVES_N, bool SPLIT, int HALVES = 1>
 __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* smem, const int* otab,
-                                              ce_f32x16 (&acc)[WM][WN], int n0) {
+                                              ce_f32x16 (&acc)[WM][WN], int n0, float* partial = nullptr) {
+  // partial != nullptr (split-K): the raw accumulators go to that slice of the workspace, nothing else happens here
+  // (k_splitk_reduce adds the slices and applies bias / residual / activation)
   // HALVES = 2: the cout range goes through the staging buffer in two passes (half the LDS: the 16-bit BN = 128 tile
   // then fits three blocks per CU)
   constexpr int BH = BN / HALVES;  // couts per pass
@@ -66,13 +68,19 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
     __syncthreads();
     const int ncol = n0 + hh * BH + 4 * c4;
     ce_f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *(const VFX_CE_GLOBAL ce_f32x4*)(p.bias + ncol);
+    if (p.bias && !partial) bv = *(const VFX_CE_GLOBAL ce_f32x4*)(p.bias + ncol);
     int opix[NPASS];
     ce_f32x4 val[NPASS];
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
       opix[q] = otab[r0 + q * RPP];
       val[q] = *reinterpret_cast<const ce_f32x4*>(smem + (r0 + q * RPP) * LDO + 4 * c4) + bv;
+    }
+    if (partial) {
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q)
+        if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(partial + (int64_t)opix[q] * Cout + ncol) = val[q];
+      continue;
     }
     if (p.residual) {
       ce_f32x4 res[NPASS];

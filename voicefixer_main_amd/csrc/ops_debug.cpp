@@ -30,9 +30,13 @@ void run_one(vfx_handle* h, TapConvParams& p, DeviceBlob& blob, hipStream_t s) {
   ConvStage* ds = static_cast<ConvStage*>(blob.alloc(st.size() * sizeof(ConvStage)));
   VFX_HIP(hipMemcpy(ds, st.data(), st.size() * sizeof(ConvStage), hipMemcpyHostToDevice));
   p.stages = ds;
+  p.ksplit = choose_ksplit(p);
+  if (p.ksplit > 1) p.ws = static_cast<float*>(blob.alloc((size_t)p.ksplit * p.B * p.out_img_stride * p.Cout * sizeof(float)));
+  else p.ksplit = 0;
   TapConvParams* d = static_cast<TapConvParams*>(blob.alloc(sizeof(TapConvParams)));
   VFX_HIP(hipMemcpy(d, &p, sizeof(p), hipMemcpyHostToDevice));
   launch_conv(p, d, s);
+  if (p.ksplit > 1) launch_splitk_reduce(p, s);
 }
 }  // namespace
 

@@ -160,6 +160,14 @@ struct TapConvParams {
   float act_slope;         // LeakyReLU slope in [0, 1] (1 = identity)
   int act_elu;             // 1: ELU instead of LeakyReLU
   int* flags;              // the handle's sticky device flags (VFX_FLAG_F16_SATURATED); may be NULL
+  // Split-K (choose_ksplit): the deep ResUNet levels have a few hundred output pixels per clip and K = 3456 .. 6912 -- a
+  // launch of 100 .. 400 blocks that each walk the whole K range.  ksplit > 1: the stage table is cut into ksplit
+  // consecutive ranges, block (tile, s) accumulates range s and stores its raw fp32 partial tile into slice s of `ws`
+  // ([ksplit][B * out_img_stride][Cout]); k_splitk_reduce adds the slices in order and applies the epilogue (bias,
+  // residual, raw / activated output).  The split depends on the per-clip geometry only, never on the batch size:
+  // results do not depend on how clips are batched.
+  int ksplit;
+  float* ws;
 };
 
 // One fused TFGAN ResStack layer (resblock.hip): y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2.
@@ -212,6 +220,8 @@ double resblock_flops(const ResBlockParams& hp);
 void set_conv1d_geometry(TapConvParams& p, int B, int T, int K, int dil, bool reflect);
 void finish_params(TapConvParams& p);  // fills total_steps, M and the tile / patch geometry, validates
 int count_stages(const TapConvParams& p);
+int choose_ksplit(const TapConvParams& p);  // after finish_params
+void launch_splitk_reduce(const TapConvParams& hp, hipStream_t stream);  // hp: absolute pointers
 void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out);  // p: absolute pointers
 void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
 int conv_block_n(const TapConvParams& hp);
@@ -292,6 +302,7 @@ struct ConvProfile {  // HIP-event timing of every convolution launch (vfx_profi
   bool enabled = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::vector<double> flops;
+  std::vector<double> bytes;  // algorithmic HBM bytes of the launch
   std::vector<int> bn;
   std::vector<TapConvParams> desc;  // fused ResStack layers are described as M = B*T, Cout = C, nseg = 0
 };
@@ -306,6 +317,7 @@ struct RunCtx {
 struct Plan {
   std::vector<std::function<void(const RunCtx&)>> ops;
   std::vector<TapConvParams> host_params;  // arena-relative until bind()
+  std::vector<TapConvParams> abs_params;   // the same with absolute pointers, as uploaded by bind()
   TapConvParams* dev_params = nullptr;
   ConvStage* dev_stages = nullptr;
   std::map<size_t, std::vector<TapSeg>> phase_segs;  // phased launches: host_params index -> per-phase segment
