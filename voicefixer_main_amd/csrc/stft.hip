@@ -15,7 +15,7 @@
 //   when sp/cos/sin are not requested.  (One frame per workgroup, everything re-fetched per frame: 0.30 TB/s.)
 //
 // Inverse (vfx_istft): ONE kernel.  A workgroup owns IH = 8 hops of the overlap-add buffer and runs the frames that
-//   reach into them (IH + floor(2047 / hop) = 12 frames; the 4 halo frames are recomputed by the neighbouring
+//   reach into them (IH + floor(2047 / hop) = 12 frames; IH = 2 for launches too small to fill the chip; the 4 halo frames are recomputed by the neighbouring
 //   workgroup -- their spectra come from L2): Hermitian spectrum -> packed 1024-point complex inverse FFT -> x synthesis
 //   window -> added into the workgroup's slice of the overlap-add buffer IN LDS; at the end every owned sample is
 //   divided by the window sum-of-squares envelope (summed from the window on the fly) and written once.  The
@@ -204,7 +204,8 @@ __global__ __launch_bounds__(128) void k_mel_project(const float* __restrict__ s
 // (same in the in-repo twin tools/dsp/base.py:193-200, `end = start + length`): the L mod hop samples past hop*(T-1) are
 // reconstructed from the tails of the last frames.  Positions whose envelope is tiny are left undivided
 // (librosa.filters.window_sumsquare semantics).
-constexpr int IH = 8;  // hops of the overlap-add buffer a workgroup owns
+// IH = hops of the overlap-add buffer a workgroup owns: 8 (12 frames per workgroup) for large launches, 2 (6 frames, three
+// times the inverse FFTs but a third of the serial chain) when there are too few frames to fill the chip (streaming chunks)
 
 __device__ __forceinline__ void load_spectrum(const float* __restrict__ R, const float* __restrict__ I, int j, float2 xk[4],
                                               float2 xn[4]) {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void load_spectrum(const float* __restrict__ R, const
 __global__ __launch_bounds__(256, 5) void k_istft(const float* __restrict__ re, const float* __restrict__ im,
                                                 const float* __restrict__ window, const float2* __restrict__ tw,
                                                 const float2* __restrict__ rtw, int T, int L, int hop, int groups,
-                                                float* __restrict__ wav) {
+                                                int IH, float* __restrict__ wav) {
   __shared__ float2 z[NC];
   __shared__ float2 twl[NC];
   extern __shared__ __attribute__((aligned(16))) float ola[];  // [IH * hop]
@@ -321,11 +322,12 @@ void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, 
 void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop, float* wav,
                   hipStream_t stream) {
   // groups cover the positions [0, 1024 + L) of the un-trimmed overlap-add buffer
+  const int IH = (int64_t)B * T >= 4096 ? 8 : 2;
   const int span = IH * hop;
   const int groups = (NFFT / 2 + L + span - 1) / span;
   hipLaunchKernelGGL(k_istft, dim3(B * groups), dim3(256), (size_t)span * sizeof(float), stream, re, im, t.window,
                      reinterpret_cast<const float2*>(t.twiddle), reinterpret_cast<const float2*>(t.rtwiddle), T, L, hop,
-                     groups, wav);
+                     groups, IH, wav);
   VFX_HIP(hipGetLastError());
 }
 
