@@ -200,17 +200,16 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The newest committed bench line (profiles/r01_bench_v*.json) carries every key of the bench.py contract,
-    including the `roofline` and `cpu_baseline` objects, with self-consistent numbers."""
-    import glob
+    """The committed bench line of the default workload (profiles/r02_bench_gsr16x10.json) carries every key of the
+    bench.py contract, including the `roofline`, `cpu_baseline` and in-run `parity` objects, with self-consistent numbers."""
     import json
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_bench_v*.json")), key=lambda f: int(re.findall(r"_v(\d+)", f)[0]))
-    d = json.load(open(files[-1]))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_gsr16x10.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["workload"] == "gsr16x10" and "model" not in d["config"]
+    assert d["parity"]["logmel_l1"] < d["parity"]["bar"]["logmel_l1"] and d["parity"]["clips"] >= 1
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
