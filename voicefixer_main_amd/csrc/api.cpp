@@ -450,7 +450,7 @@ static double conv_algo_bytes(const TapConvParams& q) {
 }
 static double resblock_algo_bytes(const ResBlockParams& q) {
   const double n = (double)q.B * (q.geo2d ? (double)q.H * q.W : (double)q.T) * q.C;
-  return n * 8.0 + (q.asrc ? n * 2.0 + (q.ya ? n * 2.0 : 0.0) : 0.0);  // x in, y out (+ the fp16 forms of the two-form trunk)
+  return n * 8.0 + (q.asrc ? n * 2.0 : 0.0) + (q.ya ? n * 2.0 : 0.0);  // x in, y out (+ the fp16 forms: xa in, ya out)
 }
 
 void PlanBuilder::add_conv(TapConvParams p) {

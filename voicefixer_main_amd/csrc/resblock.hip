@@ -436,8 +436,33 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
       res[q] = KEEPRES ? f32x4{0.f, 0.f, 0.f, 0.f}  // already added in LDS
                        : *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * C + 4 * c4);
 #pragma unroll
+    for (int q = 0; q < NPASS; ++q) val[q] += res[q];
+#pragma unroll
     for (int q = 0; q < NPASS; ++q)
-      if (opix[q] >= 0) *(VFX_GLOBAL f32x4*)(p.y + (int64_t)opix[q] * C + 4 * c4) = val[q] + res[q];
+      if (opix[q] >= 0) *(VFX_GLOBAL f32x4*)(p.y + (int64_t)opix[q] * C + 4 * c4) = val[q];
+    if constexpr (HI && !G2) {
+      // 16-bit mode, last layer of a stack: also the activated fp16 form for the upsampler that follows
+      // (ya = fp16(LeakyReLU(y, act_slope)), 2 bytes per element): it then reads half the bytes and does no arithmetic on them
+      if (p.ya) {
+        const float aslope = p.act_slope;
+        const bool even = (tid & 1) == 0;
+        bool f16_sat = false;
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+          f32x4 u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] = fmaxf(val[q][e], val[q][e] * aslope);
+          const unsigned h01 = pack_f16x2(u[0], u[1], f16_sat), h23 = pack_f16x2(u[2], u[3], f16_sat);
+          // quad_perm [1,0,3,2]: the even lane of a pair collects the pair's 8 consecutive channels (16 bytes)
+          const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)h01, 0xB1, 0xf, 0xf, false);
+          const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)h23, 0xB1, 0xf, 0xf, false);
+          const u32x4 w = {h01, h23, g0, g1};
+          if (opix[q] >= 0 && even)
+            *(VFX_GLOBAL f32x4*)(p.ya + (int64_t)opix[q] * (C / 2) + 2 * c4) = __builtin_bit_cast(f32x4, w);
+        }
+        report_f16_saturation(f16_sat, p.flags);
+      }
+    }
   }
 }
 
@@ -450,7 +475,9 @@ static size_t resblock_lds_bytes(int C) {
 
 template <int C, int NW, bool HI, bool G2 = false>
 static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
-  const size_t lds = resblock_lds_bytes(C);
+  // VFX_RB_LDS_PAD (bytes): occupancy experiments -- extra LDS per block lowers the blocks per CU
+  static const size_t pad = getenv("VFX_RB_LDS_PAD") ? (size_t)atoi(getenv("VFX_RB_LDS_PAD")) : 0;
+  const size_t lds = resblock_lds_bytes(C) + pad;
   static uint64_t attr_devices = 0;  // one static per instantiation
   if (first_use_on_current_device(attr_devices)) {
     VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI, G2>), hipFuncAttributeMaxDynamicSharedMemorySize,

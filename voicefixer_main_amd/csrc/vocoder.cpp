@@ -93,8 +93,9 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
     VocConvW up;
     up.cin = c;
     up.cout = c / 2;
-    // the upsampler reads the activated trunk, unless the stack in front of it is fused (raw trunk only)
-    up.mode = pack_mode(cfg, st == 0 || !stack_fused(cfg, c));
+    // the upsampler reads the activated trunk, unless the stack in front of it is fused on the raw trunk only (in the
+    // 16-bit mode the last fused layer also writes the activated fp16 form)
+    up.mode = pack_mode(cfg, st == 0 || !stack_fused(cfg, c) || cfg.precision == 2);
     for (int r = 0; r < s; ++r) {
       std::vector<std::pair<int, int>> taps;
       for (auto& ek : phase_taps(s, pad, r)) taps.push_back({0, ek.second});
@@ -305,10 +306,17 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.C = up.cout;
         rp.dil = dil;
         rp.hionly = cfg.precision == 2;
+        Forms ynew;
+        ynew.raw = y2;
+        if (cfg.precision == 2 && li + 1 == nlayers && !last_stage) {
+          // last layer in front of an upsampler: also the activated fp16 form (LeakyReLU(up_slope)) for it
+          ynew.act = pb.alloc_f(act_floats((int64_t)B * Tlen * up.cout));
+          rp.ya = const_cast<float*>(rel_ptr(ynew.act));
+          rp.act_slope = cfg.voc_up_slope;
+        }
         pb.add_resblock(rp);
         free_forms(cur);
-        cur = Forms{};
-        cur.raw = y2;
+        cur = ynew;
       } else if (fuse_act) {
         // one launch per layer on the trunk in both forms: conv1 reads the activated fp16 trunk, the residual is the raw
         // one; the next trunk is written raw and -- unless it only feeds the vocoder tail -- activated for its consumer
