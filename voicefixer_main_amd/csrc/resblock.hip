@@ -104,10 +104,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
   // x patch pixel lr + 32q -> byte offset in x (chunk 0) / validity
   unsigned voff[NG];
   unsigned okmask = 0;
+  // Swizzle key of this thread's patch rows.  1-D patches: (row >> 1) & 7, the same for every row group.  2-D patches
+  // (G2, even width PW): ((pj >> 1) + (W1 / 2) * pi) & 7, the key of k_conv's 2-D tiles -- the bank half of row pi*PW + pj
+  // is pj & 1, and the lanes of a ds_read_b128 group (runs of consecutive columns of W1-wide h rows) get distinct
+  // (bank half, slot) pairs for every tap shift; the row-linear key gave 47-57 % LDS conflict cycles there (PMC).
+  int keyq[NG];
+  const int hW1 = W1 >> 1;
 #pragma unroll
   for (int q = 0; q < NG; ++q) {
     const int prow = lr + RG * q;
     const int pi = prow / PW, pj = prow - pi * PW;
+    keyq[q] = G2 ? (((pj >> 1) + hW1 * pi) & 7) : key_l;
     if constexpr (G2) {  // patch pixel (pi, pj) = image pixel (i0 - 2 + pi, j0 - 2 + pj)
       const int r = i0 - 2 + pi, c = j0 - 2 + pj;
       const bool ok = (prow < P) & ((unsigned)r < (unsigned)Hh) & ((unsigned)c < (unsigned)Ww);
@@ -121,6 +128,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
     }
   }
   int arow1[WM], arow2[WM];  // A row of this lane's h pixel: in the x patch (tap offset added) / in the h buffer
+  int kq0[WM], kpar[WM];     // 2-D mode: swizzle key of its patch pixel before the tap shift, and its column parity
   bool hval[WM];             // that h pixel lies inside the tile's h grid and inside the sequence
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
@@ -128,6 +136,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
     const int li = ml / W1, lj = ml - li * W1;
     arow1[a] = li < TH ? li * PW + lj : 0;
     arow2[a] = ml;
+    kq0[a] = li < TH ? (lj >> 1) + hW1 * li : 0;
+    kpar[a] = li < TH ? (lj & 1) : 0;
     if constexpr (G2) {  // h pixel (li, lj) = image pixel (i0 - 1 + li, j0 - 1 + lj)
       hval[a] = (li < TH) & ((unsigned)(i0 - 1 + li) < (unsigned)Hh) & ((unsigned)(j0 - 1 + lj) < (unsigned)Ww);
     } else {
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
           }
         }
         if constexpr (HI) {  // fp16 in the hi half only
-          *reinterpret_cast<uint2*>(row0 + RG * q * CROW + (((cg >> 1) ^ key_l) << 4) + 8 * (cg & 1)) =
+          *reinterpret_cast<uint2*>(row0 + RG * q * CROW + (((cg >> 1) ^ keyq[q]) << 4) + 8 * (cg & 1)) =
               make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
           continue;
         }
@@ -203,8 +213,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
         const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
         char* rowp = row0 + RG * q * CROW;
         const int half = 8 * (cg & 1);
-        *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ key_l) << 4) + half) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ key_l) << 4) + half) = make_uint2(l01, l23);
+        *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ keyq[q]) << 4) + half) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ keyq[q]) << 4) + half) = make_uint2(l01, l23);
       }
     if constexpr (HI) report_f16_saturation(f16_sat, p.flags);
   };
@@ -214,14 +224,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
   // stride that is a multiple of 256 bytes puts every row on the same half of the 64 LDS banks, and rows r, r + 1 share
   // their swizzle key: without the parity swap the fragment reads of conv2 are 2-way bank conflicts (measured: a third of
   // the LDS cycles of the kernel).  Patch rows (128-byte stride) alternate halves by themselves: chunk = -1.
-  auto mma = [&](const BFrag& R, const char* img_base, int stride, const int (&row)[WM], int chunk) __attribute__((always_inline)) {
+  // use_keyov: `keyov` holds the swizzle keys (already << 4) of the rows -- they are not the row-linear ones (2-D patches).
+  auto mma = [&](const BFrag& R, const char* img_base, int stride, const int (&row)[WM], int chunk, const int (&keyov)[WM],
+                 bool use_keyov) __attribute__((always_inline)) {
     const char* base[WM];
     int key[WM];
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
       base[a] = img_base + row[a] * stride;
       if (chunk >= 0) base[a] += (NCH > 1 ? (chunk ^ (row[a] & 1)) : chunk) * CROW;
-      key[a] = swz_key(row[a]);
+      key[a] = use_keyov ? keyov[a] : swz_key(row[a]);
     }
     if constexpr (HI) {
 #pragma unroll
@@ -301,10 +313,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
       // below is for a fetch issued before it
       if (k == KT - 1 - AHEAD && has_dma) issue_patch(c + 1, ((c + 1) & 1) * CPATCH);
       if (k >= AHEAD) wait_b_dyn<NG, WL, HI>(ring(g), WL * AHEAD + ((has_dma && k >= KT - 1 - AHEAD) ? NG : 0));
-      int rows[WM];
+      int rows[WM], kov[WM];
 #pragma unroll
-      for (int a = 0; a < WM; ++a) rows[a] = arow1[a] + (G2 ? p.poff9[k] : p.poff[k]);
-      mma(ring(g), lds + (c & 1) * CPATCH, CROW, rows, -1);
+      for (int a = 0; a < WM; ++a) {
+        rows[a] = arow1[a] + (G2 ? p.poff9[k] : p.poff[k]);
+        // 2-D mode: tap k = (dy, dx) reads patch pixel (li + dy, lj + dx): ((lj + dx) >> 1) = (lj >> 1) + (((lj & 1) + dx) >> 1)
+        int k0 = kq0[a];
+        if constexpr (G2) asm volatile("" : "+v"(k0));  // recompute per tap: hoisting 18 keys out of the chunk loop spills
+        kov[a] = ((k0 + hW1 * (k / 3) + (k % 3 == 2 ? 1 : 0) + (k % 3 == 1 ? kpar[a] : 0)) & 7) << 4;
+      }
+      mma(ring(g), lds + (c & 1) * CPATCH, CROW, rows, -1, kov, G2);
       __builtin_amdgcn_sched_barrier(0);
     }
     drain();
@@ -367,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
         const int r = arow2[a] + (G2 ? p.hoff9[k] : k - 1);
         rows[a] = r < 0 ? 0 : (r > CBM - 1 ? CBM - 1 : r);  // clamped rows only feed outputs that are masked anyway
       }
-      mma(ring(g), lds + H_OFF, HROW, rows, c);
+      mma(ring(g), lds + H_OFF, HROW, rows, c, rows, false);
       __builtin_amdgcn_sched_barrier(0);
     }
   drain();
