@@ -83,6 +83,23 @@ def test_resblock_layer(engine, C, T, fused):
         assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), (d, err)
 
 
+def test_resblock_layer_long_sequence(engine):
+    """C = 64 over sequences long enough that a persistent block of the register-weights kernel (resblock_rw.hip, 16-bit
+    mode) walks SEVERAL tiles -- prefetched patches, the kept residual and the LDS overlays are reused across tiles; clips of
+    unequal tile phase (T not a multiple of the tile).  The other modes run k_resblock over the same shapes."""
+    if engine.tol['name'] == 'fp32':
+        pytest.skip("the fused kernel has no fp32 form")
+    B, C, T = 3, 64, 70001
+    x = _rand((B, C, T), 41)
+    w1, w2 = _rand((C, C, 3), 42, 0.08), _rand((C, C, 3), 43, 0.08)
+    b1, b2 = _rand((C,), 44, 0.1), _rand((C,), 45, 0.1)
+    for d in (1, 27, 81, 2187):
+        ref = _resblock_ref(x, w1, b1, w2, b2, d, 0.01)
+        y = engine.op_resblock(x.permute(0, 2, 1).contiguous(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), d, 0.01, True)
+        err = (y.cpu().permute(0, 2, 1).double() - ref).abs().max().item()
+        assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), (d, err)
+
+
 @pytest.mark.parametrize("prune_w,H,W", [(False, 5, 1), (False, 10, 3), (True, 4, 16)])
 def test_conv_transpose2d(engine, prune_w, H, W):
     B, Cin, Cout = 2, 64, 32

@@ -547,6 +547,7 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
       d.seg[0].C = hp.C;
       d.seg[0].ntaps = 6;
       d.hionly = hp.hionly;
+      d.nstages = hp.rw ? hp.tile_m / 32 : (hp.C >= 128 ? 8 : 4);  // waves per block (the kernel's second template argument)
       c.prof->desc.push_back(d);
     } else {
       launch_resblock(hp, pl->dev_rb + idx, c.stream);
@@ -1188,7 +1189,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       for (int s2 = 0; s2 < d.nseg; ++s2) K += d.seg[s2].ntaps * d.seg[s2].C;
       char kname[64];
       if (d.nseg == 0) {  // fused ResStack layer
-        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.Cout >= 128 ? 8 : 4, d.hionly ? " f16" : "");
+        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.nstages, d.hionly ? " f16" : "");
       } else {
         bool elu = false;
         for (int s2 = 0; s2 < d.nseg; ++s2) elu = elu || d.seg[s2].act == ACT_ELU;

@@ -544,9 +544,12 @@ void plan_block2d(ResBlockParams& p) {
 void plan_resblock(ResBlockParams& p) {
   VFX_CHECK(p.asrc ? resblock_act_supported(p.C) : resblock_supported(p.C), "resblock: C=%d is not supported", p.C);
   const int d = p.dil;
-  const int MT = p.tile_m ? p.tile_m : CBM;  // h positions per tile (resblock_act: 64 or 128)
+  // 16-bit mode, C = 64: the persistent register-weights kernel (resblock_rw.hip) with its own tile size
+  p.rw = (!p.asrc && p.hionly && p.C == 64 && resblock_rw_tile() != 0) ? 1 : 0;
+  if (p.rw) p.tile_m = resblock_rw_tile();
+  const int MT = p.tile_m ? p.tile_m : CBM;  // h positions per tile (resblock_act: 64 or 128; resblock_rw: 128 or 256)
   const int PR = MT + 64;                    // patch rows per buffer (= kPatchMaxRows for MT = 128)
-  VFX_CHECK(MT == 64 || MT == 128, "resblock: tile of %d positions", MT);
+  VFX_CHECK(MT == 64 || MT == 128 || (MT == 256 && p.rw), "resblock: tile of %d positions", MT);
   p.tile_m = MT;
   if (MT + 2 * d <= PR) {
     p.fold = 0;
@@ -579,6 +582,10 @@ void plan_resblock(ResBlockParams& p) {
 void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   if (hp.asrc) {
     launch_resblock_act(hp, dparams, stream);
+    return;
+  }
+  if (hp.rw) {
+    launch_resblock_rw(hp, dparams, stream);
     return;
   }
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;

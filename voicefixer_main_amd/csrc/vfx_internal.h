@@ -192,7 +192,8 @@ struct ResBlockParams {
   // activated fp16 tensor xa = fp16(LeakyReLU(x)) (2 bytes per element), x stays the raw residual; besides y the kernel
   // writes ya = fp16(LeakyReLU(y, act_slope)) for the next consumer (NULL: not needed).  Weights: pack_conv mode 3.
   int asrc;
-  int tile_m;       // h positions per tile: 0 = 128 (k_resblock); resblock_act: 64 or 128 (resblock_act_tile())
+  int tile_m;       // h positions per tile: 0 = 128 (k_resblock); resblock_act: 64 or 128 (resblock_act_tile()); resblock_rw: 128 or 256
+  int rw;           // set by plan_resblock: the persistent register-weights kernel runs this layer (resblock_rw.hip: 16-bit mode, C = 64)
   const float* xa;
   float* ya;
   float act_slope;
@@ -209,6 +210,12 @@ bool resblock_supported(int C);
 bool resblock_act_supported(int C);
 int resblock_act_tile();
 void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
+// resblock_pc.hip: the same layer as a persistent producer / consumer kernel (one block per CU walks a range of tiles)
+bool resblock_pc_enabled();
+void launch_resblock_pc(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
+// resblock_rw.hip: C = 64, 16-bit mode -- persistent blocks, weights in registers, next patch prefetched into registers
+int resblock_rw_tile();
+void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 bool block2d_supported(int C);
 void plan_resblock(ResBlockParams& p);
 void plan_block2d(ResBlockParams& p);
