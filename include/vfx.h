@@ -217,6 +217,13 @@ int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H, int W, in
 int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int C, const float* w1, const float* b1,
                     const float* w2, const float* b2, int dil, float slope, int fused, float* y, void* stream);
 
+/* Two consecutive ResStack layers (dilations dil, dil2) as ONE launch: y = layer_b(layer_a(x)), the intermediate tensor never
+ * leaves the CU (resblock_rw.hip).  precision 2, C = 64, dil <= 32, dil2 <= 62 only -- what the vocoder plan pairs (dilations
+ * (1, 3) and (9, 27) of the 44.1 kHz stack).  Weights / biases as in vfx_op_resblock, on the HOST. */
+int vfx_op_resblock_pair(vfx_handle* h, const float* x, int B, int T, int C, const float* wa1, const float* ba1,
+                         const float* wa2, const float* ba2, int dil, const float* wb1, const float* bb1,
+                         const float* wb2, const float* bb2, int dil2, float slope, float* y, void* stream);
+
 /* One fused 2-D ConvBlockRes of the ResUNets (models/components/modules.py:223-271; Cin == Cout = C in {32, 64},
  * identity shortcut): y = x + conv2(lrelu(bn2(conv1(lrelu(bn1(x)))))) with 3x3 convolutions in ONE launch (h stays
  * in LDS).  x, y (B, H, W, C) on the device; w1, w2 (C, C, 3, 3) and the folded eval-mode BatchNorm affines

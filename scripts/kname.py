@@ -3,7 +3,8 @@
 k_conv<BN, ELU, SPLIT, ABL, RING, HI>  ->  "k_conv<BN, ELU, SPLIT>" (+ " f16" for the 16-bit launches of precision 2)
 k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
 k_resblock_act<C, NW, MT>              ->  "k_resblock<C, NW> f16"
-k_resblock_rw<NW>, k_resblock_pc<C>    ->  "k_resblock<64, NW> f16", "k_resblock<C, 8> f16"
+k_resblock_rw<NW, PAIR>                ->  "k_resblock<64, NW> f16" / "k_resblock_pair<64, NW> f16"
+k_resblock_pc<C>                       ->  "k_resblock<C, 8> f16"
 """
 import re
 
@@ -19,6 +20,8 @@ def short(n, width=40):
     if name == "k_resblock_act" and len(args) >= 2:      # the fused wide layer of the 16-bit mode
         return "k_resblock<%s, %s> f16" % (args[0], args[1])
     if name == "k_resblock_rw" and args:                 # C = 64, 16-bit mode: persistent, weights in registers
+        if len(args) >= 2 and args[1] == "true":         # two layers per launch
+            return "k_resblock_pair<64, %s> f16" % args[0]
         return "k_resblock<64, %s> f16" % args[0]
     if name == "k_resblock_pc" and args:
         return "k_resblock<%s, 8> f16" % args[0]

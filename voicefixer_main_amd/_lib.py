@@ -61,6 +61,8 @@ SIGNATURES = {
                                       c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "vfx_op_resblock": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                 c_float, c_int, c_void_p, c_void_p]),
+    "vfx_op_resblock_pair": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "vfx_op_block2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
 }

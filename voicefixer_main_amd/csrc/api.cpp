@@ -547,7 +547,8 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
       d.seg[0].C = hp.C;
       d.seg[0].ntaps = 6;
       d.hionly = hp.hionly;
-      d.nstages = hp.rw ? hp.tile_m / 32 : (hp.C >= 128 ? 8 : 4);  // waves per block (the kernel's second template argument)
+      d.nstages = hp.rw ? hp.tile_m / 32 : (hp.C >= 128 ? 8 : 4);                       // waves per block
+      d.seg[0].ntaps = hp.dil2 > 0 ? 12 : 6;                                            // pairs: four convolutions
       c.prof->desc.push_back(d);
     } else {
       launch_resblock(hp, pl->dev_rb + idx, c.stream);
@@ -1189,7 +1190,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       for (int s2 = 0; s2 < d.nseg; ++s2) K += d.seg[s2].ntaps * d.seg[s2].C;
       char kname[64];
       if (d.nseg == 0) {  // fused ResStack layer
-        snprintf(kname, sizeof(kname), "k_resblock<%d; %d>%s", d.Cout, d.nstages, d.hionly ? " f16" : "");
+        snprintf(kname, sizeof(kname), "%s<%d; %d>%s", d.seg[0].ntaps == 12 ? "k_resblock_pair" : "k_resblock", d.Cout, d.nstages, d.hionly ? " f16" : "");
       } else {
         bool elu = false;
         for (int s2 = 0; s2 < d.nseg; ++s2) elu = elu || d.seg[s2].act == ACT_ELU;

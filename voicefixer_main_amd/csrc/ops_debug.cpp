@@ -207,6 +207,49 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
   return 0;
 }
 
+// Two consecutive ResStack layers (dilations dil, dil2) of the 16-bit mode at C = 64 as ONE launch (resblock_rw.hip, PAIR): the
+// first layer's output never leaves the CU.  Weights / biases in PyTorch layout on the HOST: wa1, ba1, wa2, ba2 = first layer,
+// wb1 .. bb2 = second layer.  Fails (returns 1) where the plan would not pair the layers.
+extern "C" int vfx_op_resblock_pair(vfx_handle* h, const float* x, int B, int T, int C, const float* wa1, const float* ba1,
+                                    const float* wa2, const float* ba2, int dil, const float* wb1, const float* bb1,
+                                    const float* wb2, const float* bb2, int dil2, float slope, float* y, void* stream) {
+  try {
+    VFX_CHECK(h && x && y && wa1 && ba1 && wa2 && ba2 && wb1 && bb1 && wb2 && bb2 && B > 0 && T > 0, "bad argument");
+    DeviceGuard device_guard_(h->device);
+    VFX_CHECK(h->cfg.precision == 2 && resblock_rw_pair_ok(C, dil, dil2), "vfx_op_resblock_pair: needs the 16-bit mode, C = 64 and small dilations");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scratch sc;
+    std::vector<std::pair<int, int>> taps = {{0, 0}, {0, 1}, {0, 2}};
+    ResBlockParams rp{};
+    rp.x = x;
+    rp.y = y;
+    rp.w1 = sc.blob.upload(pack_conv(wa1, C, C, 1, 3, 0, C, taps, 2));
+    rp.w2 = sc.blob.upload(pack_conv(wa2, C, C, 1, 3, 0, C, taps, 2));
+    rp.b1 = sc.blob.upload(ba1, C);
+    rp.b2 = sc.blob.upload(ba2, C);
+    rp.w1b = sc.blob.upload(pack_conv(wb1, C, C, 1, 3, 0, C, taps, 2));
+    rp.w2b = sc.blob.upload(pack_conv(wb2, C, C, 1, 3, 0, C, taps, 2));
+    rp.b1b = sc.blob.upload(bb1, C);
+    rp.b2b = sc.blob.upload(bb2, C);
+    rp.slope = slope;
+    rp.B = B;
+    rp.T = T;
+    rp.C = C;
+    rp.hionly = 1;
+    rp.flags = h->d_flags;
+    rp.dil = dil;
+    rp.dil2 = dil2;
+    plan_resblock(rp);
+    ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
+    VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
+    launch_resblock(rp, d, s);
+    VFX_HIP(hipStreamSynchronize(s));
+  } catch (const vfx::Error&) {
+    return 1;
+  }
+  return 0;
+}
+
 // One fused 2-D ConvBlockRes (Cin == Cout = C in {32, 64}, identity shortcut; resblock.hip, G2 mode):
 //   y = x + conv2(lrelu(bn2(conv1(lrelu(bn1(x))))));  x, y (B, H, W, C) on the device; w1, w2 in PyTorch layout (C, C, 3, 3)
 //   and the folded BatchNorm affines sc*/sh* [C] on the HOST.

@@ -551,7 +551,19 @@ void plan_resblock(ResBlockParams& p) {
   const int PR = MT + 64;                    // patch rows per buffer (= kPatchMaxRows for MT = 128)
   VFX_CHECK(MT == 64 || MT == 128 || (MT == 256 && p.rw), "resblock: tile of %d positions", MT);
   p.tile_m = MT;
-  if (MT + 2 * d <= PR) {
+  if (p.dil2 > 0) {
+    // layer pair: both layers over the MT-index space of the tile, MT - 4 - 2 dil2 outputs per tile (resblock_rw.hip)
+    VFX_CHECK(p.rw && resblock_rw_pair_ok(p.C, d, p.dil2), "resblock: layers of dilation %d, %d cannot run as a pair", d, p.dil2);
+    p.fold = 0;
+    p.TH = 1;
+    p.W1 = MT;
+    p.TWo = MT - 4 - 2 * p.dil2;
+    p.tiles_h = 1;
+    p.tiles_w = (p.T + p.TWo - 1) / p.TWo;
+    p.PW = MT + 2 * d;
+    p.P = p.PW;
+    for (int k = 0; k < 3; ++k) p.poff[k] = k * d;
+  } else if (MT + 2 * d <= PR) {
     p.fold = 0;
     p.TH = 1;
     p.W1 = MT;
@@ -564,7 +576,9 @@ void plan_resblock(ResBlockParams& p) {
   } else {
     // rows of d samples; h tile TH x (TW + 2) <= MT pixels, x patch (TH + 2) x (TW + 2) <= PR
     p.fold = 1;
-    const int TW = d >= 16 ? 16 : d;
+    // tile width: the widest (<= 16) that cuts a row of d samples into equal parts -- d = 81 as 6 x 16 wastes 15 of 96 columns
+    // (the d = 81 layers ran 15 % longer than the other folded ones), as 6 x 14 it wastes 3; the h tile is 16 x 16 instead of 14 x 18
+    const int TW = d >= 16 ? (d + (d + 15) / 16 - 1) / ((d + 15) / 16) : d;
     p.W1 = TW + 2;
     p.TH = std::min(MT / p.W1, PR / p.W1 - 2);
     p.TWo = TW;
@@ -608,7 +622,7 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
 }
 
 double resblock_flops(const ResBlockParams& hp) {
-  return 2.0 * 2.0 * (double)hp.B * hp.T * hp.C * ((hp.geo2d ? 9.0 : 3.0) * hp.C);
+  return (hp.dil2 > 0 ? 2.0 : 1.0) * 2.0 * 2.0 * (double)hp.B * hp.T * hp.C * ((hp.geo2d ? 9.0 : 3.0) * hp.C);  // pairs: two layers
 }
 
 }  // namespace vfx

@@ -19,25 +19,43 @@
 // Tile geometry, weights (pack_conv mode 2: fp16 in the hi fragments of 32-channel chunks), arithmetic and summation order are
 // those of k_resblock<64, 4, HI> (same products, same summation order).
 // MT = 256 (NW = 8, one block per CU): the halo costs 1.25x instead of 1.5x input bytes.  MT = 128 (NW = 4): two blocks per CU.
+//
+// The kernel is bandwidth-bound (4.1 .. 4.4 TB/s of mixed reads and writes; k_resblock reaches the same with three blocks per
+// CU), so the next step is fewer bytes: PAIR = two consecutive layers of small dilation -- (1, 3), (9, 27) -- in ONE pass (NW = 8).
+// The first layer's output y1 never leaves the CU: it is the second layer's residual (the registers that held x) and, activated,
+// its patch (LDS).  Both layers work over the same 256-index space of the tile (index m = position base + m); a tile advances by
+// 252 - 2 d2 outputs.  Per pair x comes in once and y goes out once: 2.05 .. 2.4 instead of 4.0 .. 4.3 units of the tensor size.
+// Registers hold conv1 of the first layer only (48); the other three sets of fragments sit in LDS (72 KB, wave-slice-major:
+// conflict-free ds_read_b128) -- with more of them in registers the allocator parks fragments in scratch, and a scratch reload
+// queues behind the prefetch like any other load.  LDS of a pair (145 KB): R0 = 40 KB, R1 = 32 KB, the fragments, the biases;
+//   first layer:  patch R0, h R1;  second layer: patch (= activated y1) R1, h R0;
+//   the accumulators are staged for the epilogue in two halves of 128 rows (35 KB over R0) so that R1 is free for the second
+//   patch while the first epilogue runs.
+#include <type_traits>
+
 #include "conv_common.h"
 #include "vfx_internal.h"
 
 namespace vfx {
 
-template <int NW>
+template <int NW, bool PAIR>
 __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams* __restrict__ pp, int ntiles, int per_block) {
   constexpr int C = 64;
   constexpr int NTHR = NW * 64;
+  constexpr int WM = 2;                     // 32-row MFMA blocks per wave: wave = 64 positions x 32 channels
   constexpr int MT = NW * 32;               // h positions per tile
   constexpr int PR = MT + 64;               // patch rows (plan_resblock)
   constexpr int RQ = NTHR / 16;             // rows per load group: 16 lanes x 16 bytes = one 256-byte row of raw x
   constexpr int NCQ = MT / RQ;              // centre loads per thread (8)
   constexpr int NHQ = 64 / RQ;              // halo loads per thread (2 or 4)
-  constexpr int WM = 2;                     // 32-row MFMA blocks per wave: wave = 64 positions x 32 channels
   constexpr int ROWB = 128;                 // bytes per LDS row: 64 channels of fp16
-  constexpr int H_OFF = PR * ROWB;          // h behind the patch (no barrier between conv1 and the h write)
-  constexpr int LDO = C + 4;                // staged output row (floats), overlays patch + h
-  static_assert(NCQ == 8 && MT * LDO * 4 <= (PR + MT) * ROWB, "staging must fit over patch + h");
+  constexpr int R0 = 0, R1 = PR * ROWB;     // the two operand regions: R0 = PR rows, R1 = MT rows
+  constexpr int LDO = C + 4;                // staged output row (floats)
+  constexpr int NHALF = PAIR ? 2 : 1;       // the accumulators are staged over R0 (+ R1) at once, or in two halves over R0
+  static_assert(NCQ == 8 && (MT / NHALF) * LDO * 4 <= (PAIR ? PR : PR + MT) * ROWB, "staging must fit");
+  constexpr int WL_OFF = (PR + MT) * ROWB;  // pairs: weight fragments [conv2 A | conv1 B | conv2 B], 24 KB each
+  constexpr int BIAS_OFF = PAIR ? WL_OFF + 3 * 24 * 1024 : WL_OFF;  // b1 (pairs: b1, b2, second layer's b1, b2): C floats each
+  static_assert(!PAIR || NW == 8, "pairs: 256-position tiles");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = reinterpret_cast<char*>(smem);
@@ -53,28 +71,49 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   const int rowstride = p.fold ? d : 0;
   const int tiles_per_img = p.tiles_w * p.tiles_h;
   const float slope = p.slope;
+  const int d2 = p.dil2;           // PAIR: the second layer's dilation
   const int c0 = p.fold ? PW : d;  // patch row of h pixel 0: patch row m + c0 holds the input sample AT h pixel m (the residual)
 
-  // ---- weights: this wave's 32 output channels of both convolutions, all taps, for the lifetime of the block ----------
-  f16x8 W[2][2][3][2];  // [conv][32-channel chunk][tap][K = 16 step]
+  // ---- weights: this wave's 32 output channels, all taps, for the lifetime of the block ---------------------------------
+  // registers: [conv][32-channel chunk][tap][K = 16 step] (pairs: conv1 of the first layer only);  LDS (pairs): 1 KB per
+  // (set, chunk, tap, K step, 32-channel half), lane * 16 inside
+  f16x8 W[PAIR ? 1 : 2][2][3][2];
   {
     const int64_t ts = (int64_t)C * kKC;
     const unsigned nb_off = (unsigned)(wn * 1024 + lane * 4) * 4u;
 #pragma unroll
-    for (int cv = 0; cv < 2; ++cv)
+    for (int set = 0; set < (PAIR ? 4 : 2); ++set)  // conv1 A, conv2 A, conv1 B, conv2 B
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const char* w = reinterpret_cast<const char*>((cv ? p.w2 : p.w1) + (3 * c + k) * ts) + nb_off;
-          W[cv][c][k][0] = __builtin_bit_cast(f16x8, *(const VFX_GLOBAL f32x4*)(w));
-          W[cv][c][k][1] = __builtin_bit_cast(f16x8, *(const VFX_GLOBAL f32x4*)(w + 2048));
+          const float* wt = set == 0 ? p.w1 : (set == 1 ? p.w2 : (set == 2 ? p.w1b : p.w2b));
+          const char* w = reinterpret_cast<const char*>(wt + (3 * c + k) * ts) + nb_off;
+          if (PAIR && set >= 1) {
+            if (wm == 0) {
+#pragma unroll
+              for (int s2 = 0; s2 < 2; ++s2)
+                *reinterpret_cast<f32x4*>(lds + WL_OFF + (((((set - 1) * 6 + 3 * c + k) * 2 + s2) * 2 + wn) << 10) + lane * 16) =
+                    *(const VFX_GLOBAL f32x4*)(w + 2048 * s2);
+            }
+          } else {
+            W[set][c][k][0] = __builtin_bit_cast(f16x8, *(const VFX_GLOBAL f32x4*)(w));
+            W[set][c][k][1] = __builtin_bit_cast(f16x8, *(const VFX_GLOBAL f32x4*)(w + 2048));
+          }
         }
   }
-  // conv1's bias lives in LDS behind patch + h (a VMEM load per tile would queue behind the prefetch), conv2's in 4 registers
-  float* const b1s = reinterpret_cast<float*>(lds + (PR + MT) * ROWB);
+  // conv1's bias lives in LDS (a VMEM load per tile would queue behind the prefetch), conv2's in 4 registers (pairs: all four
+  // vectors in LDS)
+  float* const b1s = reinterpret_cast<float*>(lds + BIAS_OFF);
   if (tid < C) b1s[tid] = p.b1[tid];
-  const f32x4 b2v = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * cg);
+  f32x4 b2v = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * cg);
+  if constexpr (PAIR) {
+    if (tid < C) {
+      b1s[C + tid] = p.b2[tid];
+      b1s[2 * C + tid] = p.b1b[tid];
+      b1s[3 * C + tid] = p.b2b[tid];
+    }
+  }
 
   // Per-thread geometry is tile-independent but is RECOMPUTED per tile (exact magic-number divisions, a few VALU operations
   // per row): as tables it costs 40 registers that the 256 of this kernel do not have.
@@ -91,6 +130,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     const int hr = lr_v + RQ * q;
     return hr < c0 ? hr : hr + MT;
   };
+  // sample offset of h pixel m from h pixel (0, 0), far outside every sequence if the tile has no such pixel
+  auto hrel_of = [&](int m) __attribute__((always_inline)) {
+    const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
+    return li < TH ? li * rowstride + lj : -(1 << 29);
+  };
 
   const int t_begin = blockIdx.x * per_block, t_end = min(t_begin + per_block, ntiles);
   auto tile_geom = [&](int t, int& img, int& j0, int& base_h) __attribute__((always_inline)) {
@@ -98,7 +142,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     const int ti = (t / p.tiles_w) % p.tiles_h;
     img = t / tiles_per_img;
     j0 = tj * p.TWo;
-    base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;
+    base_h = PAIR ? j0 - 2 - d2 : (p.fold ? ti * TH * d + j0 - 1 : j0 - 1);  // position of h pixel 0 (pairs: of index 0, below)
   };
 
   f32x4 PC[NCQ], PH[NHQ];  // the raw patch of the NEXT tile, in flight / landed
@@ -121,11 +165,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     }
   };
   // raw row -> LeakyReLU -> fp16 -> this thread's 8 bytes of the patch row: piece cg >> 1 (8 channels) at slot piece ^ key
-  auto to_patch = [&](const f32x4& raw, int pr, bool& sat) __attribute__((always_inline)) {
+  auto to_patch = [&](char* patch, const f32x4& raw, int pr, bool& sat) __attribute__((always_inline)) {
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[e], raw[e] * slope);
-    *reinterpret_cast<uint2*>(lds + pr * ROWB + (((cg >> 1) ^ ((pr >> 1) & 7)) << 4) + 8 * (cg & 1)) =
+    *reinterpret_cast<uint2*>(patch + pr * ROWB + (((cg >> 1) ^ ((pr >> 1) & 7)) << 4) + 8 * (cg & 1)) =
         make_uint2(pack_f16x2(v[0], v[1], sat), pack_f16x2(v[2], v[3], sat));
   };
 
@@ -146,62 +190,59 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], ah[a], acc[a], 0, 0, 0);
     }
   };
-
-  if (t_begin < t_end) request(t_begin);
-  __syncthreads();  // b1s
-  for (int t = t_begin; t < t_end; ++t) {
-    asm volatile("" : "+v"(lr_v), "+v"(l31_v));
-    int img, j0, base_h;
-    tile_geom(t, img, j0, base_h);
-    int arow1[WM], hrel_m[WM];  // this lane's h pixel: its patch row / its sample offset from h pixel (0, 0) (far outside: none)
+  // weight fragments of set 0 .. 3 = conv1 A, conv2 A, conv1 B, conv2 B (registers, or LDS for the sets a pair keeps there)
+  auto mma_set = [&](auto set_tag, int c, int k, const char* img_base, const int (&row)[WM]) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
+    if constexpr (PAIR && SET >= 1) {
+      f16x8 w[2];
 #pragma unroll
-    for (int a = 0; a < WM; ++a) {
-      const int ml = (wm * WM + a) * 32 + l31_v;
-      const int li = (int)(((unsigned)ml * inv_w1) >> 20), lj = ml - li * W1;
-      arow1[a] = li < TH ? li * PW + lj : 0;
-      hrel_m[a] = li < TH ? li * rowstride + lj : -(1 << 29);
+      for (int s2 = 0; s2 < 2; ++s2)
+        w[s2] = *reinterpret_cast<const f16x8*>(lds + WL_OFF + (((((SET - 1) * 6 + 3 * c + k) * 2 + s2) * 2 + wn) << 10) + lane * 16);
+      mma(w, img_base, row, c);
+    } else {
+      mma(W[SET][c][k], img_base, row, c);
     }
+  };
 
-    // ---- the landed patch: to LDS as operands; its centre stays as the residual --------------------------------------
-    f32x4 K[NCQ];
-    {
-      bool sat = false;
-#pragma unroll
-      for (int q = 0; q < NCQ; ++q) {
-        K[q] = PC[q];
-        if (crow(q) < P) to_patch(PC[q], crow(q), sat);
-      }
-#pragma unroll
-      for (int q = 0; q < NHQ; ++q)
-        if (hrow(q) < P) to_patch(PH[q], hrow(q), sat);
-      report_f16_saturation(sat, p.flags);
-    }
-    __syncthreads();  // the patch is complete
-    if (t + 1 < t_end) request(t + 1);  // lands while this tile is computed and stored
-
-    // ---- conv1 (chunk-major taps: the order of k_resblock) ---------------------------------------------------------------
+  // conv1 -> h -> conv2 of ONE layer over the index space of the tile; the accumulators hold conv2 on return.
+  //   SECOND = false: A rows of conv1 are patch rows arow1[a] + poff[k] of the x patch (R0), h goes to R1;
+  //   SECOND = true (pairs): the patch is the first layer's activated output over the SAME index space (R1; rows
+  //   m + (k - 1) d2, clamped: rows that would need an index outside the tile only feed results that are never stored), h to R0.
+  auto layer = [&](auto second_tag, const int (&arow1)[WM], int base_h) __attribute__((always_inline)) {
+    constexpr bool SECOND = decltype(second_tag)::value;
+    const char* patch = lds + (SECOND ? R1 : R0);
+    char* hbuf = lds + (SECOND ? R0 : R1);
+    const float* bias1 = b1s + (SECOND ? 2 * C : 0);
+    // conv1 (chunk-major taps: the order of k_resblock)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         int rows[WM];
 #pragma unroll
-        for (int a = 0; a < WM; ++a) rows[a] = arow1[a] + p.poff[k];
-        mma(W[0][c][k], lds, rows, c);
+        for (int a = 0; a < WM; ++a) {
+          if constexpr (SECOND) {
+            const int r = (wm * WM + a) * 32 + l31_v + (k - 1) * d2;
+            rows[a] = r < 0 ? 0 : (r > MT - 1 ? MT - 1 : r);
+          } else {
+            rows[a] = arow1[a] + p.poff[k];
+          }
+        }
+        mma_set(std::integral_constant<int, SECOND ? 2 : 0>{}, c, k, patch, rows);
       }
-    // ---- h = LeakyReLU(conv1 + b1) as fp16 operands, zero outside the sequence ------------------------------------------
+    // h = LeakyReLU(conv1 + b1) as fp16 operands, zero outside the sequence
     {
       bool sat = false;
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
         const int m = (wm * WM + a) * 32 + l31_v;
-        const bool hval = (unsigned)(base_h + hrel_m[a]) < (unsigned)T;
-        char* rowp = lds + H_OFF + m * ROWB + 8 * lh;
+        const bool hval = (unsigned)(base_h + (SECOND ? m : hrel_of(m))) < (unsigned)T;
+        char* rowp = hbuf + m * ROWB + 8 * lh;
         const int key = (m >> 1) & 7;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4 u;
-          const f32x4 b1v = *reinterpret_cast<const f32x4*>(b1s + wn * 32 + 8 * j + 4 * lh);
+          const f32x4 b1v = *reinterpret_cast<const f32x4*>(bias1 + wn * 32 + 8 * j + 4 * lh);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float tt = acc[a][4 * j + e] + b1v[e];
@@ -214,7 +255,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       report_f16_saturation(sat, p.flags);
     }
     __syncthreads();  // h is complete
-    // ---- conv2 from the resident h ----------------------------------------------------------------------------------------
+    // conv2 from the resident h
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -225,48 +266,127 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
           const int r = (wm * WM + a) * 32 + l31_v + k - 1;
           rows[a] = r < 0 ? 0 : (r > MT - 1 ? MT - 1 : r);  // clamped rows only feed outputs that are masked anyway
         }
-        mma(W[1][c][k], lds + H_OFF, rows, c);
+        mma_set(std::integral_constant<int, SECOND ? 3 : 1>{}, c, k, hbuf, rows);
       }
-    __syncthreads();  // every wave is done with the patch and h: the staged tile overlays them
-    // ---- epilogue: stage the accumulators, then y = conv2 + x + b2 in the layout of the centre loads ------------------
+    __syncthreads();  // every wave is done with the patch and h: the staged accumulators may overlay them
+  };
+  // the accumulators of rows [half * MT / NHALF, (half + 1) * MT / NHALF) to the staging rows (floats, over R0 (+ R1))
+  auto stage = [&](int half) __attribute__((always_inline)) {
+    if (NHALF == 2 && (wm >> 1) != half) return;  // wave-uniform: waves wm = 0, 1 hold the first 128 rows
 #pragma unroll
     for (int a = 0; a < WM; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int row = (wm * WM + a) * 32 + l31_v;
+        const int row = (wm * WM + a) * 32 + l31_v - half * (MT / NHALF);
         *reinterpret_cast<f32x4*>(smem + row * LDO + wn * 32 + 8 * j + 4 * lh) =
             f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = 0.f;
       }
-    __syncthreads();
+  };
+
+  if (t_begin < t_end) request(t_begin);
+  __syncthreads();  // the biases (and the fragments a pair keeps in LDS) are there
+  for (int t = t_begin; t < t_end; ++t) {
+    asm volatile("" : "+v"(lr_v), "+v"(l31_v));
+    int img, j0, base_h;
+    tile_geom(t, img, j0, base_h);
+    int arow1[WM];  // patch row of this lane's h pixels
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const int ml = (wm * WM + a) * 32 + l31_v;
+      const int li = (int)(((unsigned)ml * inv_w1) >> 20), lj = ml - li * W1;
+      arow1[a] = li < TH ? li * PW + lj : 0;
+    }
+
+    // ---- the landed patch: to LDS as operands; its centre stays as the residual --------------------------------------
+    f32x4 K[NCQ];
+    {
+      bool sat = false;
+#pragma unroll
+      for (int q = 0; q < NCQ; ++q) {
+        K[q] = PC[q];
+        if (crow(q) < P) to_patch(lds + R0, PC[q], crow(q), sat);
+      }
+#pragma unroll
+      for (int q = 0; q < NHQ; ++q)
+        if (hrow(q) < P) to_patch(lds + R0, PH[q], hrow(q), sat);
+      report_f16_saturation(sat, p.flags);
+    }
+    __syncthreads();  // the patch is complete
+    if (t + 1 < t_end) request(t + 1);  // lands while this tile is computed and stored
+
+    layer(std::false_type{}, arow1, base_h);
+
+    if constexpr (PAIR) {
+      // ---- first layer's epilogue: y1 = conv2 + x + b2 stays on the CU -- as the second layer's residual (registers, same
+      // thread -> row map) and, activated, as its patch (R1).  Index m of the tile = position base_h + m for BOTH layers: the
+      // first layer's outputs are m = 1 .. MT-2, the second one's h is right for m = 1+d2 .. MT-2-d2, its outputs for
+      // m = 2+d2 .. MT-3-d2 (the MT - 4 - 2 d2 positions a tile advances by).  Outside the sequence y1 is zero (the padding
+      // of the second layer's conv1).
+      bool sat = false;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        stage(half);
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < NCQ / 2; ++qq) {
+          const int q = half * (NCQ / 2) + qq;
+          const int m = lr_v + RQ * q;
+          const bool ok = (m >= 1) & (m <= MT - 2) & ((unsigned)(base_h + m) < (unsigned)T);
+          const f32x4 b2a = *reinterpret_cast<const f32x4*>(b1s + C + 4 * cg);
+          const f32x4 val = (*reinterpret_cast<const f32x4*>(smem + (m - half * (MT / 2)) * LDO + 4 * cg) + K[q]) + b2a;
+          K[q] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
+          to_patch(lds + R1, K[q], m, sat);
+        }
+        __syncthreads();  // the staged half has been read (second half: the second patch is complete)
+      }
+      report_f16_saturation(sat, p.flags);
+      layer(std::true_type{}, arow1, base_h);
+      b2v = *reinterpret_cast<const f32x4*>(b1s + 3 * C + 4 * cg);
+    }
+
+    // ---- epilogue: y = conv2 + residual + b2 in the layout of the centre loads ----------------------------------------------
     {
       float* yi = p.y + (int64_t)img * T * C + 4 * cg;
       const bool even = (tid & 1) == 0;
       const float aslope = p.act_slope;
       bool sat = false;
 #pragma unroll
-      for (int q = 0; q < NCQ; ++q) {
-        const int m = lr_v + RQ * q;
-        const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
-        const int pos = base_h + li * rowstride + lj;
-        const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
-        const f32x4 val = (*reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * cg) + K[q]) + b2v;
-        if (ok) *(VFX_GLOBAL f32x4*)(yi + (int64_t)pos * C) = val;
-        if (p.ya) {  // last layer in front of an upsampler: also ya = fp16(LeakyReLU(y, act_slope)), cf. k_resblock
-          f32x4 u;
+      for (int half = 0; half < NHALF; ++half) {
+        stage(half);
+        __syncthreads();
 #pragma unroll
-          for (int e = 0; e < 4; ++e) u[e] = fmaxf(val[e], val[e] * aslope);
-          const unsigned h01 = pack_f16x2(u[0], u[1], sat), h23 = pack_f16x2(u[2], u[3], sat);
-          const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)h01, 0xB1, 0xf, 0xf, false);
-          const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)h23, 0xB1, 0xf, 0xf, false);
-          const u32x4 w = {h01, h23, g0, g1};
-          if (ok && even) *(VFX_GLOBAL f32x4*)(p.ya + ((int64_t)img * T + pos) * (C / 2) + 2 * cg) = __builtin_bit_cast(f32x4, w);
+        for (int qq = 0; qq < NCQ / NHALF; ++qq) {
+          const int q = half * (NCQ / NHALF) + qq;
+          const int m = lr_v + RQ * q;
+          int pos;
+          bool ok;
+          if constexpr (PAIR) {
+            pos = base_h + m;
+            ok = (m >= 2 + d2) & (m <= MT - 3 - d2) & ((unsigned)pos < (unsigned)T);
+          } else {
+            const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
+            pos = base_h + li * rowstride + lj;
+            ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
+          }
+          const f32x4 val = (*reinterpret_cast<const f32x4*>(smem + (m - half * (MT / NHALF)) * LDO + 4 * cg) + K[q]) + b2v;
+          if (ok) *(VFX_GLOBAL f32x4*)(yi + (int64_t)pos * C) = val;
+          if (p.ya) {  // last layer in front of an upsampler: also ya = fp16(LeakyReLU(y, act_slope)), cf. k_resblock
+            f32x4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = fmaxf(val[e], val[e] * aslope);
+            const unsigned h01 = pack_f16x2(u[0], u[1], sat), h23 = pack_f16x2(u[2], u[3], sat);
+            const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)h01, 0xB1, 0xf, 0xf, false);
+            const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)h23, 0xB1, 0xf, 0xf, false);
+            const u32x4 w = {h01, h23, g0, g1};
+            if (ok && even) *(VFX_GLOBAL f32x4*)(p.ya + ((int64_t)img * T + pos) * (C / 2) + 2 * cg) = __builtin_bit_cast(f32x4, w);
+          }
         }
+        __syncthreads();  // the staged rows have been read: the next half / the next patch may overwrite them
       }
       if (p.ya) report_f16_saturation(sat, p.flags);
     }
-    __syncthreads();  // the staged tile has been read: the next patch may overwrite it
   }
 }
 
@@ -279,10 +399,18 @@ int resblock_rw_tile() {
   return mt;
 }
 
-template <int NW>
+// Two consecutive layers as one launch: 256-position tiles, the first layer's patch must fit (d <= 32) and a tile must still
+// advance by at least half of its positions (d2 <= 62).  VFX_RB_PAIR=0: one launch per layer.
+bool resblock_rw_pair_ok(int C, int dil, int dil2) {
+  static const bool on = !(getenv("VFX_RB_PAIR") && atoi(getenv("VFX_RB_PAIR")) == 0);
+  return on && C == 64 && resblock_rw_tile() == 256 && dil >= 1 && dil <= 32 && dil2 >= 1 && 256 - 4 - 2 * dil2 >= 128;
+}
+
+template <int NW, bool PAIR>
 static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {
   constexpr int MT = NW * 32;
-  const size_t lds = (size_t)(MT + 64 + MT) * 128 + 64 * sizeof(float);  // patch + h (the staged tile overlays them) + conv1's bias
+  // the two operand regions (the staged accumulators overlay them) + biases; pairs: + three sets of weight fragments
+  const size_t lds = (size_t)(MT + 64 + MT) * 128 + (PAIR ? (size_t)72 * 1024 + 4 * 64 * sizeof(float) : 64 * sizeof(float));
   int dev = 0, cus = 256;
   VFX_HIP(hipGetDevice(&dev));
   VFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -291,17 +419,20 @@ static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t
   const int grid = (int)((ntiles + per_block - 1) / per_block);
   static uint64_t attr_devices = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_rw<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_rw<NW, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_resblock_rw<NW>), dim3(grid), dim3(NW * 64), lds, stream, dparams, (int)ntiles, per_block);
+  hipLaunchKernelGGL((k_resblock_rw<NW, PAIR>), dim3(grid), dim3(NW * 64), lds, stream, dparams, (int)ntiles, per_block);
 }
 
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   VFX_CHECK(hp.rw && hp.hionly && hp.C == 64 && !hp.geo2d && !hp.asrc, "resblock_rw: needs the 16-bit mode and C = 64");
   const int64_t ntiles = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(ntiles > 0 && ntiles < ((int64_t)1 << 30), "resblock_rw: bad tile count");
-  if (hp.tile_m == 256) launch_rw<8>(dparams, ntiles, stream);
-  else if (hp.tile_m == 128) launch_rw<4>(dparams, ntiles, stream);
+  if (hp.dil2 > 0) {
+    VFX_CHECK(hp.tile_m == 256 && !hp.fold && hp.w1b && hp.w2b && hp.b1b && hp.b2b, "resblock_rw: bad layer pair");
+    launch_rw<8, true>(dparams, ntiles, stream);
+  } else if (hp.tile_m == 256) launch_rw<8, false>(dparams, ntiles, stream);
+  else if (hp.tile_m == 128) launch_rw<4, false>(dparams, ntiles, stream);
   else VFX_CHECK(false, "resblock_rw: tile of %d positions", hp.tile_m);
   VFX_HIP(hipGetLastError());
 }

@@ -193,6 +193,13 @@ struct ResBlockParams {
   // writes ya = fp16(LeakyReLU(y, act_slope)) for the next consumer (NULL: not needed).  Weights: pack_conv mode 3.
   int asrc;
   int tile_m;       // h positions per tile: 0 = 128 (k_resblock); resblock_act: 64 or 128 (resblock_act_tile()); resblock_rw: 128 or 256
+  // Layer pair (resblock_rw.hip, PAIR): dil2 > 0 = a second layer (dilation dil2, weights w1b .. b2b, same slope) follows in the
+  // same launch; y is ITS output, the first layer's output is never stored.
+  int dil2;
+  const float* w1b;
+  const float* w2b;
+  const float* b1b;
+  const float* b2b;
   int rw;           // set by plan_resblock: the persistent register-weights kernel runs this layer (resblock_rw.hip: 16-bit mode, C = 64)
   const float* xa;
   float* ya;
@@ -215,6 +222,7 @@ bool resblock_pc_enabled();
 void launch_resblock_pc(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 // resblock_rw.hip: C = 64, 16-bit mode -- persistent blocks, weights in registers, next patch prefetched into registers
 int resblock_rw_tile();
+bool resblock_rw_pair_ok(int C, int dil, int dil2);  // this pair of consecutive layers can run as one launch
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 bool block2d_supported(int C);
 void plan_resblock(ResBlockParams& p);

@@ -306,6 +306,17 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.C = up.cout;
         rp.dil = dil;
         rp.hionly = cfg.precision == 2;
+        // 16-bit mode, C = 64: two layers of small dilation as one launch -- the tensor between them is never stored
+        if (rp.hionly && li + 1 < nlayers && resblock_rw_tile() != 0 && resblock_rw_pair_ok(up.cout, dil, dil * cfg.voc_dilation_base)) {
+          auto& next = W->res[st][li + 1];
+          dil *= cfg.voc_dilation_base;
+          ++li;
+          rp.dil2 = dil;
+          rp.w1b = next.first.w;
+          rp.w2b = next.second.w;
+          rp.b1b = next.first.bias;
+          rp.b2b = next.second.bias;
+        }
         Forms ynew;
         ynew.raw = y2;
         if (cfg.precision == 2 && li + 1 == nlayers && !last_stage) {

@@ -291,6 +291,19 @@ class Engine:
                                             int(bool(fused)), _ptr(y), self._stream()), "vfx_op_resblock")
         return y
 
+    def op_resblock_pair(self, x, layer_a, dil_a, layer_b, dil_b, slope=0.01):
+        """Two consecutive ResStack layers as one launch (16-bit mode, C = 64); layer_* = (w1, b1, w2, b2) in torch layout."""
+        x = _dev_f32(x, self.device)
+        B, T, C = x.shape
+        hp = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        la, lb = [hp(a) for a in layer_a], [hp(a) for a in layer_b]
+        cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        y = torch.empty_like(x)
+        _lib.check(self.lib.vfx_op_resblock_pair(self.h, _ptr(x), B, T, C, cp(la[0]), cp(la[1]), cp(la[2]), cp(la[3]), int(dil_a),
+                                                 cp(lb[0]), cp(lb[1]), cp(lb[2]), cp(lb[3]), int(dil_b), float(slope), _ptr(y),
+                                                 self._stream()), "vfx_op_resblock_pair")
+        return y
+
     def op_block2d(self, x, w1, sc1, sh1, w2, sc2, sh2, slope=0.01):
         """One fused ConvBlockRes (identity shortcut) on x (B, H, W, C) channels-last; w1 / w2 (C, C, 3, 3) and the folded
         BatchNorm affines (C) in torch layout on the host."""
