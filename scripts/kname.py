@@ -4,7 +4,7 @@ k_conv<BN, ELU, SPLIT, ABL, RING, HI>  ->  "k_conv<BN, ELU, SPLIT>" (+ " f16" fo
 k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
 k_resblock_act<C, NW, MT>              ->  "k_resblock<C, NW> f16"
 k_resblock_rw<NW, PAIR>                ->  "k_resblock<64, NW> f16" / "k_resblock_pair<64, NW> f16"
-k_resblock_pc<C>                       ->  "k_resblock<C, 8> f16"
+k_resblock_pc<C>, k_resblock_rl<C>      ->  "k_resblock<C, 8> f16"
 """
 import re
 
@@ -23,6 +23,8 @@ def short(n, width=40):
         if len(args) >= 2 and args[1] == "true":         # two layers per launch
             return "k_resblock_pair<64, %s> f16" % args[0]
         return "k_resblock<64, %s> f16" % args[0]
+    if name == "k_resblock_rl" and args:                 # C = 128, 16-bit mode: the patch through registers
+        return "k_resblock<%s, 8> f16" % args[0]
     if name == "k_resblock_pc" and args:
         return "k_resblock<%s, 8> f16" % args[0]
     if name == "k_resblock" and len(args) >= 2:

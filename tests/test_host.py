@@ -189,7 +189,7 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "voicefixer_main_amd", "csrc")
-    for name in ("conv.hip", "resblock.hip", "resblock_act.hip", "resblock_pc.hip"):
+    for name in ("conv.hip", "resblock.hip", "resblock_act.hip", "resblock_pc.hip", "resblock_rl.hip"):
         out = str(tmp_path / (name + ".s"))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                         "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, name)], check=True,

@@ -81,6 +81,22 @@ extern "C" int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, i
   return 0;
 }
 
+// The activated fp16 output of a fused layer must be fp16(LeakyReLU(y)) exactly: checked inside the debug entry points so that a
+// test sees a mismatch as an error of the call.
+static void check_activated_output(const float* y, const float* dya, size_t n, float slope, hipStream_t s) {
+  VFX_HIP(hipStreamSynchronize(s));
+  std::vector<float> hy(n);
+  std::vector<_Float16> hya(n);
+  VFX_HIP(hipMemcpy(hy.data(), y, n * sizeof(float), hipMemcpyDeviceToHost));
+  VFX_HIP(hipMemcpy(hya.data(), dya, n * sizeof(_Float16), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {
+    const float v = hy[i] > 0.f ? hy[i] : hy[i] * slope;
+    const _Float16 e = (_Float16)std::min(std::max(v, -65504.f), 65504.f);
+    VFX_CHECK((float)e == (float)hya[i], "activated output differs from fp16(LeakyReLU(y)) at element %zu (%g vs %g)", i,
+              (double)(float)hya[i], (double)(float)e);
+  }
+}
+
 // One ResStack layer y = x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 on (B, T, C) tensors; weights in PyTorch
 // Conv1d layout (C, C, 3) on the HOST.  fused != 0: k_resblock (C = 64 / 128, split-bf16 mode only);
 // fused == 0: two k_conv launches with the ACTIVATED intermediate tensor (any C multiple of 32), which is what
@@ -99,8 +115,10 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
     // two-launch form, 16-bit mode: h travels as an activated fp16 tensor (64-channel stages) when C allows it
     const bool h_f16 = !fused && h->cfg.precision == 2 && C % 64 == 0;
     const bool h_act = !(h->cfg.precision == 2 && !h_f16);
-    float* dw1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, pmode));
-    float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, h_f16 ? 3 : pmode));
+    // (fused, 16-bit mode, C = 128: resblock_rl.hip reads 64-channel fp16 fragments)
+    const bool rl = fused && h->cfg.precision == 2 && C == 128 && resblock_rl_enabled();
+    float* dw1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, rl ? 3 : pmode));
+    float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, (h_f16 || rl) ? 3 : pmode));
     float* db1 = sc.blob.upload(b1, C);
     float* db2 = sc.blob.upload(b2, C);
     if (fused && h->cfg.precision == 2 && resblock_act_supported(C)) {
@@ -138,18 +156,7 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
       VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
       launch_resblock(rp, d, s);
-      // ya must be fp16(LeakyReLU(y)): checked here so that the test sees a failure as an error of the call
-      VFX_HIP(hipStreamSynchronize(s));
-      std::vector<float> hy(hx.size());
-      std::vector<_Float16> hya(hx.size());
-      VFX_HIP(hipMemcpy(hy.data(), y, hy.size() * sizeof(float), hipMemcpyDeviceToHost));
-      VFX_HIP(hipMemcpy(hya.data(), dya, hya.size() * sizeof(_Float16), hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < hy.size(); ++i) {
-        const float v = hy[i] > 0.f ? hy[i] : hy[i] * slope;
-        const _Float16 e = (_Float16)std::min(std::max(v, -65504.f), 65504.f);
-        VFX_CHECK((float)e == (float)hya[i], "vfx_op_resblock: activated output differs from fp16(LeakyReLU(y)) at element %zu (%g vs %g)",
-                  i, (double)(float)hya[i], (double)(float)e);
-      }
+      check_activated_output(y, dya, hx.size(), slope, s);
     } else if (fused) {
       VFX_CHECK(split && resblock_supported(C), "vfx_op_resblock: the fused kernel needs precision 1 or 2 and C = 64 or 128");
       ResBlockParams rp{};
@@ -166,10 +173,17 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       rp.hionly = h->cfg.precision == 2;
       rp.flags = h->d_flags;
       rp.dil = dil;
+      float* dya = nullptr;
+      if (rp.hionly) {  // 16-bit mode: also the activated fp16 form a last layer writes for the upsampler behind it
+        dya = static_cast<float*>(sc.blob.alloc((size_t)B * T * C * sizeof(_Float16)));
+        rp.ya = dya;
+        rp.act_slope = slope;
+      }
       plan_resblock(rp);
       ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
       VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
       launch_resblock(rp, d, s);
+      if (dya) check_activated_output(y, dya, (size_t)B * T * C, slope, s);
     } else {
       float* hbuf = static_cast<float*>(sc.blob.alloc((size_t)B * T * C * sizeof(float)));
       TapConvParams p1{};
@@ -239,11 +253,14 @@ extern "C" int vfx_op_resblock_pair(vfx_handle* h, const float* x, int B, int T,
     rp.flags = h->d_flags;
     rp.dil = dil;
     rp.dil2 = dil2;
+    float* dya = static_cast<float*>(sc.blob.alloc((size_t)B * T * C * sizeof(_Float16)));
+    rp.ya = dya;
+    rp.act_slope = slope;
     plan_resblock(rp);
     ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
     VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
     launch_resblock(rp, d, s);
-    VFX_HIP(hipStreamSynchronize(s));
+    check_activated_output(y, dya, (size_t)B * T * C, slope, s);
   } catch (const vfx::Error&) {
     return 1;
   }

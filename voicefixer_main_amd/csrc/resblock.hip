@@ -547,6 +547,7 @@ void plan_resblock(ResBlockParams& p) {
   // 16-bit mode, C = 64: the persistent register-weights kernel (resblock_rw.hip) with its own tile size
   p.rw = (!p.asrc && p.hionly && p.C == 64 && resblock_rw_tile() != 0) ? 1 : 0;
   if (p.rw) p.tile_m = resblock_rw_tile();
+  p.rl = (!p.asrc && p.hionly && p.C == 128 && resblock_rl_enabled()) ? 1 : 0;
   const int MT = p.tile_m ? p.tile_m : CBM;  // h positions per tile (resblock_act: 64 or 128; resblock_rw: 128 or 256)
   const int PR = MT + 64;                    // patch rows per buffer (= kPatchMaxRows for MT = 128)
   VFX_CHECK(MT == 64 || MT == 128 || (MT == 256 && p.rw), "resblock: tile of %d positions", MT);
@@ -580,10 +581,11 @@ void plan_resblock(ResBlockParams& p) {
     // (the d = 81 layers ran 15 % longer than the other folded ones), as 6 x 14 it wastes 3; the h tile is 16 x 16 instead of 14 x 18
     const int TW = d >= 16 ? (d + (d + 15) / 16 - 1) / ((d + 15) / 16) : d;
     p.W1 = TW + 2;
-    p.TH = std::min(MT / p.W1, PR / p.W1 - 2);
-    p.TWo = TW;
     const int rows = (p.T + d - 1) / d;
-    p.tiles_h = (rows + p.TH - 1) / p.TH;
+    const int th_max = std::min(MT / p.W1, PR / p.W1 - 2);
+    p.tiles_h = (rows + th_max - 1) / th_max;
+    p.TH = (rows + p.tiles_h - 1) / p.tiles_h;  // equal parts here too: 23 rows are 4 x 6, not 4 x 7
+    p.TWo = TW;
     p.tiles_w = (d + TW - 1) / TW;
     p.PW = p.W1;
     p.P = (p.TH + 2) * p.W1;
@@ -600,6 +602,10 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
   }
   if (hp.rw) {
     launch_resblock_rw(hp, dparams, stream);
+    return;
+  }
+  if (hp.rl) {
+    launch_resblock_rl(hp, dparams, stream);
     return;
   }
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;

@@ -200,6 +200,8 @@ struct ResBlockParams {
   const float* w2b;
   const float* b1b;
   const float* b2b;
+  int rl;           // set by plan_resblock: the register-loaded-patch kernel runs this layer (resblock_rl.hip: 16-bit mode, C = 128;
+                    // weights: pack_conv mode 3)
   int rw;           // set by plan_resblock: the persistent register-weights kernel runs this layer (resblock_rw.hip: 16-bit mode, C = 64)
   const float* xa;
   float* ya;
@@ -221,6 +223,9 @@ void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams
 bool resblock_pc_enabled();
 void launch_resblock_pc(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 // resblock_rw.hip: C = 64, 16-bit mode -- persistent blocks, weights in registers, next patch prefetched into registers
+// resblock_rl.hip: C = 128, 16-bit mode -- the whole patch through registers in one round trip, x read once
+bool resblock_rl_enabled();
+void launch_resblock_rl(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 int resblock_rw_tile();
 bool resblock_rw_pair_ok(int C, int dil, int dil2);  // this pair of consecutive layers can run as one launch
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
