@@ -53,6 +53,14 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
   static_assert(NW % WAVES_N == 0 && WAVES_M == 1 && WM * 32 == MT, "one wave = MT positions x 32 channels");
   constexpr bool PREFETCH_RES = false;       // the residual requested with the patch: measured -2 % at MT = 128, 64 more registers
   constexpr int WL = 4;                      // weight loads per tap and wave (four K = 16 fragments)
+#ifndef VFX_RBA_RING
+#define VFX_RBA_RING 2
+#endif
+  // Weight taps in flight: a tap is requested AHEAD taps before its use.  One tap of the MT = 128 form is 16 MFMAs (0.2 us) per
+  // wave against an L2 round trip of ~0.6 us, but deeper rings measured no gain (-DVFX_RBA_RING=3 / 4: 0.974 / 0.999 ms median
+  // per layer against 0.966 with one tap ahead, same box; 221 / 238 registers): the arithmetic phase waits for LDS -- every MFMA
+  // needs its own 1 KB A fragment from LDS, which is the LDS bandwidth of the CU at full MFMA rate -- not for weights.
+  constexpr int RING = MT == 128 ? VFX_RBA_RING : 2, AHEAD = RING - 1;
   constexpr int HROW = C * 2;                // bytes per h row (fp16)
   constexpr int NT1 = 3 * NCH;               // taps of conv1 (chunk-major); conv2 has as many
   constexpr int EPC = 64, NEP = C / EPC;     // epilogue: passes of 64 channels
@@ -192,26 +200,32 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
     }
   };
 
-  // ---- weight ring: global tap g (conv1: 0 .. NT1-1, conv2: NT1 .. 2*NT1-1) in register group g % 2 ---------------
-  BFrag R0 = {}, R1 = {};
-  auto ring = [&](int g) __attribute__((always_inline)) -> BFrag& { return (g & 1) ? R1 : R0; };
+  // ---- weight ring: global tap g (conv1: 0 .. NT1-1, conv2: NT1 .. 2*NT1-1) in register group g % RING -------------
+  BFrag R0 = {}, R1 = {}, R2 = {}, R3 = {};
+  auto ring = [&](int g) __attribute__((always_inline)) -> BFrag& {
+    const int i = g % RING;
+    return i == 0 ? R0 : (i == 1 ? R1 : (i == 2 ? R2 : R3));
+  };
   auto fetch = [&](int g) __attribute__((always_inline)) {
     const float* w = g < NT1 ? p.w1 + g * ts : (g < 2 * NT1 ? p.w2 + (g - NT1) * ts : p.w2 + (NT1 - 1) * ts);
-    if (!(VFX_RBA_ABL & 1) || g == 0) load_b_asm(ring(g), w, nb_off);
+    if (!(VFX_RBA_ABL & 1) || g < AHEAD) load_b_asm(ring(g), w, nb_off);
   };
-  // tap g's weights are older than the one fetch (WL loads) issued after them
+  // tap g's weights are older than the AHEAD fetches (WL loads each) issued after them
   auto wait_tap = [&](int g) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
     use_b(ring(g));
   };
   auto drain = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     use_b(R0);
     use_b(R1);
+    if constexpr (RING > 2) use_b(R2);
+    if constexpr (RING > 3) use_b(R3);
   };
 
-  fetch(0);
-  drain();          // the patch and tap 0 have landed (this wave's share)
+#pragma unroll
+  for (int g = 0; g < AHEAD; ++g) fetch(g);
+  drain();          // the patch and the first taps have landed (this wave's share)
   __syncthreads();  // ... and everybody else's
 
   // ---- phase 1: conv1 ---------------------------------------------------------------------------------------------
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int g = 3 * c + k;
-      fetch(g + 1);
+      fetch(g + AHEAD);
       wait_tap(g);
       int rows[WM];
 #pragma unroll
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
       mma(ring(g), lds + c * PBYTES, CROW, rows, -1);
       __builtin_amdgcn_sched_barrier(0);
     }
-  drain();          // tap NT1 (the first of conv2) has landed
+  drain();          // the first taps of conv2 have landed
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
 
   if (!(VFX_RBA_ABL & 32))
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int g = NT1 + 3 * c + k;
-      fetch(g + 1);  // past the end: the last tap again, never consumed
+      fetch(g + AHEAD);  // past the end: the last tap again, never consumed
       wait_tap(g);
       int rows[WM];
 #pragma unroll

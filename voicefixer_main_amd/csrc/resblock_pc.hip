@@ -370,9 +370,7 @@ void launch_resblock_pc(const ResBlockParams& hp, const ResBlockParams* dparams,
   VFX_CHECK(hp.asrc && hp.hionly && hp.C == 256 && hp.xa && hp.tile_m == 128, "resblock_pc: needs the 16-bit mode, C = 256, 128-position tiles");
   const int64_t ntiles = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(ntiles > 0 && ntiles < ((int64_t)1 << 30), "resblock_pc: bad tile count");
-  int dev = 0, cus = 256;
-  VFX_HIP(hipGetDevice(&dev));
-  VFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int cus = cu_count_of_current_device();
   const int per_block = (int)((ntiles + cus - 1) / cus);
   const int grid = (int)((ntiles + per_block - 1) / per_block);  // one block per CU (the block owns the CU's LDS); every block has >= 1 tile
   const size_t lds = (size_t)(256 / 64) * CPATCH + (size_t)128 * 256 * 2;  // 96 KB + 64 KB

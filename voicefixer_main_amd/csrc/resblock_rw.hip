@@ -406,15 +406,25 @@ bool resblock_rw_pair_ok(int C, int dil, int dil2) {
   return on && C == 64 && resblock_rw_tile() == 256 && dil >= 1 && dil <= 32 && dil2 >= 1 && 256 - 4 - 2 * dil2 >= 128;
 }
 
+int cu_count_of_current_device() {
+  static int cus[64] = {};
+  int dev = 0;
+  VFX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    VFX_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus[dev] = n > 0 ? n : 256;
+  }
+  return cus[dev];
+}
+
 template <int NW, bool PAIR>
 static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {
   constexpr int MT = NW * 32;
   // the two operand regions (the staged accumulators overlay them) + biases; pairs: + three sets of weight fragments
   const size_t lds = (size_t)(MT + 64 + MT) * 128 + (PAIR ? (size_t)72 * 1024 + 4 * 64 * sizeof(float) : 64 * sizeof(float));
-  int dev = 0, cus = 256;
-  VFX_HIP(hipGetDevice(&dev));
-  VFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int slots = cus * (NW == 4 ? 2 : 1);  // 256 registers per wave: 8 waves per CU
+  const int slots = cu_count_of_current_device() * (NW == 4 ? 2 : 1);  // 256 registers per wave: 8 waves per CU
   const int per_block = (int)((ntiles + slots - 1) / slots);
   const int grid = (int)((ntiles + per_block - 1) / per_block);
   static uint64_t attr_devices = 0;

@@ -229,6 +229,8 @@ void launch_resblock_rl(const ResBlockParams& hp, const ResBlockParams* dparams,
 int resblock_rw_tile();
 bool resblock_rw_pair_ok(int C, int dil, int dil2);  // this pair of consecutive layers can run as one launch
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
+// compute units of the current device (cached per device): grid size of the persistent kernels
+int cu_count_of_current_device();
 bool block2d_supported(int C);
 void plan_resblock(ResBlockParams& p);
 void plan_block2d(ResBlockParams& p);
