@@ -20,8 +20,8 @@
 //      hand-counted vmcnt as in k_conv / k_resblock;
 //   2. h = LeakyReLU(acc + b1) as fp16, 512-byte rows, over the (dead) patch buffers;
 //   3. conv2 from the resident h;
-//   4. epilogue in four passes of 64 channels: + b2 + x (the raw residual, requested in phase 0 together with the patch
-//      and held in 64 registers: no load latency at the end of the tile), raw fp32 y and fp16 ya.
+//   4. epilogue in two passes of 128 channels: + b2 + x (the raw residual: pass 0's is requested behind the last weight
+//      fetch of conv2, pass 1's while pass 0 is added and stored), raw fp32 y and fp16 ya.
 // Geometry (plan_resblock) as k_resblock: 1-D tiles for d <= 32, folded rows of d samples with vertical taps above.
 #include "conv_common.h"
 #include "vfx_internal.h"
@@ -61,9 +61,22 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
   // per layer against 0.966 with one tap ahead, same box; 221 / 238 registers): the arithmetic phase waits for LDS -- every MFMA
   // needs its own 1 KB A fragment from LDS, which is the LDS bandwidth of the CU at full MFMA rate -- not for weights.
   constexpr int RING = MT == 128 ? VFX_RBA_RING : 2, AHEAD = RING - 1;
+#ifndef VFX_RBA_PFNEXT
+#define VFX_RBA_PFNEXT 1
+#endif
+  // The residual of epilogue pass p + 1 is requested while pass p is added and stored, and the one of pass 0 behind the LAST
+  // weight fetch of conv2 (nothing younger is waited for before the epilogue): the four passes were four memory round trips
+  // (the epilogue is 0.28 of the layer's 0.975 ms in the ablation).  One more set of residual registers.
+  constexpr bool PFNEXT = VFX_RBA_PFNEXT && MT == 128 && !PREFETCH_RES && AHEAD == 1 && VFX_RBA_ABL == 0;
   constexpr int HROW = C * 2;                // bytes per h row (fp16)
   constexpr int NT1 = 3 * NCH;               // taps of conv1 (chunk-major); conv2 has as many
-  constexpr int EPC = 64, NEP = C / EPC;     // epilogue: passes of 64 channels
+#ifndef VFX_RBA_EPC
+#define VFX_RBA_EPC 128
+#endif
+  // Two passes of 128 channels, not four of 64: a pass is a memory round trip (its residual) and two block barriers.  Measured
+  // per layer (median of 24 launches, same box): 64 / no prefetch 1.011 ms, 64 / next-pass prefetch 0.99, 128 / none 0.995,
+  // 128 / prefetch 0.97 (250 registers).
+  constexpr int EPC = MT == 128 ? VFX_RBA_EPC : 64, NEP = C / EPC;  // epilogue: passes of EPC channels (EPC / 32 waves stage a pass)
   constexpr int LDO = EPC + 4;               // staged output row (floats)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -129,6 +142,9 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
   const int c4 = tid % V, r0 = tid / V;
   int opix[NPASS];
   f32x4 res[NEP][NPASS];
+  f32x4 b2v[NEP];  // conv2's bias for this thread's channels of every pass: fetched here, not in the pass (an L2 round trip each)
+#pragma unroll
+  for (int pass = 0; pass < NEP; ++pass) b2v[pass] = *(const VFX_GLOBAL f32x4*)(p.b2 + pass * EPC + 4 * c4);
 #pragma unroll
   for (int q = 0; q < NPASS; ++q) {
     const int m = r0 + q * RPP;  // h pixel of the staged row
@@ -277,13 +293,31 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
   __syncthreads();  // h is complete
 
   // ---- phase 3: conv2 from the resident h ------------------------------------------------------------------------------
+  auto request_res = [&](int pass) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q)
+      res[pass][q] = *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * C + pass * EPC + 4 * c4);
+  };
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int g = NT1 + 3 * c + k;
-      fetch(g + AHEAD);  // past the end: the last tap again, never consumed
-      wait_tap(g);
+      if (PFNEXT && g >= 2 * NT1 - 2) {
+        // the last two taps: the final (real) weight fetch, then the residual of epilogue pass 0 -- NPASS loads that are
+        // younger than every weight still waited for
+        if (g == 2 * NT1 - 2) {
+          fetch(g + 1);
+          request_res(0);
+          asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL + NPASS) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NPASS) : "memory");
+        }
+        use_b(ring(g));
+      } else {
+        fetch(g + AHEAD);  // past the end: the last tap again, never consumed
+        wait_tap(g);
+      }
       int rows[WM];
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
@@ -293,7 +327,7 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
       mma(ring(g), lds, HROW, rows, c);
       __builtin_amdgcn_sched_barrier(0);
     }
-  drain();
+  if (!PFNEXT) drain();
   __syncthreads();  // every wave is done with h
 
   // ---- phase 4: y = conv2 + b2 + x, raw fp32 and (optionally) activated fp16 ---------------------------------------------
@@ -310,24 +344,24 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
   }
 #pragma unroll
   for (int pass = 0; pass < NEP; ++pass) {
-    if ((wn >> 1) == pass) {
+    if (wn / (EPC / 32) == pass) {
 #pragma unroll
       for (int a = 0; a < WM; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int row = a * 32 + l31;
-          *reinterpret_cast<f32x4*>(smem + row * LDO + (wn & 1) * 32 + 8 * j + 4 * lh) =
+          *reinterpret_cast<f32x4*>(smem + row * LDO + (wn % (EPC / 32)) * 32 + 8 * j + 4 * lh) =
               f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
         }
     }
     __syncthreads();  // the pass is staged
     const int ncol = pass * EPC + 4 * c4;
-    const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + ncol);
+    const f32x4 bv = b2v[pass];
     f32x4 val[NPASS];
-    if constexpr (!PREFETCH_RES) {
-#pragma unroll
-      for (int q = 0; q < NPASS; ++q)
-        res[pass][q] = *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * C + ncol);
+    if constexpr (PFNEXT) {
+      if (pass + 1 < NEP) request_res(pass + 1);  // in flight while this pass is added and stored
+    } else if constexpr (!PREFETCH_RES) {
+      request_res(pass);
     }
 #pragma unroll
     for (int q = 0; q < NPASS; ++q)
@@ -359,7 +393,7 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
 static size_t resblock_act_lds_bytes(int C, int MT) {
   const size_t patches = (size_t)(C / 64) * (MT + 64) * CROW;
   const size_t h = (size_t)MT * C * 2;
-  const size_t epi = (size_t)MT * (64 + 4) * 4;
+  const size_t epi = (size_t)MT * ((MT == 128 ? VFX_RBA_EPC : 64) + 4) * 4;
   return std::max(std::max(patches, h), epi);
 }
 
