@@ -59,6 +59,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
   constexpr int NCH = C / 32;  // 32-channel chunks = waves along N
   constexpr int WAVES_N = NCH, WAVES_M = NW / WAVES_N, WM = 4 / WAVES_M;  // (C, NW) = (64, 4): 2, 2, 2;  (128, 8): 4, 2, 2
   constexpr int RING = WM >= 4 ? 2 : 3, AHEAD = RING - 1;
+  constexpr int NBUF = (NCH == 4 && !G2) ? 3 : 2;  // patch buffers (chunks in flight / in use)
   constexpr int HROW = C * 4;         // bytes per h row
   constexpr int H_OFF = 0;            // h overlays the patch buffers (dead once conv1 is done): less LDS, more blocks per CU
   constexpr int NT1 = KT * NCH;       // taps of conv1 (chunk-major); conv2 has as many
@@ -299,19 +300,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
 #pragma unroll
   for (int g = 0; g < AHEAD; ++g) fetch(g);
   issue_patch(0, 0);
+  // NBUF = 3 (four chunks: C = 128): chunks 0, 1, 2 arrive in ONE round trip, chunk 3 goes into chunk 0's buffer once conv1 is
+  // done with it -- two exposed memory latencies per tile instead of four (a chunk is 0.2 us of MFMAs, a round trip 2 us)
+  if constexpr (NBUF == 3) {
+    issue_patch(1, CPATCH);
+    issue_patch(2, 2 * CPATCH);
+  }
   drain();
   transform_patch(0, 0);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const bool has_dma = c + 1 < NCH;
-    __syncthreads();  // patch c is visible; the other buffer is free
+    // the patch requested while this chunk is computed: the next one, or (three buffers) chunk 3 during chunk 1
+    const int dma_chunk = NBUF == 3 ? (c == 1 ? 3 : NCH) : c + 1;
+    const bool has_dma = dma_chunk < NCH;
+    __syncthreads();  // patch c is visible; the buffer of the chunk before it is free
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const int g = KT * c + k;
       fetch(g + AHEAD);
-      // the next chunk's patch is requested right after the fetch of this chunk's LAST tap, so every counted wait
+      // the patch is requested right after the fetch of this chunk's LAST tap, so every counted wait
       // below is for a fetch issued before it
-      if (k == KT - 1 - AHEAD && has_dma) issue_patch(c + 1, ((c + 1) & 1) * CPATCH);
+      if (k == KT - 1 - AHEAD && has_dma) issue_patch(dma_chunk, (dma_chunk % NBUF) * CPATCH);
       if (k >= AHEAD) wait_b_dyn<NG, WL, HI>(ring(g), WL * AHEAD + ((has_dma && k >= KT - 1 - AHEAD) ? NG : 0));
       int rows[WM], kov[WM];
 #pragma unroll
@@ -322,11 +331,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
         if constexpr (G2) asm volatile("" : "+v"(k0));  // recompute per tap: hoisting 18 keys out of the chunk loop spills
         kov[a] = ((k0 + hW1 * (k / 3) + (k % 3 == 2 ? 1 : 0) + (k % 3 == 1 ? kpar[a] : 0)) & 7) << 4;
       }
-      mma(ring(g), lds + (c & 1) * CPATCH, CROW, rows, -1, kov, G2);
+      mma(ring(g), lds + (c % NBUF) * CPATCH, CROW, rows, -1, kov, G2);
       __builtin_amdgcn_sched_barrier(0);
     }
     drain();
-    if (has_dma) transform_patch(((c + 1) & 1) * CPATCH, c + 1);
+    if (c + 1 < NCH) transform_patch(((c + 1) % NBUF) * CPATCH, c + 1);
   }
 
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
 static size_t resblock_lds_bytes(int C) {
   const size_t h_end = (size_t)CBM * C * 4;                       // h overlays the patch buffers
   const size_t epi_end = (size_t)CBM * (C + 4) * 4 + CBM * 4;
-  const size_t patches = (size_t)(C == 32 ? 1 : 2) * CPATCH;      // one chunk: one buffer
+  const size_t patches = (size_t)(C == 32 ? 1 : (C == 128 ? 3 : 2)) * CPATCH;  // one chunk: one buffer; four chunks: three
   return std::max(std::max(h_end, patches), epi_end);
 }
 
