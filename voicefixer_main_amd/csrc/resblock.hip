@@ -29,15 +29,21 @@ namespace vfx {
 
 // n is a compile-time constant after unrolling; only these counts occur (NG = patch DMA instructions per wave,
 // WL = weight loads per tap and wave)
+#ifndef VFX_RB_RING32
+#define VFX_RB_RING32 3  // weight ring of the C = 32 2-D block (see RING below); 5 needs three blocks per CU instead of four
+#endif
+
 template <int NG, int WL, bool HI>
 __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
-  switch (n) {
-    case WL: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL) : "memory"); break;
-    case 2 * WL: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * WL) : "memory"); break;
-    case WL + NG: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL + NG) : "memory"); break;
-    case 2 * WL + NG: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * WL + NG) : "memory"); break;
+#define VFX_WAIT_CASE(v) case v: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(v) : "memory"); break;
+  switch (n) {  // n is a compile-time constant after unrolling: AHEAD weight fetches (WL loads each) [+ one patch request (NG)]
+    VFX_WAIT_CASE(1) VFX_WAIT_CASE(2) VFX_WAIT_CASE(3) VFX_WAIT_CASE(4) VFX_WAIT_CASE(5) VFX_WAIT_CASE(6) VFX_WAIT_CASE(7)
+    VFX_WAIT_CASE(8) VFX_WAIT_CASE(9) VFX_WAIT_CASE(10) VFX_WAIT_CASE(11) VFX_WAIT_CASE(12) VFX_WAIT_CASE(13) VFX_WAIT_CASE(14)
+    VFX_WAIT_CASE(15) VFX_WAIT_CASE(16) VFX_WAIT_CASE(17) VFX_WAIT_CASE(18) VFX_WAIT_CASE(19) VFX_WAIT_CASE(20) VFX_WAIT_CASE(21)
+    VFX_WAIT_CASE(22) VFX_WAIT_CASE(23) VFX_WAIT_CASE(24)
     default: asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); break;
   }
+#undef VFX_WAIT_CASE
   if constexpr (HI) use_b_hi(R);
   else use_b(R);
 }
@@ -49,7 +55,7 @@ __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
 // Cin == Cout, identity shortcut):  y = x + conv2(lrelu(bn2(conv1(lrelu(bn1(x))))))  with 3x3 convolutions.  Tile = h grid
 // of TH x W1 = 128 pixels (8 x 16 or 16 x 8), outputs = its interior, x patch = (TH + 2) x (W1 + 2) = 180 pixels.
 template <int C, int NW, bool HI, bool G2 = false>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)) void k_resblock(const ResBlockParams* __restrict__ pp) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? (VFX_RB_RING32 >= 5 ? 3 : 4) : 3) : (HI ? 4 : 2)) void k_resblock(const ResBlockParams* __restrict__ pp) {
   constexpr int KT = G2 ? 9 : 3;  // taps per convolution
   constexpr int WL = HI ? 2 : 4;  // weight loads per tap and wave (HI: fp16 operands, hi fragments only)
   constexpr int NTHR = NW * 64;
@@ -58,7 +64,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
   static_assert(kPatchMaxRows % RG == 0, "patch rows must split into whole DMA groups");
   constexpr int NCH = C / 32;  // 32-channel chunks = waves along N
   constexpr int WAVES_N = NCH, WAVES_M = NW / WAVES_N, WM = 4 / WAVES_M;  // (C, NW) = (64, 4): 2, 2, 2;  (128, 8): 4, 2, 2
-  constexpr int RING = WM >= 4 ? 2 : 3, AHEAD = RING - 1;
+  // weight taps in flight.  C = 32 (2-D blocks): the timing-only build without weight refreshes (-DVFX_RB_ABL_NOWEIGHTS) runs that
+  // block 25 % faster, but deeper rings do not (-DVFX_RB_RING32=4: 2.97 ms per step against 2.95 with 3; 5 at three blocks per CU:
+  // 3.40): it is not the latency of a fetch but their number -- the four waves of a block (32 pixels x ALL 32 output channels each)
+  // fetch the same 74 KB of fragments per tile, four blocks per CU: ~30 B/clk of the CU's 64 B/clk L2 path.
+  constexpr int RING = WM >= 4 ? 2 : ((C == 32 && G2) ? VFX_RB_RING32 : 3), AHEAD = RING - 1;
   constexpr int NBUF = (NCH == 4 && !G2) ? 3 : 2;  // patch buffers (chunks in flight / in use)
   constexpr int HROW = C * 4;         // bytes per h row
   constexpr int H_OFF = 0;            // h overlays the patch buffers (dead once conv1 is done): less LDS, more blocks per CU
@@ -270,10 +280,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
   };
 
   // ---- weight ring: global tap g (conv1: 0 .. NT1-1, conv2: NT1 .. 2*NT1-1) in register group g % RING ------
-  BFrag R0 = {}, R1 = {}, R2 = {};
-  auto ring = [&](int g) __attribute__((always_inline)) -> BFrag& { return g % RING == 0 ? R0 : (g % RING == 1 ? R1 : R2); };
+  BFrag R0 = {}, R1 = {}, R2 = {}, R3 = {}, R4 = {};
+  auto ring = [&](int g) __attribute__((always_inline)) -> BFrag& {
+    const int i = g % RING;
+    return i == 0 ? R0 : (i == 1 ? R1 : (i == 2 ? R2 : (i == 3 ? R3 : R4)));
+  };
   auto fetch = [&](int g) __attribute__((always_inline)) {
     const float* w = g < NT1 ? p.w1 + g * ts : (g < 2 * NT1 ? p.w2 + (g - NT1) * ts : p.w2 + (NT1 - 1) * ts);
+#ifdef VFX_RB_ABL_NOWEIGHTS  // timing-only build (wrong results): the weight ring is filled once and never refreshed
+    if (g >= RING) return;
+#endif
     if constexpr (HI) load_b_asm_hi(ring(g), w, nb_off);
     else load_b_asm(ring(g), w, nb_off);
   };
@@ -282,11 +298,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (C == 32 ? 4 : 3) : (HI ? 4 : 2)
     if constexpr (HI) {
       use_b_hi(R0);
       use_b_hi(R1);
-      if constexpr (RING == 3) use_b_hi(R2);
+      if constexpr (RING >= 3) use_b_hi(R2);
+      if constexpr (RING >= 4) use_b_hi(R3);
+      if constexpr (RING >= 5) use_b_hi(R4);
     } else {
       use_b(R0);
       use_b(R1);
-      if constexpr (RING == 3) use_b(R2);
+      if constexpr (RING >= 3) use_b(R2);
+      if constexpr (RING >= 4) use_b(R3);
+      if constexpr (RING >= 5) use_b(R4);
     }
   };
 

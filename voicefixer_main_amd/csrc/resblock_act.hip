@@ -58,8 +58,9 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
 #endif
   // Weight taps in flight: a tap is requested AHEAD taps before its use.  One tap of the MT = 128 form is 16 MFMAs (0.2 us) per
   // wave against an L2 round trip of ~0.6 us, but deeper rings measured no gain (-DVFX_RBA_RING=3 / 4: 0.974 / 0.999 ms median
-  // per layer against 0.966 with one tap ahead, same box; 221 / 238 registers): the arithmetic phase waits for LDS -- every MFMA
-  // needs its own 1 KB A fragment from LDS, which is the LDS bandwidth of the CU at full MFMA rate -- not for weights.
+  // per layer against 0.966 with one tap ahead, same box; 221 / 238 registers): the arithmetic phase does not wait for weights.
+  // (Every MFMA takes its own 1 KB A fragment from LDS -- 128 B/clk per CU at full MFMA rate, half of what ds_read_b128 delivers --
+  // and the two waves of a SIMD wait for those reads and for the block barriers between the phases.)
   constexpr int RING = MT == 128 ? VFX_RBA_RING : 2, AHEAD = RING - 1;
 #ifndef VFX_RBA_PFNEXT
 #define VFX_RBA_PFNEXT 1
