@@ -50,6 +50,7 @@ sys.path.insert(0, HERE)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (spec; 2495 measured)
+PEAK_VALU_TFLOPS = 157.3        # fp32 vector peak (packed FMA), MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MAC_MEL_PER_FRAME = 92853664
 MAC_SPEC_PER_FRAME = 780251136
@@ -270,11 +271,24 @@ def measure_hbm_stages(eng, B, L, reps=20):
     re, im = sp * co, sp * si
     t_is = timed(lambda: lib.vfx_istft(h, P(re), P(im), B, T, L, P(out), st))
 
-    def line(bytes_per_frame, t):
+    # arithmetic per frame (fp32 flops): 1024-point complex FFT 5 N log2 N = 51 200; real-FFT untangle + magnitude 1025 x 21
+    # (+ 3 for cos / sin); window 2048; mel 2 x 2018.  Inverse: pack 1024 x 20, FFT, window + scale 2 x 2048, overlap-add 2048.
+    # Against the fp32 vector peak (157.3 TFLOP/s, packed FMA) the ridge is 19.7 flop/B: the mel-only front-end (35 flop/B)
+    # is bound by VALU issue, the phase-emitting one and the ISTFT by HBM.
+    def line(bytes_per_frame, flop_per_frame, t):
         gbs = bytes_per_frame * frames / t / 1e9
-        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+        tf = flop_per_frame * frames / t / 1e12
+        inten = flop_per_frame / bytes_per_frame
+        return {"bound": "valu" if inten > PEAK_VALU_TFLOPS * 1e3 / PEAK_HBM_GBS else "hbm",
+                "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "valu": {"achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s (fp32 vector)",
+                         "frac": round(tf / PEAK_VALU_TFLOPS, 4), "flop_per_frame": flop_per_frame},
+                "intensity_flop_per_byte": round(inten, 1),
                 "bytes_per_frame": bytes_per_frame, "frames": frames, "us": round(t * 1e6, 1)}
-    return {"stft_mel": line(2276, t_mel), "stft_phase": line(14064, t_ph), "istft": line(9964, t_is)}
+    fft = 51200
+    return {"stft_mel": line(2276, fft + 1025 * 21 + 2048 + 2 * 2018, t_mel),
+            "stft_phase": line(14064, fft + 1025 * 24 + 2048, t_ph),
+            "istft": line(9964, fft + 1024 * 20 + 2 * 2048 + 2048, t_is)}
 
 
 def live_traffic(args):

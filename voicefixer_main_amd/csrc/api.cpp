@@ -657,6 +657,7 @@ void set_mel_filterbank(vfx_handle* h, const float* fb) {
   }
   off[NM] = (int)val.size();
   h->fe.fb_val = h->blob.upload(val);
+  h->fe.fb_nnz = (int)val.size();
   h->fe.fb_start = h->blob.upload_i(start);
   h->fe.fb_off = h->blob.upload_i(off);
 }

@@ -1,25 +1,31 @@
 // stft.hip -- fused STFT front-end / ISTFT back-end for gfx950.
 //
-// Forward (vfx_stft_mel): a 256-thread workgroup walks F consecutive frames of one clip (F chosen so that the whole
-//   launch is about one round of resident workgroups).  What does not depend on the frame is fetched ONCE per
-//   workgroup -- the periodic Hann window (8 values per thread, registers), the twiddle table of the five radix-4
-//   passes (LDS), the band bounds of the mel filterbank -- and the samples of frame t+1 are
-//   requested before the FFT of frame t starts, so a frame costs LDS traffic and barriers only:
-//   reflect-padded frame x window  ->  1024-point complex radix-4 Stockham FFT in LDS (5 passes, one butterfly per
-//   thread per pass)  ->  real-FFT untangle to 1025 bins  ->  mag = sqrt(max(re^2+im^2, eps)), cos = re/mag,
-//   sin = im/mag (FDomainHelper.spectrogram_phase, tools/pytorch/modules/fDomainHelper.py:60-65)  ->  banded sparse
-//   mel projection from LDS (MelScale.forward, tools/pytorch/mel_scale.py:52-64; the filterbank has 2018 non-zeros,
-//   1..55 per band)  ->  optional log10(max(.,1e-8)) (to_log, tools/pytorch/pytorch_util.py:157-159).
-//   The reference does the DFT as two conv1d(1->1025, k=2048) = 4.2 MMAC/frame; the FFT needs ~0.06 MFLOP/frame,
-//   which makes the stage HBM/latency bound: 441 new samples in, 128 mel out per frame (2276 B/frame algorithmic)
-//   when sp/cos/sin are not requested.  (One frame per workgroup, everything re-fetched per frame: 0.30 TB/s.)
+// Forward (vfx_stft_mel): ONE WAVE per frame.  A wave walks F consecutive frames of one clip (F chosen so that the launch is
+//   about one round of resident waves); four waves share a workgroup's tables -- the FFT twiddles, the periodic Hann window
+//   and the non-zeros of the mel filterbank in LDS -- and nothing else: after the table fill there is no block barrier.
+//   Per frame: reflect-padded frame x window  ->  1024-point complex FFT by the wave (64 lanes x 16 points: Stockham passes of
+//   radix 16, 16, 4, three exchanges through the wave's own 8.7 KB of LDS)  ->  real-FFT untangle to 1025 bins  ->
+//   mag = sqrt(max(re^2+im^2, eps)), cos = re/mag, sin = im/mag (FDomainHelper.spectrogram_phase,
+//   tools/pytorch/modules/fDomainHelper.py:60-65)  ->  banded sparse mel projection from LDS (MelScale.forward,
+//   tools/pytorch/mel_scale.py:52-64; the filterbank has 2018 non-zeros, 1..55 per band; a lane sums band `lane` and band
+//   `127 - lane`)  ->  optional log10(max(.,1e-8)) (to_log, tools/pytorch/pytorch_util.py:157-159).  The samples of frame
+//   t+1 are requested before the FFT of frame t.
+//   The reference does the DFT as two conv1d(1->1025, k=2048) = 4.2 MMAC/frame; the FFT path needs 79 kflop/frame.  With
+//   2276 B/frame of algorithmic traffic (441 new samples in, 128 mel out) the mel-only front-end is bound by VALU ISSUE, not
+//   by HBM (35 flop/B against a ridge of 20): a wave64 instruction occupies its SIMD for four cycles and a frame is ~2300 of
+//   them.  Measured (16 x 10 s): 65 us = 0.07 of the HBM roofline / 0.12 of the fp32 vector peak; the phase-emitting form
+//   (14 KB/frame, HBM-bound) 59 us = 0.48 of 8 TB/s.  History: one frame per workgroup with everything re-fetched 121 us;
+//   a 256-thread workgroup walking F frames with a five-pass radix-4 FFT (two block barriers per pass) 90 / 71 us --
+//   7 us of barrier and LDS latency per frame and only five workgroups per CU to hide it.
 //
-// Inverse (vfx_istft): ONE kernel.  A workgroup owns IH = 8 hops of the overlap-add buffer and runs the frames that
-//   reach into them (IH + floor(2047 / hop) = 12 frames; IH = 2 for launches too small to fill the chip; the 4 halo frames are recomputed by the neighbouring
-//   workgroup -- their spectra come from L2): Hermitian spectrum -> packed 1024-point complex inverse FFT -> x synthesis
-//   window -> added into the workgroup's slice of the overlap-add buffer IN LDS; at the end every owned sample is
-//   divided by the window sum-of-squares envelope (summed from the window on the fly) and written once.  The
-//   16 KB-per-frame buffer of windowed frames that a two-kernel form moves through HBM (write + read) does not exist.
+// Inverse (vfx_istft): ONE kernel.  A workgroup owns IH = 16 hops of the overlap-add buffer (LDS) and runs the frames that
+//   reach into them (IH + 4 = 20; IH = 2 for launches too small to fill the chip; the 4 halo frames are recomputed by the
+//   neighbouring workgroup -- their spectra come from L2), one frame per wave at a time: Hermitian spectrum -> packed
+//   1024-point complex inverse FFT (the same wave-level transform) -> x synthesis window -> added into the buffer.  Frames
+//   that run together are at least five apart, so they touch disjoint samples, and a sample's contributions arrive in a fixed
+//   order: five rounds, one block barrier each.  At the end every owned sample is divided by the window sum-of-squares
+//   envelope (summed from the window on the fly) and written once.  The 16 KB-per-frame buffer of windowed frames that a
+//   two-kernel form moves through HBM (write + read) does not exist.
 //   torchlibrosa ISTFT semantics (see oracle/dsp.py): `y[:, n_fft//2 : n_fft//2 + length]`.
 #include "vfx_internal.h"
 
@@ -49,38 +55,94 @@ __device__ __forceinline__ void fft4(float2& v0, float2& v1, float2& v2, float2&
   v3 = make_float2(a1.x - a3.x, a1.y - a3.y);
 }
 
-// 1024-point Stockham FFT, 256 threads, data in `z` (LDS, natural order in and out).
-// `v` holds this thread's four inputs of the FIRST pass (z[j + r*256]); `twl` = the workgroup's LDS copy of
-// e^{-2 pi i m / 1024} (pass p multiplies input r by twl[k r 1024 / (4 Ns)], Ns = 4^p, k = j mod Ns; conjugated for the
-// inverse).  The caller guarantees that nobody reads `z` any more when this is entered; all of `z` is valid (and a
-// barrier has been passed) on return.
+// ---- wave-level 1024-point complex FFT -----------------------------------------------------------------------------------
+// ONE wave transforms a frame: 64 lanes x 16 points, Stockham passes of radix 16, 16, 4 (the 16-point butterfly = two
+// radix-4 stages in registers), the three exchanges through the wave's own LDS buffer -- no block barrier anywhere: a
+// wave's LDS operations execute in order, so a `wave_sync()` (compiler fence) between a store and the loads of other lanes'
+// data is all it takes.  The 256-thread form (five radix-4 passes, two block barriers each, one frame per workgroup at a
+// time) kept the chip at a handful of frames in flight per CU: 7 us per frame of barrier and LDS latency for 0.3 us of
+// arithmetic.
+constexpr int ZP = NC + NC / 16 + 1;  // float2 per wave buffer: one pad element per 16 (conflict-free strided access) + 1 (below)
+__device__ __forceinline__ int zpad(int i) { return i + (i >> 4); }
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// 16-point DFT in registers, n = 4a + b -> k = c + 4d: radix-4 over a, twiddle W16^(bc), radix-4 over b.
+// On return X[k] sits in v[4 (k & 3) + (k >> 2)] (see out16()).
 template <int SIGN>
-__device__ __forceinline__ void fft1024(float2* z, float2 v[4], const float2* twl, int j) {
+__device__ __forceinline__ void fft16(float2 (&v)[16]) {
 #pragma unroll
-  for (int pass = 0; pass < 5; ++pass) {
-    const int Ns = 1 << (2 * pass);
-    const int k = j & (Ns - 1);
-    if (pass > 0) {
-      const int tstep = NC / (4 * Ns);  // table stride of this pass
-      float2 w[3];
+  for (int b = 0; b < 4; ++b) fft4<SIGN>(v[b], v[4 + b], v[8 + b], v[12 + b]);  // v[4c + b] = Y_b[c]
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+  constexpr float s = SIGN < 0 ? -1.f : 1.f;  // W16^m = cos(2 pi m / 16) + s i sin(2 pi m / 16)
+  auto tw = [&](float2& x, float c, float sn) __attribute__((always_inline)) { x = cmul(x, make_float2(c, s * sn)); };
+  tw(v[4 * 1 + 1], C1, S1);    // m = 1
+  tw(v[4 * 1 + 2], R2, R2);    // m = 2
+  tw(v[4 * 1 + 3], S1, C1);    // m = 3
+  tw(v[4 * 2 + 1], R2, R2);    // m = 2
+  v[4 * 2 + 2] = SIGN < 0 ? make_float2(v[10].y, -v[10].x) : make_float2(-v[10].y, v[10].x);  // m = 4: -+ i
+  tw(v[4 * 2 + 3], -R2, R2);   // m = 6
+  tw(v[4 * 3 + 1], S1, C1);    // m = 3
+  tw(v[4 * 3 + 2], -R2, R2);   // m = 6
+  tw(v[4 * 3 + 3], -C1, -S1);  // m = 9
 #pragma unroll
-      for (int r = 1; r < 4; ++r) {
-        w[r - 1] = twl[k * r * tstep];
-        if (SIGN > 0) w[r - 1].y = -w[r - 1].y;
-      }
-      __syncthreads();
+  for (int c = 0; c < 4; ++c) fft4<SIGN>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);  // v[4c + d] = X[c + 4d]
+}
+__device__ __forceinline__ constexpr int out16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+// In: v[r] = x[lane + 64 r].  Out: v[m] = X[lane + 64 m] (natural order).  `zw` = this wave's LDS buffer (ZP float2), `twl` =
+// the workgroup's LDS copy of e^{-2 pi i m / 1024} (conjugated here for the inverse).
+template <int SIGN>
+__device__ __forceinline__ void wfft1024(float2 (&v)[16], float2* zw, const float2* twl, int lane) {
+  auto twid = [&](int idx) __attribute__((always_inline)) {
+    float2 w = twl[idx];
+    if (SIGN > 0) w.y = -w.y;
+    return w;
+  };
+  // (padded positions written out: i + (i >> 4) is linear in r for every access pattern below, so each is one base address
+  // plus an immediate offset)
+  // pass 1: radix 16, Ns = 1 (no twiddles): out[16 lane + r] -> 17 lane + r
+  fft16<SIGN>(v);
+  float2* const w1 = zw + 17 * lane;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = z[j + r * (NC / 4)];
+  for (int r = 0; r < 16; ++r) w1[r] = v[out16(r)];
+  wave_sync();
+  // pass 2: radix 16, Ns = 16: in[lane + 64 r] * W256^(k r), k = lane mod 16;  out[16 (lane - k) + k + 16 r]
+  const int k = lane & 15;
+  const float2* const r2 = zw + lane + (lane >> 4);  // in[lane + 64 r] -> + 68 r
 #pragma unroll
-      for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], w[r - 1]);
-      __syncthreads();
-    }
-    fft4<SIGN>(v[0], v[1], v[2], v[3]);
-    const int j0 = ((j - k) << 2) + k;
+  for (int r = 0; r < 16; ++r) v[r] = r2[68 * r];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) z[j0 + r * Ns] = v[r];
+  for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], twid(4 * k * r));
+  wave_sync();
+  fft16<SIGN>(v);
+  float2* const w2 = zw + 17 * (lane - k) + k;  // out[16 (lane - k) + k + 16 r] -> + 17 r
+#pragma unroll
+  for (int r = 0; r < 16; ++r) w2[17 * r] = v[out16(r)];
+  wave_sync();
+  // pass 3: radix 4, Ns = 256: four butterflies per lane, j = lane + 64 q: in[j + 256 r] * W1024^(j r) -> X[j + 256 r]
+  float2 u[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = lane + 64 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[4 * q + r] = r2[68 * q + 272 * r];  // in[j + 256 r]
+#pragma unroll
+    for (int r = 1; r < 4; ++r) u[4 * q + r] = cmul(u[4 * q + r], twid(j * r));
+    fft4<SIGN>(u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]);
   }
-  __syncthreads();
+  wave_sync();  // every lane is done reading zw: the caller may overwrite it
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[q + 4 * r] = u[4 * q + r];  // X[lane + 64 (q + 4 r)]
+}
+
+// base[idx] with a wave-uniform base and a 32-bit BYTE offset: the scalar-base addressing mode (one VGPR per address)
+__device__ __forceinline__ float ldg32(const float* base, unsigned idx) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + 4u * idx);
 }
 
 __device__ __forceinline__ int reflect_index(int i, int L) {
@@ -88,72 +150,124 @@ __device__ __forceinline__ int reflect_index(int i, int L) {
   return i >= L ? 2 * (L - 1) - i : i;
 }
 
-// The four sample pairs (x[2n], x[2n+1]), n = j + 256 r, of the reflect-padded frame t.
-__device__ __forceinline__ void load_frame(const float* __restrict__ x, int L, int t, int hop, int j, float2 out[4]) {
+// The sixteen sample pairs (x[2n], x[2n+1]), n = lane + 64 r, of the reflect-padded frame t.  `x` is wave-uniform (a scalar
+// base): every load is base + one 32-bit lane offset.
+__device__ __forceinline__ void load_frame(const float* __restrict__ x, int L, int t, int hop, int lane, float2 (&out)[16]) {
   const int base = t * hop - NFFT / 2;
+  if (base >= 0 && base + NFFT <= L) {  // wave-uniform: an interior frame
+    const unsigned o = (unsigned)(base + 2 * lane);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int g = base + 2 * (j + r * (NC / 4));
-    if (g >= 0 && g + 1 < L) out[r] = make_float2(x[g], x[g + 1]);
-    else out[r] = make_float2(x[reflect_index(g, L)], x[reflect_index(g + 1, L)]);
+    for (int r = 0; r < 16; ++r) out[r] = make_float2(ldg32(x, o + 128u * r), ldg32(x, o + 128u * r + 1u));
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int g = base + 2 * (lane + 64 * r);
+      out[r] = make_float2(ldg32(x, (unsigned)reflect_index(g, L)), ldg32(x, (unsigned)reflect_index(g + 1, L)));
+    }
   }
 }
 
-__global__ __launch_bounds__(256, 5) void k_stft_mel(const float* __restrict__ wav, int L, int T,
-                                                   const float* __restrict__ window,
-                                                   const float2* __restrict__ tw,
-                                                   const float2* __restrict__ rtw,
-                                                   const float* __restrict__ fb_val,
-                                                   const int* __restrict__ fb_start,
-                                                   const int* __restrict__ fb_off, float* __restrict__ mel,
-                                                   float* __restrict__ sp, float* __restrict__ cosp,
-                                                   float* __restrict__ sinp, int log10_mel, int hop, float eps,
-                                                   int F, int groups) {
-  __shared__ float2 z[NC];
+constexpr int STFT_WAVES = 4;  // waves per workgroup: each walks its own frames
+
+// e^{-2 pi i (lane + 64 m) / 2048} = e^{-2 pi i lane / 2048} * e^{-2 pi i m / 32}: the lane's own factor (one table read per
+// wave) times a compile-time constant -- no table read per bin
+__device__ __forceinline__ float2 rtw_of(float2 lane_w, int m) {
+  constexpr float C[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                           0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.f, -0.19509032201612825f,
+                           -0.38268343236508977f, -0.55557023301960218f, -0.70710678118654752f, -0.83146961230254524f,
+                           -0.92387953251128674f, -0.98078528040323043f};
+  constexpr float S[16] = {0.f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f, 0.70710678118654752f,
+                           0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f,
+                           0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960218f,
+                           0.38268343236508977f, 0.19509032201612825f};
+  return cmul(lane_w, make_float2(C[m], -S[m]));
+}
+
+// SPEC: the launch writes sp / cos / sin (any of them); false = the mel-only front-end of the restore path
+template <bool SPEC>
+__global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_stft_mel(const float* __restrict__ wav, int L, int T,
+                                                                 const float* __restrict__ window,
+                                                                 const float2* __restrict__ tw,
+                                                                 const float2* __restrict__ rtw,
+                                                                 const float* __restrict__ fb_val,
+                                                                 const int* __restrict__ fb_start,
+                                                                 const int* __restrict__ fb_off, float* __restrict__ mel,
+                                                                 float* __restrict__ sp, float* __restrict__ cosp,
+                                                                 float* __restrict__ sinp, int log10_mel, int hop, float eps,
+                                                                 int F, int groups, int total_groups, int fb_lds) {
   __shared__ float2 twl[NC];
-  __shared__ float mag_s[NBINS + 3];
-  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+  __shared__ float2 wl[NC];  // the window, as pairs (w[2n], w[2n+1])
+  __shared__ float fbl[kMelNnzMax];  // the non-zeros of the mel filterbank (band-major): the band sums read them once per frame
+  __shared__ float2 zbuf[STFT_WAVES][ZP];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = tid & 63;
+#pragma unroll
+  for (int r = 0; r < NC / (STFT_WAVES * 64); ++r) {
+    twl[tid + r * STFT_WAVES * 64] = tw[tid + r * STFT_WAVES * 64];
+    wl[tid + r * STFT_WAVES * 64] = *reinterpret_cast<const float2*>(window + 2 * (tid + r * STFT_WAVES * 64));
+  }
+  if (mel && fb_lds)  // (a caller-supplied filterbank with more non-zeros than the table holds is read from global memory)
+    for (int i = tid; i < fb_off[NMEL]; i += STFT_WAVES * 64) fbl[i] = fb_val[i];
+  __syncthreads();  // the only block barrier: from here on the waves are independent
+  const int gw = blockIdx.x * STFT_WAVES + wave;  // this wave's group of F consecutive frames of one clip
+  if (gw >= total_groups) return;
+  const int b = gw / groups, g = gw - b * groups;
   const int t_begin = g * F, t_end = min(T, t_begin + F);
-  const int j = threadIdx.x;
   const float* x = wav + (int64_t)b * L;
+  float2* zw = zbuf[wave];
+  float* ms = reinterpret_cast<float*>(zw);  // the magnitudes of the frame, over the FFT buffer once it is consumed
 
-  // constants of the whole frame walk: the FFT twiddle table in LDS, the window in registers
-  float2 w[4];
+  // constants of the frame walk: this lane's two mel bands
+  int f0[2], o0[2], nb[2];
+  // (band lane and band 127 - lane: the bands grow with the frequency -- 1 .. 55 bins -- so every lane sums about 32 products)
+  const int band[2] = {lane, NMEL - 1 - lane};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    twl[j + r * (NC / 4)] = tw[j + r * (NC / 4)];
-    w[r] = *reinterpret_cast<const float2*>(window + 2 * (j + r * (NC / 4)));
-  }
-  int f0 = 0, o0 = 0, nb = 0;
-  if (j < NMEL) {
-    f0 = fb_start[j];
-    o0 = fb_off[j];
-    nb = fb_off[j + 1] - o0;
+  for (int h = 0; h < 2; ++h) {
+    f0[h] = fb_start[band[h]];
+    o0[h] = fb_off[band[h]];
+    nb[h] = fb_off[band[h] + 1] - o0[h];
   }
 
-  float2 xin[4];
-  if (t_begin < t_end) load_frame(x, L, t_begin, hop, j, xin);
-  __syncthreads();  // twl is complete (fft1024 reads it before its first barrier)
+  const float2 rtw_lane = rtw[lane];
+  float2 xin[16];
+  load_frame(x, L, t_begin, hop, lane, xin);
   for (int t = t_begin; t < t_end; ++t) {
-    float2 v[4];
+    asm volatile("" : "+v"(lane));  // the frame-independent LDS addresses are recomputed per frame, not kept (and spilled)
+    float2 v[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = make_float2(xin[r].x * w[r].x, xin[r].y * w[r].y);
-    if (t + 1 < t_end) load_frame(x, L, t + 1, hop, j, xin);  // in flight during this frame's FFT
-    fft1024<-1>(z, v, twl, j);
+    for (int r = 0; r < 16; ++r) {
+      const float2 ww = wl[lane + 64 * r];
+      v[r] = make_float2(xin[r].x * ww.x, xin[r].y * ww.y);
+    }
+    if (t + 1 < t_end) load_frame(x, L, t + 1, hop, lane, xin);  // in flight during this frame's FFT
+    wfft1024<-1>(v, zw, twl, lane);
+    // natural order to LDS: the untangle pairs Z[k] with Z[1024 - k], which another lane holds
+    float2* const nat = zw + lane + (lane >> 4);  // Z[lane + 64 m] -> + 68 m
+#pragma unroll
+    for (int m = 0; m < 16; ++m) nat[68 * m] = v[m];
+    wave_sync();
+    // Z[1024 - (lane + 64 m)] = Z[(64 - lane) + 64 (15 - m)]; lane 0: Z[64 (16 - m)], and Z[1024] = Z[0] is its own v[0]
+    // (its read of m = 0 lands on the spare element behind the buffer)
+    const int jp = 64 - lane;
+    const float2* const par = lane == 0 ? zw + 68 : zw + jp + (jp >> 4);
+    float2 zn[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) zn[m] = par[68 * (15 - m)];
+    if (lane == 0) zn[0] = v[0];
+    wave_sync();  // zw is free: the magnitudes go over it
+    __builtin_amdgcn_sched_barrier(0);
 
     // real-FFT untangle: X[k] = E[k] + W^k O[k], E = (Z[k] + conj Z[N-k]) / 2, O = (Z[k] - conj Z[N-k]) / (2i)
     const int64_t row = ((int64_t)b * T + t) * NBINS;
-    auto bin = [&](int k, float2 wk) __attribute__((always_inline)) {
-      const float2 zk = z[k & (NC - 1)];
-      const float2 zn = z[(NC - k) & (NC - 1)];
-      const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-      const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    auto bin = [&](int k, float2 zk, float2 znk, float2 wk) __attribute__((always_inline)) {
+      const float2 e = make_float2(0.5f * (zk.x + znk.x), 0.5f * (zk.y - znk.y));
+      const float2 o = make_float2(0.5f * (zk.y + znk.y), -0.5f * (zk.x - znk.x));
       const float2 wo = cmul(wk, o);
       const float re = e.x + wo.x, im = e.y + wo.y;
-      // clamp on the POWER (fDomainHelper.py:62).  v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the IEEE expansions: the
-      // kernel is bound by instruction issue (~700 per wave and frame), and these were a fifth of them
+      // clamp on the POWER (fDomainHelper.py:62); v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the IEEE expansions
       const float mag = __builtin_amdgcn_sqrtf(fmaxf(re * re + im * im, eps));
-      mag_s[k] = mag;
+      ms[k] = mag;
+      if constexpr (!SPEC) return;
       if (sp) sp[row + k] = mag;
       if (cosp || sinp) {
         const float inv = __builtin_amdgcn_rcpf(mag);  // mag = 0 (eps = 0, silent bin): inf, 0 * inf = NaN like 0 / 0
@@ -162,22 +276,34 @@ __global__ __launch_bounds__(256, 5) void k_stft_mel(const float* __restrict__ w
       }
     };
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bin(j + r * (NC / 4), rtw[j + r * (NC / 4)]);  // the same four L1 lines every frame
-    if (j == 0) bin(NC, rtw[NC]);
-    __syncthreads();  // mag_s complete; every read of z is done before the next frame's first pass writes it
-    if (mel && j < NMEL) {
-      float acc0 = 0.f, acc1 = 0.f;  // two chains: the loads of the loop do not depend on the sums
-      int i = 0;
-      for (; i + 1 < nb; i += 2) {
-        acc0 = fmaf(mag_s[f0 + i], fb_val[o0 + i], acc0);
-        acc1 = fmaf(mag_s[f0 + i + 1], fb_val[o0 + i + 1], acc1);
-      }
-      if (i < nb) acc0 = fmaf(mag_s[f0 + i], fb_val[o0 + i], acc0);
-      const float acc = acc0 + acc1;
-      mel[((int64_t)b * T + t) * NMEL + j] = log10_mel ? log10f(fmaxf(acc, 1e-8f)) : acc;
+    for (int m = 0; m < 16; ++m) {
+      bin(lane + 64 * m, v[m], zn[m], rtw_of(rtw_lane, m));
+      if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four bins at a time: their temporaries are not 16-fold live
     }
-    // the next write of mag_s (next frame's untangle) lies behind the barriers of the next FFT, which the mel threads
-    // only reach after this loop body
+    if (lane == 0) bin(NC, v[0], zn[0], make_float2(-1.f, 0.f));  // Z[1024] = Z[0], W^1024 = -1
+    wave_sync();
+    if (mel) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // four chains (the loads of the loop do not depend on the sums)
+        const float* mp = ms + f0[h];
+        auto band_sum = [&](auto fp) __attribute__((always_inline)) {
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+          int i = 0;
+          for (; i + 3 < nb[h]; i += 4) {
+            a0 = fmaf(mp[i], fp[i], a0);
+            a1 = fmaf(mp[i + 1], fp[i + 1], a1);
+            a2 = fmaf(mp[i + 2], fp[i + 2], a2);
+            a3 = fmaf(mp[i + 3], fp[i + 3], a3);
+          }
+          for (; i < nb[h]; ++i) a0 = fmaf(mp[i], fp[i], a0);
+          return (a0 + a2) + (a1 + a3);
+        };
+        const float acc = fb_lds ? band_sum(fbl + o0[h]) : band_sum(fb_val + o0[h]);
+        mel[((int64_t)b * T + t) * NMEL + band[h]] = log10_mel ? log10f(fmaxf(acc, 1e-8f)) : acc;
+      }
+    }
+    wave_sync();  // ms is consumed before the next frame's first pass writes the buffer
   }
 }
 
@@ -204,76 +330,89 @@ __global__ __launch_bounds__(128) void k_mel_project(const float* __restrict__ s
 // (same in the in-repo twin tools/dsp/base.py:193-200, `end = start + length`): the L mod hop samples past hop*(T-1) are
 // reconstructed from the tails of the last frames.  Positions whose envelope is tiny are left undivided
 // (librosa.filters.window_sumsquare semantics).
-// IH = hops of the overlap-add buffer a workgroup owns: 8 (12 frames per workgroup) for large launches, 2 (6 frames, three
-// times the inverse FFTs but a third of the serial chain) when there are too few frames to fill the chip (streaming chunks)
-
-__device__ __forceinline__ void load_spectrum(const float* __restrict__ R, const float* __restrict__ I, int j, float2 xk[4],
-                                              float2 xn[4]) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int k = j + r * (NC / 4);
-    xk[r] = make_float2(R[k], I[k]);
-    xn[r] = make_float2(R[NC - k], I[NC - k]);
-  }
-}
-
-__global__ __launch_bounds__(256, 5) void k_istft(const float* __restrict__ re, const float* __restrict__ im,
-                                                const float* __restrict__ window, const float2* __restrict__ tw,
-                                                const float2* __restrict__ rtw, int T, int L, int hop, int groups,
-                                                int IH, float* __restrict__ wav) {
-  __shared__ float2 z[NC];
+// A workgroup owns IH hops of the overlap-add buffer (LDS) and runs the frames that reach into them, four at a time: each
+// wave packs and inverse-transforms its own frame (wave-level FFT, no barrier) and adds it into the buffer; which frames run
+// together is chosen so that they cannot touch the same sample (see the kernel).
+// IH = 16 (20 frames per workgroup) for large launches, 2 (6 frames, three times the inverse FFTs but a fraction of the serial
+// chain) when there are too few frames to fill the chip (streaming chunks).
+__global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_istft(const float* __restrict__ re, const float* __restrict__ im,
+                                                              const float* __restrict__ window, const float2* __restrict__ tw,
+                                                              const float2* __restrict__ rtw, int T, int L, int hop, int groups,
+                                                              int IH, float* __restrict__ wav) {
   __shared__ float2 twl[NC];
+  __shared__ float2 wl[NC];  // the synthesis window, as pairs
+  __shared__ float2 zbuf[STFT_WAVES][ZP];
   extern __shared__ __attribute__((aligned(16))) float ola[];  // [IH * hop]
   const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
-  const int j = threadIdx.x;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = tid & 63;
   const int span = IH * hop;
   const int p0 = g * span;                      // first owned position of the un-trimmed overlap-add buffer
   const int t_lo = max(0, g * IH - (NFFT - 1) / hop), t_hi = min(T - 1, g * IH + IH - 1);
-  for (int i = j; i < span; i += 256) ola[i] = 0.f;
-
-  float2 w[4];
+  for (int i = tid; i < span; i += STFT_WAVES * 64) ola[i] = 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    twl[j + r * (NC / 4)] = tw[j + r * (NC / 4)];
-    w[r] = *reinterpret_cast<const float2*>(window + 2 * (j + r * (NC / 4)));
+  for (int r = 0; r < NC / (STFT_WAVES * 64); ++r) {
+    twl[tid + r * STFT_WAVES * 64] = tw[tid + r * STFT_WAVES * 64];
+    wl[tid + r * STFT_WAVES * 64] = *reinterpret_cast<const float2*>(window + 2 * (tid + r * STFT_WAVES * 64));
   }
   const float sc = 1.0f / NC;
+  const float2 rtw_lane = rtw[lane];
+  __syncthreads();  // ola zeroed, twl and wl complete
 
-  float2 xk[4], xn[4];
-  if (t_lo <= t_hi) {
-    const int64_t f = (int64_t)b * T + t_lo;
-    load_spectrum(re + f * NBINS, im + f * NBINS, j, xk, xn);
-  }
-  __syncthreads();  // ola zeroed, twl complete
-  for (int t = t_lo; t <= t_hi; ++t) {
-    float2 v[4];
+  // the spectrum of this wave's frame of a round: (Re, Im) of bins k and 1024 - k, k = lane + 64 r
+  float2 xk[16], xn[16];
+  auto load_spectrum = [&](int t) __attribute__((always_inline)) {
+    const float* R = re + ((int64_t)b * T + t) * NBINS;
+    const float* I = im + ((int64_t)b * T + t) * NBINS;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float2 e = make_float2(0.5f * (xk[r].x + xn[r].x), 0.5f * (xk[r].y - xn[r].y));
-      const float2 d = make_float2(0.5f * (xk[r].x - xn[r].x), 0.5f * (xk[r].y + xn[r].y));
-      float2 wk = rtw[j + r * (NC / 4)];
-      wk.y = -wk.y;  // conj(W^k) = e^{+2 pi i k / 2048}
-      const float2 o = cmul(wk, d);
-      v[r] = make_float2(e.x - o.y, e.y + o.x);  // Z = E + i O
+    for (int r = 0; r < 16; ++r) {
+      const unsigned k = (unsigned)(lane + 64 * r);
+      xk[r] = make_float2(ldg32(R, k), ldg32(I, k));
+      xn[r] = make_float2(ldg32(R, NC - k), ldg32(I, NC - k));
     }
-    if (t < t_hi) {  // the next frame's spectrum travels during this frame's FFT
-      const int64_t f = (int64_t)b * T + t + 1;
-      load_spectrum(re + f * NBINS, im + f * NBINS, j, xk, xn);
-    }
-    fft1024<1>(z, v, twl, j);
-    const int off = t * hop - p0;  // frame sample o lands at owned index off + o
+  };
+  // Frames at least D apart touch disjoint samples.  Round r (D rounds, one block barrier each) takes the frames f = r (mod D) of
+  // the workgroup's n frames, wave w those with f / D = w (mod 4): the frames of a round add into the buffer CONCURRENTLY and
+  // never meet, and a sample's contributions arrive in round order -- sums that do not depend on timing.
+  const int D = (NFFT + hop - 1) / hop;
+  const int n = t_hi - t_lo + 1;
+  // this wave's frame list in processing order: (r, f) with f = r + D (wave + 4 j)
+  auto first_in_round = [&](int r) __attribute__((always_inline)) { return r + D * wave; };
+  int r = 0, f = first_in_round(0);
+  while (r < D && f >= n) f = first_in_round(++r);  // the first frame of this wave, if any
+  if (r < D) load_spectrum(t_lo + f);
+  for (int round = 0; round < D; ++round) {  // block-uniform trip count
+    while (r == round) {
+      const int t = t_lo + f;
+      asm volatile("" : "+v"(lane));  // as in the forward kernel
+      float2 v[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = j + r * (NC / 4);
-      const float2 zz = z[n];
-      const int i0 = off + 2 * n;
-      if (i0 >= 0 && i0 < span) ola[i0] += zz.x * sc * w[r].x;          // one thread per sample of the frame,
-      if (i0 + 1 >= 0 && i0 + 1 < span) ola[i0 + 1] += zz.y * sc * w[r].y;  // frames one after the other
+      for (int q = 0; q < 16; ++q) {
+        const float2 e = make_float2(0.5f * (xk[q].x + xn[q].x), 0.5f * (xk[q].y - xn[q].y));
+        const float2 d = make_float2(0.5f * (xk[q].x - xn[q].x), 0.5f * (xk[q].y + xn[q].y));
+        float2 wk = rtw_of(rtw_lane, q);
+        wk.y = -wk.y;  // conj(W^k) = e^{+2 pi i k / 2048}
+        const float2 o = cmul(wk, d);
+        v[q] = make_float2(e.x - o.y, e.y + o.x);  // Z = E + i O
+      }
+      // advance to this wave's next frame and request its spectrum: it travels during this frame's FFT
+      f += D * STFT_WAVES;
+      while (r < D && f >= n) f = first_in_round(++r);
+      if (r < D) load_spectrum(t_lo + f);
+      wfft1024<1>(v, zbuf[wave], twl, lane);
+      const int off = t * hop - p0;  // frame sample o lands at owned index off + o
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int i0 = off + 2 * (lane + 64 * m);
+        const float2 ww = wl[lane + 64 * m];
+        if (i0 >= 0 && i0 < span) ola[i0] += v[m].x * sc * ww.x;  // one lane per sample, no other frame of the round nearby
+        if (i0 + 1 >= 0 && i0 + 1 < span) ola[i0 + 1] += v[m].y * sc * ww.y;
+      }
     }
-    __syncthreads();  // the adds are done and z is free before the next frame's first pass
+    __syncthreads();
   }
   const int total = NFFT + hop * (T - 1);
-  for (int i = j; i < span; i += 256) {
+  for (int i = tid; i < span; i += STFT_WAVES * 64) {
     const int p = p0 + i, n = p - NFFT / 2;
     if (n < 0 || n >= L) continue;
     float out = 0.f;
@@ -296,10 +435,10 @@ __global__ __launch_bounds__(256, 5) void k_istft(const float* __restrict__ re, 
   }
 }
 
-// Frames per workgroup of the forward kernel: as many as keep the launch at one round of resident workgroups
-// (5 per CU -- 92 VGPRs, 20 KB of LDS -- x 256 CUs), at most 32.
+// Frames per wave of the forward kernel: as many as keep the launch at about one round of resident waves
+// (2 workgroups of 4 waves per CU -- 59 KB of LDS -- x 256 CUs), at most 32.
 static int frames_per_group(int64_t frames) {
-  const int64_t f = (frames + 1279) / 1280;
+  const int64_t f = (frames + 2047) / 2048;
   return (int)std::max<int64_t>(1, std::min<int64_t>(32, f));
 }
 
@@ -307,9 +446,12 @@ void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, in
                      float* cosp, float* sinp, int log10_mel, int hop, float eps, hipStream_t stream) {
   const int F = frames_per_group((int64_t)B * T);
   const int groups = (T + F - 1) / F;
-  hipLaunchKernelGGL(k_stft_mel, dim3(B * groups), dim3(256), 0, stream, wav, L, T, t.window,
+  const int total = B * groups;
+  auto kernel = (sp || cosp || sinp) ? k_stft_mel<true> : k_stft_mel<false>;
+  hipLaunchKernelGGL(kernel, dim3((total + STFT_WAVES - 1) / STFT_WAVES), dim3(STFT_WAVES * 64), 0, stream, wav, L, T, t.window,
                      reinterpret_cast<const float2*>(t.twiddle), reinterpret_cast<const float2*>(t.rtwiddle),
-                     t.fb_val, t.fb_start, t.fb_off, mel, sp, cosp, sinp, log10_mel, hop, eps, F, groups);
+                     t.fb_val, t.fb_start, t.fb_off, mel, sp, cosp, sinp, log10_mel, hop, eps, F, groups, total,
+                     t.fb_nnz <= kMelNnzMax ? 1 : 0);
   VFX_HIP(hipGetLastError());
 }
 
@@ -322,7 +464,7 @@ void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, 
 void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop, float* wav,
                   hipStream_t stream) {
   // groups cover the positions [0, 1024 + L) of the un-trimmed overlap-add buffer
-  const int IH = (int64_t)B * T >= 4096 ? 8 : 2;
+  const int IH = (int64_t)B * T >= 4096 ? 16 : 2;
   const int span = IH * hop;
   const int groups = (NFFT / 2 + L + span - 1) / span;
   hipLaunchKernelGGL(k_istft, dim3(B * groups), dim3(256), (size_t)span * sizeof(float), stream, re, im, t.window,

@@ -252,6 +252,8 @@ double conv_flops(const TapConvParams& hp);
 // ---------------------------------------------------------------------------------------------
 // front-end tables + small kernels -- see stft.hip / small_ops.hip
 // ---------------------------------------------------------------------------------------------
+constexpr int kMelNnzMax = 2048;  // non-zeros of the mel filterbank that k_stft_mel keeps in LDS (2018 for the 128-band HTK table)
+
 struct FrontEndTables {
   float* window = nullptr;    // [2048] periodic Hann
   float* twiddle = nullptr;   // [1024] float2 e^{-2 pi i m / 1024}
@@ -259,6 +261,7 @@ struct FrontEndTables {
   float* fb_val = nullptr;    // packed non-zeros of the mel filterbank, band-major
   int* fb_start = nullptr;    // [128] first frequency bin of band m
   int* fb_off = nullptr;      // [129] offsets into fb_val
+  int fb_nnz = 0;             // entries of fb_val (<= kMelNnzMax: k_stft_mel keeps them in LDS)
   float* voc_inv_weight = nullptr;  // [128] 1 / mel band weight
 };
 
