@@ -217,6 +217,11 @@ int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H, int W, in
 int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int C, const float* w1, const float* b1,
                     const float* w2, const float* b2, int dil, float slope, int fused, float* y, void* stream);
 
+/* Host-only (no GPU, no handle): the tile geometry the plan gives one fused ResStack layer -- or a layer pair, dil2 > 0 -- of
+ * C channels over sequences of T positions in precision mode `precision`.  out[12] = fold, TH, W1, TWo, tiles_h, tiles_w, PW, P,
+ * tile_m, rw, rl, asrc (ResBlockParams).  The CPU tests use it to check that the tiles cover every position exactly once. */
+int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int precision, int* out);
+
 /* Two consecutive ResStack layers (dilations dil, dil2) as ONE launch: y = layer_b(layer_a(x)), the intermediate tensor never
  * leaves the CU (resblock_rw.hip).  precision 2, C = 64, dil <= 32, dil2 <= 62 only -- what the vocoder plan pairs (dilations
  * (1, 3) and (9, 27) of the 44.1 kHz stack).  Weights / biases as in vfx_op_resblock, on the HOST. */

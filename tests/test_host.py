@@ -221,3 +221,45 @@ def test_committed_bench_line_follows_the_contract():
     # value = audio seconds of all ranks / wall seconds
     audio = d["n_gpus"] * d["config"]["clips_per_gpu"] * d["config"]["clip_seconds"]
     assert abs(d["value"] - audio / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+
+
+@pytest.mark.parametrize("C,precision", [(64, 2), (64, 1), (128, 2), (256, 2)])
+def test_resblock_tiles_cover_every_position_once(C, precision):
+    """Tile geometry of the fused ResStack kernels (plan_resblock, host-only entry point): over the vocoder's dilations, the
+    layer pairs of the 16-bit C = 64 stack and short / long / unaligned sequences, the outputs the kernels' masks let through
+    -- restated here from resblock.hip / resblock_rw.hip / resblock_act.hip -- hit every position exactly once, and the taps
+    of conv1 stay inside the patch."""
+    import ctypes
+    from voicefixer_main_amd import _lib
+    lib = _lib.load()
+    out = (ctypes.c_int * 12)()
+    cases = [(d, 0) for d in (1, 3, 9, 27, 81, 243, 729, 2187)]
+    if C == 64 and precision == 2:
+        cases += [(1, 3), (9, 27), (3, 9)]
+    for T in (3, 90, 1000, 49049, 70001):
+        for d, d2 in cases:
+            assert lib.vfx_plan_resblock_geometry(C, T, d, d2, precision, out) == 0, (T, d, d2)
+            fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, MT, rw, rl, asrc = list(out)
+            MT = MT or 128
+            assert P <= MT + 64 and TH * W1 <= MT and TH >= 1
+            hits = np.zeros(T, dtype=np.int32)
+            m = np.arange(MT)
+            for ti in range(tiles_h):
+                for tj in range(tiles_w):
+                    j0 = tj * TWo
+                    if d2 > 0:                      # pair: both layers over the index space of the tile
+                        pos = j0 - 2 - d2 + m
+                        ok = (m >= 2 + d2) & (m <= MT - 3 - d2)
+                    else:
+                        li, lj = m // W1, m % W1
+                        base_h = ti * TH * d + j0 - 1 if fold else j0 - 1
+                        pos = base_h + li * (d if fold else 0) + lj
+                        ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2)
+                        if fold:
+                            ok &= j0 + lj - 1 < d
+                        # conv1 reads patch rows li * PW + lj + k * (PW if fold else d), k = 0..2
+                        rows = np.where(li < TH, li * PW + lj, 0) + 2 * (PW if fold else d)
+                        assert rows.max() < P, (T, d, rows.max(), P)
+                    ok &= (pos >= 0) & (pos < T)
+                    np.add.at(hits, pos[ok], 1)
+            assert hits.min() == 1 and hits.max() == 1, (C, precision, T, d, d2, int(hits.min()), int(hits.max()))

@@ -61,6 +61,7 @@ SIGNATURES = {
                                       c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "vfx_op_resblock": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                 c_float, c_int, c_void_p, c_void_p]),
+    "vfx_plan_resblock_geometry": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vfx_op_resblock_pair": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "vfx_op_block2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

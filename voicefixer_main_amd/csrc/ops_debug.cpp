@@ -221,6 +221,33 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
   return 0;
 }
 
+// Host-only: the tile geometry plan_resblock() gives one fused ResStack layer (or layer pair, dil2 > 0) of `C` channels over
+// sequences of `T` positions in precision mode `precision` -- so that the CPU test suite can check that the tiles of every
+// kernel family (1-D, folded, pairs; 128- and 256-position tiles) write each output position exactly once.
+// out[12] = fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, tile_m, rw, rl, asrc.  Needs no GPU and no handle.
+extern "C" int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int precision, int* out) {
+  try {
+    VFX_CHECK(out && T > 0 && dil >= 1 && dil2 >= 0, "bad argument");
+    ResBlockParams rp{};
+    rp.B = 1;
+    rp.T = T;
+    rp.C = C;
+    rp.dil = dil;
+    rp.dil2 = dil2;
+    rp.hionly = precision == 2;
+    if (precision == 2 && resblock_act_supported(C)) {
+      rp.asrc = 1;
+      rp.tile_m = resblock_act_tile();
+    }
+    plan_resblock(rp);
+    const int v[12] = {rp.fold, rp.TH, rp.W1, rp.TWo, rp.tiles_h, rp.tiles_w, rp.PW, rp.P, rp.tile_m, rp.rw, rp.rl, rp.asrc};
+    for (int i = 0; i < 12; ++i) out[i] = v[i];
+  } catch (const vfx::Error&) {
+    return 1;
+  }
+  return 0;
+}
+
 // Two consecutive ResStack layers (dilations dil, dil2) of the 16-bit mode at C = 64 as ONE launch (resblock_rw.hip, PAIR): the
 // first layer's output never leaves the CU.  Weights / biases in PyTorch layout on the HOST: wa1, ba1, wa2, ba2 = first layer,
 // wb1 .. bb2 = second layer.  Fails (returns 1) where the plan would not pair the layers.
