@@ -547,7 +547,7 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
       d.seg[0].C = hp.C;
       d.seg[0].ntaps = 6;
       d.hionly = hp.hionly;
-      d.nstages = hp.rw ? hp.tile_m / 32 : (hp.C >= 128 ? 8 : 4);                       // waves per block
+      d.nstages = resblock_block_waves(hp);                                             // waves per block
       d.seg[0].ntaps = hp.dil2 > 0 ? 12 : 6;                                            // pairs: four convolutions
       c.prof->desc.push_back(d);
     } else {

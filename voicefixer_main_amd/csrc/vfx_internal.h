@@ -216,6 +216,7 @@ struct ResBlockParams {
   int hoff9[9];      // conv2: h row offset of tap (dy, dx)
 };
 bool resblock_supported(int C);
+int resblock_block_waves(const ResBlockParams& hp);
 bool resblock_act_supported(int C);
 int resblock_act_tile();
 void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
