@@ -263,3 +263,80 @@ def test_resblock_tiles_cover_every_position_once(C, precision):
                     ok &= (pos >= 0) & (pos < T)
                     np.add.at(hits, pos[ok], 1)
             assert hits.min() == 1 and hits.max() == 1, (C, precision, T, d, d2, int(hits.min()), int(hits.max()))
+
+
+def test_wave_fft_pass_structure():
+    """The index scheme of the wave-level 1024-point FFT of csrc/stft.hip (wfft1024: 64 lanes x 16 points, Stockham passes of
+    radix 16, 16, 4; the 16-point butterfly as n = 4a + b -> k = c + 4d; padded LDS positions i + (i >> 4)), restated in numpy
+    with the same per-lane reads, twiddles and writes: it must be the DFT, forward and inverse, and no two lanes of an access may
+    collide on a padded position."""
+    N = 1024
+    rng = np.random.default_rng(0)
+    tw = np.exp(-2j * np.pi * np.arange(N) / N)
+    zpad = lambda i: i + (i >> 4)
+
+    def fft4(v, sign):
+        v0, v1, v2, v3 = v
+        a0, a1, a2, d = v0 + v2, v0 - v2, v1 + v3, v1 - v3
+        a3 = d * (-1j) if sign < 0 else d * 1j
+        return [a0 + a2, a1 + a3, a0 - a2, a1 - a3]
+
+    def fft16(v, sign):
+        v = list(v)
+        for b in range(4):
+            o = fft4([v[b], v[4 + b], v[8 + b], v[12 + b]], sign)
+            for c in range(4):
+                v[4 * c + b] = o[c] * np.exp(sign * 2j * np.pi * b * c / 16)
+        out = [None] * 16
+        for c in range(4):
+            o = fft4(v[4 * c:4 * c + 4], sign)
+            for d in range(4):
+                out[c + 4 * d] = o[d]          # the kernel finds X[k] in register 4 (k & 3) + (k >> 2)
+        return out
+
+    def wfft(z, sign):
+        T = tw if sign < 0 else np.conj(tw)
+        lds = np.zeros(N + N // 16 + 1, complex)
+        regs = [[z[lane + 64 * r] for r in range(16)] for lane in range(64)]
+        used = set()
+        for lane in range(64):                  # pass 1: out[16 lane + r] at 17 lane + r
+            o = fft16(regs[lane], sign)
+            for r in range(16):
+                p = 17 * lane + r
+                assert p == zpad(16 * lane + r) and p not in used
+                used.add(p)
+                lds[p] = o[r]
+        nxt = np.zeros_like(lds)
+        for lane in range(64):                  # pass 2: in[lane + 64 r] at lane + (lane >> 4) + 68 r
+            k = lane & 15
+            v = []
+            for r in range(16):
+                p = lane + (lane >> 4) + 68 * r
+                assert p == zpad(lane + 64 * r)
+                v.append(lds[p] * T[(4 * k * r) % N])
+            o = fft16(v, sign)
+            for r in range(16):                 # out[16 (lane - k) + k + 16 r] at 17 (lane - k) + k + 17 r
+                p = 17 * (lane - k) + k + 17 * r
+                assert p == zpad(16 * (lane - k) + k + 16 * r)
+                nxt[p] = o[r]
+        out = np.zeros(N, complex)
+        for lane in range(64):                  # pass 3: four radix-4 butterflies per lane
+            for q in range(4):
+                j = lane + 64 * q
+                v = []
+                for r in range(4):
+                    p = lane + (lane >> 4) + 68 * q + 272 * r
+                    assert p == zpad(j + 256 * r)
+                    v.append(nxt[p] * T[(j * r) % N])
+                o = fft4(v, sign)
+                for r in range(4):
+                    out[j + 256 * r] = o[r]
+        return out
+
+    z = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    assert np.abs(wfft(z, -1) - np.fft.fft(z)).max() < 1e-10
+    assert np.abs(wfft(z, +1) - np.fft.ifft(z) * N).max() < 1e-10
+    # frames that run together in the inverse kernel (five rounds, stride D) never share a sample
+    hop, nfft = 441, 2048
+    D = (nfft + hop - 1) // hop
+    assert D * hop >= nfft and D == 5
