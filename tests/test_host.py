@@ -340,3 +340,20 @@ def test_wave_fft_pass_structure():
     hop, nfft = 441, 2048
     D = (nfft + hop - 1) // hop
     assert D * hop >= nfft and D == 5
+
+
+def test_profile_kernel_names():
+    """scripts/kname.py maps the demangled names rocprofv3 records to the names bench.py / libvfx print: the persistent, pair and
+    experiment kernels of the ResStack family must land on the `k_resblock<C, NW>` rows of the tables."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from kname import short
+    ns = "void vfx::"
+    assert short(ns + "k_resblock_rw<8, false>(vfx::ResBlockParams const*, int, int)") == "k_resblock<64, 8> f16"
+    assert short(ns + "k_resblock_rw<8, true>(vfx::ResBlockParams const*, int, int)") == "k_resblock_pair<64, 8> f16"
+    assert short(ns + "k_resblock_rw<4, false>(vfx::ResBlockParams const*, int, int)") == "k_resblock<64, 4> f16"
+    assert short(ns + "k_resblock_act<256, 8, 128>(vfx::ResBlockParams const*)") == "k_resblock<256, 8> f16"
+    assert short(ns + "k_resblock_pc<256>(vfx::ResBlockParams const*, int, int)") == "k_resblock<256, 8> f16"
+    assert short(ns + "k_resblock_rl<128>(vfx::ResBlockParams const*)") == "k_resblock<128, 8> f16"
+    assert short(ns + "k_resblock<32, 2, false, true>(vfx::ResBlockParams const*)") == "k_resblock<32, 2>"
+    assert short(ns + "k_resblock<128, 8, true, false>(vfx::ResBlockParams const*)") == "k_resblock<128, 8> f16"
+    assert short(ns + "k_stft_mel<false>(float const*, int)") == "k_stft_mel<false>"
