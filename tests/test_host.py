@@ -189,7 +189,11 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "voicefixer_main_amd", "csrc")
-    for name in ("conv.hip", "resblock.hip", "resblock_act.hip", "resblock_pc.hip", "resblock_rl.hip"):
+    import re
+    # kernels that are allowed a few bytes of scratch: opt-in experiments and the opt-in 64-position form of the C = 256 layer
+    # (and k_conv<64, ELU, split, ring 3>: 8 bytes since round 1, split-bf16 mode of the vocoder's ELU convolutions only)
+    may_spill = ("k_resblock_pc", "k_resblock_rl", "k_resblock_actILi256ELi8ELi64E", "k_convILi64ELb1ELb1ELi0ELi3ELb0ELb0E")
+    for name in ("conv.hip", "resblock.hip", "resblock_act.hip", "resblock_pc.hip", "resblock_rl.hip", "resblock_rw.hip", "stft.hip"):
         out = str(tmp_path / (name + ".s"))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                         "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, name)], check=True,
@@ -197,6 +201,13 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "asm_inflight_check.py"), out],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
+        # no register spills in the kernels of the default path: a scratch reload is a VMEM operation that queues behind
+        # prefetches (the persistent kernels) and costs memory round trips everywhere else
+        asm = open(out).read()
+        for m in re.finditer(r"\n(_ZN3vfx\w+):.*?; ScratchSize: (\d+)", asm, re.S):
+            kernel, scratch = m.group(1), int(m.group(2))
+            if not any(k in kernel for k in may_spill):
+                assert scratch == 0, (name, kernel, scratch)
 
 
 def test_committed_bench_line_follows_the_contract():
