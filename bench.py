@@ -26,7 +26,9 @@ ResUNet on split-bf16 operands (it carries the log-mel L1 <= 1e-3 bar), the voco
 product; 1 = split-bf16 everywhere (3 MFMAs per product), timed as well at N = 1 and reported beside `value` as
 `split_bf16_mode`; 0 = exact fp32 MFMA.
 
-Rank 0 prints ONE JSON line.  Measured in the same run: `parity` (HIP outputs of the benched batch vs the CPU oracle on
+Rank 0 prints ONE JSON line.  At N = 1 the default run also times configs[2] and configs[4] for a few steps in the same
+process and nests their value / ms_per_step / parity (vs the float64 oracle) / roofline under `aux_workloads`
+(--no-aux skips them).  Measured in the same run: `parity` (HIP outputs of the benched batch vs the CPU oracle on
 the clips the oracle was run on; the run FAILS when the log-mel L1 exceeds the 1e-3 bar), `roofline` (HIP events around
 every convolution launch on its own stream over K more steps; `traffic` from two rocprofv3 PMC passes of a child run of
 the same workload), `roofline_hbm` (the HBM-bound front-end / back-end kernels), `cpu_baseline` (the CPU oracle, a port
@@ -74,6 +76,9 @@ def parse():
                     help="live: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of a child run of the same workload")
     ap.add_argument("--dist-selfcheck", action="store_true", help="N > 1: round-trip a tensor through dist.scatter_clips / gather_clips first")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra all-split-bf16 (precision 1) timing at N = 1")
+    ap.add_argument("--no-aux", action="store_true", help="skip the nested ssr_sr64 / stream1s measurements of the default run")
+    ap.add_argument("--aux-steps", type=int, default=3)
+    ap.add_argument("--cpu-repeats", type=int, default=3, help="timed calls of the CPU oracle (the median is reported)")
     ap.add_argument("--precision", type=int, default=2, help="0 = exact fp32 MFMA, 1 = split-bf16 (hi+lo, 3 bf16 MFMAs), 2 = ResUNet split-bf16 + vocoder fp16 (1 MFMA per product)")
     args = ap.parse_args()
     d_clips, d_sec, d_cpu = {"gsr16x10": (16, 10.0, 2), "sharded1024": (128, 10.0, 0), "ssr_sr64": (64, 3.0, 1),
@@ -132,31 +137,53 @@ def parity_wav(out, ref_wav):
 # ---------------------------------------------------------------------------------------------------------
 # CPU baseline (the oracle timed on this box's host cores; its outputs double as the parity reference)
 # ---------------------------------------------------------------------------------------------------------
-def cpu_baseline(kind, clips, n_clips, threads):
-    """The oracle's torch-CPU convolutions stop scaling (and then collapse) beyond a few dozen threads at these sizes
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(kind, clips, n_clips, threads, repeats=3, dtype=None):
+    """the oracle (a port of the reference algorithm) on the box's host cores, after one warm-up
+    call, MEDIAN of `repeats` timed calls on a bounded sample of the benched clips; thread count and CPU model stated.
+    The oracle's torch-CPU convolutions stop scaling (and then collapse) beyond a few dozen threads at these sizes
     (2 x EPYC 9575F host: 1-s clip 0.23 / 0.18 / 0.25 / 0.66 s at 8 / 16 / 32 / 64 threads, minutes at 256), so the
-    baseline uses a fixed, stated thread count instead of every hardware thread."""
+    baseline uses a fixed, stated thread count instead of every hardware thread.  `dtype` = torch.float64: the ssr oracle
+    as the PARITY reference (two fp32 evaluations of that trunk agree to ~60 dB only); it is then timed once."""
     from oracle import pipeline
     from voicefixer_main_amd import synth
     wav = clips[:n_clips]
     threads = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(threads)
+    times = []
     if kind == "gsr":
         unet_sd, voc_sd = synth.make_resunet_state_dict(0), synth.make_vocoder_state_dict(1)
         pipeline.restore_gsr(unet_sd, voc_sd, wav[:1, :, :44100])          # warm-up (thread pool, allocator)
-        t0 = time.perf_counter()
-        ref = pipeline.restore_gsr(unet_sd, voc_sd, wav)
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            ref = pipeline.restore_gsr(unet_sd, voc_sd, wav)
+            times.append(time.perf_counter() - t0)
         name = "oracle.pipeline.restore_gsr"
     else:
         unet_sd = synth.make_resunet_state_dict(2)
         pipeline.restore_ssr(unet_sd, wav[:1, :, :22050])
-        t0 = time.perf_counter()
-        ref = pipeline.restore_ssr(unet_sd, wav)
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            ref = pipeline.restore_ssr(unet_sd, wav)
+            times.append(time.perf_counter() - t0)
         name = "oracle.pipeline.restore_ssr"
-    dt = time.perf_counter() - t0
+        if dtype is not None:    # the parity reference in float64 (not the timed baseline)
+            sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in unet_sd.items()}
+            ref = pipeline.restore_ssr(sd64, wav, dtype=dtype)
+    dt = float(np.median(times))
     seconds = wav.shape[0] * wav.shape[-1] / 44100.0
     return {"value": round(seconds / dt, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "seconds": round(dt, 2), "host_cpus": os.cpu_count(),
+            "seconds": round(dt, 2), "timed_calls": [round(t, 2) for t in times], "statistic": "median",
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
             "sample": "%s (torch-CPU fp32 + numpy port of the reference algorithm) on %d clip(s) x %.0f s of the same "
                       "synthetic clips as one batch, same seeded weights, after a warm-up call"
                       % (name, wav.shape[0], wav.shape[-1] / 44100.0)}, ref
@@ -165,8 +192,9 @@ def cpu_baseline(kind, clips, n_clips, threads):
 # ---------------------------------------------------------------------------------------------------------
 # roofline: MFMA-bound convolution kernels (HIP events inside libvfx), HBM-bound DSP kernels, PMC traffic
 # ---------------------------------------------------------------------------------------------------------
-def measure_conv_roofline(eng, step, args, traffic):
-    """HIP events around every convolution launch (on the launch stream) over K more steps of the same workload;
+def measure_conv_roofline(eng, step, args, traffic, ms_step=None, steps=None):
+    """`ms_step` = the timed region's ms per step (for the whole-step MFMA line).
+    HIP events around every convolution launch (on the launch stream) over K more steps of the same workload;
     per-kernel totals come from the per-launch table libvfx writes (VFX_PROFILE_DUMP: duration, algorithmic flops and
     algorithmic HBM bytes of every launch).  The roofline object describes the kernel with the largest share of GPU time
     against the roofline that bounds it (its algorithmic intensity vs the ridge of the chip); both lines are reported."""
@@ -174,7 +202,7 @@ def measure_conv_roofline(eng, step, args, traffic):
     keep = os.environ.get("VFX_PROFILE_DUMP")   # a caller-provided path keeps the per-launch table
     dump = keep or tempfile.NamedTemporaryFile(prefix="vfx_convs_", suffix=".csv", delete=False).name
     os.environ["VFX_PROFILE_DUMP"] = dump
-    steps = max(args.steps, 1)
+    steps = max(steps or args.steps, 1)
     eng.profile_begin()
     for _ in range(steps):
         step()
@@ -186,13 +214,14 @@ def measure_conv_roofline(eng, step, args, traffic):
     per = {}
     for r in rows:
         k = r["kernel"].replace(";", ",")
-        t = per.setdefault(k, [0, 0.0, 0.0, 0.0])
+        t = per.setdefault(k, [0, 0.0, 0.0, 0.0, 0.0])
         t[0] += 1
         t[1] += float(r["ms"])
         t[2] += float(r["tflops"]) * float(r["ms"]) * 1e9   # flops of the launch
-        t[3] += float(r.get("bytes", 0) or 0)               # algorithmic HBM bytes of the launch
+        t[3] += float(r.get("bytes", 0) or 0)               # algorithmic HBM bytes of the launch (SURVEY.md section 8d)
+        t[4] += float(r.get("design_bytes", 0) or 0)        # bytes the kernel's own data layout moves
     dom = max(per, key=lambda k: per[k][1])
-    cnt, kms, kfl, kby = per[dom]
+    cnt, kms, kfl, kby, kdb = per[dom]
     tflops = kfl / (kms * 1e-3) / 1e12
     gbs = kby / (kms * 1e-3) / 1e9
     split = args.precision >= 1
@@ -210,10 +239,15 @@ def measure_conv_roofline(eng, step, args, traffic):
                  # product, so `frac` is bounded by 1/3 and mfma_issue_frac is the share of the MFMA pipe actually used
                  "mfma_issue_frac": round(tflops * per_product / peak, 4)}
     hbm_line = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                "algorithmic_bytes_per_launch": round(kby / max(cnt, 1))}
+                # a ResStack layer = x in + y out = 8 bytes per element; a convolution = its sources,
+                # residual and outputs once.  design_bytes = what the kernel's data layout moves on top (the fp16 copies of a
+                # two-form trunk: 12 bytes per element at C = 256).
+                "algorithmic_bytes_per_launch": round(kby / max(cnt, 1)), "design_bytes_per_launch": round(kdb / max(cnt, 1))}
     head = dict(hbm_line if hbm_bound else mfma_line)
     return dict({
         "bound": "hbm" if hbm_bound else "mfma",
+        "accounting": "SURVEY.md section 8(d): algorithmic flops = 2 x MAC once; algorithmic bytes = tensors in + out once "
+                      "(ResStack layer: 8 B per element); the bound follows from that intensity vs the chip's ridge",
         "kernel": "%s (%s)" % (dom, "1 x v_mfma_f32_32x32x16_f16 per product (fp16 operands), fp32 accumulate" if plain
                                else "3 x v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
                                if split else "v_mfma_f32_32x32x2_f32"),
@@ -232,11 +266,23 @@ def measure_conv_roofline(eng, step, args, traffic):
         "all_conv_kernels": {k: {"launches_per_step": v[0] // steps, "ms_per_step": round(v[1] / steps, 3),
                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
                                  "algorithmic_gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                                 "frac_mfma": round(v[2] / (v[1] * 1e-3) / 1e12 / peak, 4),
+                                 "frac_hbm": round(v[3] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                  "hbm_bytes_per_launch": ((traffic or {}).get("kernels", {}).get(k) or {}).get("bytes_per_launch")}
                              for k, v in sorted(per.items())},
         "all_conv_ms_per_step": round(ms / steps, 3),
         "all_conv_algorithmic_gflop_per_step": round(fl / steps / 1e9, 1),
-    })
+    }), step_line(fl / steps, ms_step, peak)
+
+
+def step_line(flop_per_step, ms_step, peak):
+    """The whole step against the dense 16-bit MFMA peak: algorithmic flops of every GEMM-shaped launch / the timed
+    region's time per step."""
+    if not ms_step:
+        return None
+    tf = flop_per_step / (ms_step * 1e-3) / 1e12
+    return {"gflop": round(flop_per_step / 1e9, 1), "ms": round(ms_step, 3), "tflops": round(tf, 1), "peak": peak,
+            "frac_of_mfma_peak": round(tf / peak, 4)}
 
 
 def measure_hbm_stages(eng, B, L, reps=20):
@@ -308,7 +354,7 @@ def live_traffic(args):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VFX_PROFILE_DUMP"):
         env.pop(k, None)
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-roofline", "--no-alt",
-             "--cpu-baseline-clips", "0", "--traffic", "off", "--no-parity", "--workload", args.workload,
+             "--cpu-baseline-clips", "0", "--traffic", "off", "--no-parity", "--no-aux", "--workload", args.workload,
              "--precision", str(args.precision), "--clips", str(args.clips), "--seconds", str(args.seconds)]
     try:
         dbs = {}
@@ -348,6 +394,174 @@ def live_traffic(args):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------
+class Workload:
+    """One BASELINE.json config on one rank: `step()` enqueues one pass of the hot path over its batch of clips, which are
+    resident in HBM before the clock starts."""
+
+    def __init__(self, wl, args, device, rank, world, precision, clips_n=None, seconds=None, weights=None):
+        from voicefixer_main_amd import dist as vdist
+        from voicefixer_main_amd import synth
+        from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER
+        d_clips, d_sec = {"gsr16x10": (16, 10.0), "sharded1024": (128, 10.0), "ssr_sr64": (64, 3.0), "stream1s": (1, 1.0)}[wl]
+        self.wl, self.device, self.rank, self.world, self.precision = wl, device, rank, world, precision
+        self.B = B = clips_n or d_clips
+        self.seconds = seconds = seconds or d_sec
+        self.gsr = wl in ("gsr16x10", "sharded1024")
+        self.extra = {}
+        self.phases = None
+        self.eager = None
+        self.weights = weights or {}
+
+        def state_dict(seed, kind):
+            # N ranks: rank 0 builds (or, in production, reads the checkpoint) once, everybody else receives ONE flat
+            # broadcast (SURVEY.md section 8e) -- dist.broadcast_state_dict; a world of one builds locally.
+            key = (seed, kind)
+            if key not in self.weights:
+                sd = None
+                if rank == 0:
+                    sd = synth.make_resunet_state_dict(seed) if kind == "unet" else synth.make_vocoder_state_dict(seed)
+                self.weights[key] = vdist.broadcast_state_dict(sd, device)
+            return self.weights[key]
+
+        def make_engine(precision):
+            e = Engine(device, config={"precision": precision})
+            if self.gsr:
+                e.load_state_dict(MODEL_UNET_MEL, state_dict(0, "unet"))
+                e.load_state_dict(MODEL_VOCODER, state_dict(1, "voc"))
+            else:
+                e.load_state_dict(MODEL_UNET_SPEC, state_dict(2, "unet"))
+            return e
+        self.make_engine = make_engine
+        self.eng = eng = make_engine(precision)
+
+        if wl == "gsr16x10":
+            self.clips = synth.make_clips(B, seconds, seed=1234 + 1000 * rank)               # (B, 1, L) float32, host
+            self.wav = wav = torch.from_numpy(self.clips[:, 0]).to(device)                   # resident in HBM
+            self.out = out = torch.empty_like(wav)
+            self.L = wav.shape[1]
+            self.step = lambda e=eng: e.restore_gsr(wav, out=out)
+            self.audio_per_step = world * B * seconds
+        elif wl == "sharded1024":
+            self.n_total = n_total = B * world
+            self.L = L = int(round(seconds * 44100))
+            if rank == 0:
+                self.clips = synth.make_clips(n_total, seconds, seed=1234)
+                self.full = full = torch.from_numpy(self.clips[:, 0]).to(device)             # all clips live on rank 0
+            else:
+                self.clips, self.full = None, None
+                full = None
+            self.phases = phases = {"scatter_ms": 0.0, "restore_ms": 0.0, "gather_ms": 0.0}
+            self.gathered = gathered = [None]
+            sync = lambda: torch.cuda.synchronize(device)
+
+            def step(e=eng, acc=phases):
+                back, t = vdist.sharded_step(lambda x: e.restore_gsr(x), full, n_total, L, device, sync=sync)
+                gathered[0] = back
+                for k in acc:
+                    acc[k] += t[k]
+            self.step = step
+            self.audio_per_step = n_total * seconds
+        elif wl == "ssr_sr64":
+            # 1-kHz cheby1 low-pass: 2 kHz -> 44.1 kHz super-resolution input
+            self.clips = synth.make_clips(B, seconds, seed=7 + 1000 * rank, mode="lowpass")
+            self.wav = wav = torch.from_numpy(self.clips[:, 0]).to(device)
+            self.L = wav.shape[1]
+            self.holder = holder = [None]
+
+            def step(e=eng):
+                sp = e.stft(wav, want_mel=False, want_sp=True)["sp"]        # eval_ssr_unet.py:80
+                holder[0] = e.resunet_spec(sp, wav)                         # STFT (phase) + trunk + ISTFT, unet_v2.py:86-148
+            self.step = step
+            self.audio_per_step = world * B * seconds
+        else:  # stream1s
+            self.clips = synth.make_clips(1, seconds, seed=11 + 1000 * rank)
+            self.wav = wav = torch.from_numpy(self.clips[:, 0]).to(device)
+            self.L = wav.shape[1]
+            self.holder = holder = [None]
+
+            def eager(e=eng):
+                sp = e.stft(wav, want_mel=False, want_sp=True)["sp"]
+                holder[0] = e.resunet_spec(sp, wav)
+            eager()                                                         # plans, arena (no allocation inside the capture)
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            self.graph = graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                eager()
+                torch.cuda.synchronize(device)
+                with torch.cuda.graph(graph, stream=side):
+                    eager()
+            torch.cuda.current_stream(device).wait_stream(side)
+            self.step = graph.replay
+            self.eager = eager
+            self.audio_per_step = world * seconds
+            self.extra["hipgraph"] = True
+
+    def timed(self, steps, warmup, barrier=lambda: None):
+        """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides -> seconds."""
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize(self.device)
+        if self.phases:
+            for k in self.phases:
+                self.phases[k] = 0.0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize(self.device)
+        barrier()
+        return time.perf_counter() - t0
+
+    def flags(self):
+        """The handle's sticky flags after the timed region: a 16-bit vocoder whose activations left the fp16 range, or a
+        negative mel, makes the measurement INVALID (bench.py times the raw entry point, not the re-running wrapper)."""
+        from voicefixer_main_amd import _lib
+        f = self.eng.take_flags()
+        return {"negative_input": bool(f & _lib.FLAG_NEGATIVE_INPUT), "f16_saturated": bool(f & _lib.FLAG_F16_SATURATED)}
+
+
+def dtype_string(gsr, precision):
+    return {0: "f32", 1: "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)",
+            2: "f16 (vocoder: fp16 operands, 1 MFMA per product; ResUNet: split-bf16 hi+lo; fp32 accumulate)"
+            if gsr else "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)"}[precision]
+
+
+def aux_workload(name, args, device, weights):
+    """configs[2] / configs[4] for a few steps in the process of the default run: value, ms_per_step, parity of the benched
+    batch against the FLOAT64 oracle (ssr: 2 clips, stream: the chunk), the convolution roofline (HIP events, no PMC pass)."""
+    try:
+        w = Workload(name, args, device, 0, 1, args.precision, weights=weights)
+        steps = max(1, args.aux_steps if name == "ssr_sr64" else 10 * args.aux_steps)
+        dt = w.timed(steps, 1 if name == "ssr_sr64" else 3)
+        res = {"config": {"workload": name, "clips_per_gpu": w.B, "clip_seconds": w.seconds},
+               "value": round(w.audio_per_step * steps / dt, 2), "unit": "audio-s/s", "steps": steps,
+               "ms_per_step": round(dt / steps * 1e3, 3), "dtype": dtype_string(False, args.precision),
+               "outputs_finite": bool(torch.isfinite(w.holder[0]).all().item())}
+        res.update(w.extra)
+        res.update(w.flags())
+        got = w.holder[0].clone()
+        if not args.no_roofline:
+            rstep = w.step if name != "stream1s" else w.eager     # HIP events cannot be recorded inside a graph replay
+            roof, whole = measure_conv_roofline(w.eng, rstep, args, None, ms_step=dt / steps * 1e3, steps=2)
+            roof.pop("traffic_detail", None)
+            res["roofline"], res["step"] = roof, whole
+        if not args.no_parity:
+            n = 2 if name == "ssr_sr64" else 1
+            base, ref = cpu_baseline("ssr", w.clips, n, args.cpu_threads, repeats=1, dtype=torch.float64)
+            res["cpu_baseline"] = base
+            res["parity"] = parity_wav(got[:n], ref["wav"][:, 0])
+            res["parity"]["vs"] = "oracle.pipeline.restore_ssr in FLOAT64 (CPU port of unet_v2.py:86-148)"
+        del w
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:  # an auxiliary line never takes the headline down with it
+        return {"config": {"workload": name}, "error": repr(e)[:400]}
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     maybe_spawn(args)
@@ -363,24 +577,11 @@ def main():
     torch.cuda.set_device(device)
 
     from voicefixer_main_amd import dist as vdist
-    from voicefixer_main_amd import synth
-    from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER
 
     wl = args.workload
-    gsr = wl in ("gsr16x10", "sharded1024")
-
-    def make_engine(precision):
-        e = Engine(device, config={"precision": precision})
-        if gsr:
-            e.load_state_dict(MODEL_UNET_MEL, synth.make_resunet_state_dict(0))
-            e.load_state_dict(MODEL_VOCODER, synth.make_vocoder_state_dict(1))
-        else:
-            e.load_state_dict(MODEL_UNET_SPEC, synth.make_resunet_state_dict(2))
-        return e
-
-    eng = make_engine(args.precision)
-    B = args.clips
-    extra = {}
+    weights = {}
+    w = Workload(wl, args, device, rank, world, args.precision, clips_n=args.clips, seconds=args.seconds, weights=weights)
+    eng, gsr, B, L = w.eng, w.gsr, w.B, w.L
 
     def barrier():
         if world > 1:
@@ -390,102 +591,35 @@ def main():
         vdist.selfcheck(device)
     rccl_ranks = vdist.live_ranks(device)
 
-    # ---- the step of each workload ------------------------------------------------------------------
-    if wl == "gsr16x10":
-        clips = synth.make_clips(B, args.seconds, seed=1234 + 1000 * rank)               # (B, 1, L) float32, host
-        wav = torch.from_numpy(clips[:, 0]).to(device)                                   # resident in HBM
-        out = torch.empty_like(wav)
-        L = wav.shape[1]
-        step = lambda e=eng: e.restore_gsr(wav, out=out)
-        audio_per_step = world * B * args.seconds
-    elif wl == "sharded1024":
-        n_total = B * world
-        L = int(round(args.seconds * 44100))
-        if rank == 0:
-            clips = synth.make_clips(n_total, args.seconds, seed=1234)
-            full = torch.from_numpy(clips[:, 0]).to(device)                              # all clips live on rank 0
-        else:
-            clips, full = None, None
-        phases = {"scatter_ms": 0.0, "restore_ms": 0.0, "gather_ms": 0.0}
-        gathered = [None]
-        sync = lambda: torch.cuda.synchronize(device)
-
-        def step(e=eng, acc=phases):
-            back, t = vdist.sharded_step(lambda x: e.restore_gsr(x), full, n_total, L, device, sync=sync)
-            gathered[0] = back
-            for k in acc:
-                acc[k] += t[k]
-        audio_per_step = n_total * args.seconds
-    elif wl == "ssr_sr64":
-        clips = synth.make_clips(B, args.seconds, seed=7 + 1000 * rank, mode="lowpass")   # 1-kHz cheby1 low-pass: 2 kHz -> 44.1 kHz SR
-        wav = torch.from_numpy(clips[:, 0]).to(device)
-        L = wav.shape[1]
-        holder = [None]
-
-        def step(e=eng):
-            sp = e.stft(wav, want_mel=False, want_sp=True)["sp"]        # eval_ssr_unet.py:80
-            holder[0] = e.resunet_spec(sp, wav)                         # STFT (phase) + trunk + ISTFT, unet_v2.py:86-148
-        audio_per_step = world * B * args.seconds
-    else:  # stream1s
-        clips = synth.make_clips(1, args.seconds, seed=11 + 1000 * rank)
-        wav = torch.from_numpy(clips[:, 0]).to(device)
-        L = wav.shape[1]
-        holder = [None]
-
-        def eager(e=eng):
-            sp = e.stft(wav, want_mel=False, want_sp=True)["sp"]
-            holder[0] = e.resunet_spec(sp, wav)
-        eager()                                                         # plans, arena (no allocation inside the capture)
-        side = torch.cuda.Stream(device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            eager()
-            torch.cuda.synchronize(device)
-            with torch.cuda.graph(graph, stream=side):
-                eager()
-        torch.cuda.current_stream(device).wait_stream(side)
-        step = graph.replay
-        audio_per_step = world * args.seconds
-        extra["hipgraph"] = True
-
     # ---- timed region ---------------------------------------------------------------------------------
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(device)
-    if wl == "sharded1024":
-        for k in phases:
-            phases[k] = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(device)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = w.timed(args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    flags = eng.take_flags()
+    flags = w.flags()
 
     res = None
     failed = None
     if rank == 0:
         res = {
             "metric": "restored-audio sec/s (RTF^-1), VoiceFixer 44.1 kHz",
-            "value": round(audio_per_step * args.steps / dt, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "value": round(w.audio_per_step * args.steps / dt, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {0: "f32", 1: "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)",
-                      2: "f16 (vocoder: fp16 operands, 1 MFMA per product; ResUNet: split-bf16 hi+lo; fp32 accumulate)"
-                      if gsr else "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)"}[args.precision],
+            "dtype": dtype_string(gsr, args.precision),
             "data": "synthetic",
-            "config": {"workload": wl, "precision_mode": args.precision, "clips_per_gpu": B, "clip_seconds": args.seconds,
-                       "parallelism": "dp%d" % world, "weights": "seeded random (no checkpoint available offline)"},
-            "rccl_ranks": rccl_ranks, "negative_input_flag": flags,
+            "config": {"workload": wl, "precision_mode": args.precision, "clips_per_gpu": B, "clip_seconds": w.seconds,
+                       "parallelism": "dp%d" % world, "weights": "seeded random (no checkpoint available offline)"
+                       + ("; built on rank 0, one flat broadcast to the other ranks" if world > 1 else "")},
+            "rccl_ranks": rccl_ranks, "negative_input_flag": int(flags["negative_input"]), "f16_saturated": flags["f16_saturated"],
         }
-        res.update(extra)
+        res.update(w.extra)
+        if flags["f16_saturated"]:
+            failed = ("the 16-bit vocoder clamped an activation (VFX_FLAG_F16_SATURATED): this measurement is invalid; "
+                      "run with --precision 1")
+        if flags["negative_input"]:
+            failed = "a negative mel reached to_log (VFX_FLAG_NEGATIVE_INPUT)"
         if gsr and args.precision == 2:
             res["caveat"] = ("precision 2 runs the vocoder on fp16 operands; its waveform parity is established on seeded "
                              "synthetic vocoder weights (the pretrained TFGAN checkpoint is not obtainable offline) -- "
@@ -493,33 +627,39 @@ def main():
 
     # ---- outputs of the benched batch (for parity), oracle sample --------------------------------------
     if rank == 0 and wl == "gsr16x10":
-        out_p, logmel_p = eng.restore_gsr(wav, want_logmel=True)
+        out_p, logmel_p = eng.restore_gsr(w.wav, want_logmel=True)
         res["outputs_finite"] = bool(torch.isfinite(out_p).all().item())
     elif rank == 0 and wl == "sharded1024":
-        res["outputs_finite"] = bool(torch.isfinite(gathered[0]).all().item()) and tuple(gathered[0].shape) == (n_total, L)
-        for k in phases:
-            res[k] = round(phases[k] / args.steps, 3)
-        res["clips_total"] = n_total
+        gathered = w.gathered
+        res["outputs_finite"] = bool(torch.isfinite(gathered[0]).all().item()) and tuple(gathered[0].shape) == (w.n_total, L)
+        for k in w.phases:
+            res[k] = round(w.phases[k] / args.steps, 3)
+        res["clips_total"] = w.n_total
         res["sub_batches_per_rank"] = -(-B // 37)        # 32-bit tensor addressing: <= 37 clips of 10 s per launch
         # the gathered result is the restore of the scattered clips: check two clips against a direct call
-        chk = eng.restore_gsr(full[:2])
+        chk = eng.restore_gsr(w.full[:2])
         res["gather_matches_direct_restore"] = bool(torch.equal(chk, gathered[0][:2]))
     elif rank == 0:
-        res["outputs_finite"] = bool(torch.isfinite(holder[0]).all().item())
+        res["outputs_finite"] = bool(torch.isfinite(w.holder[0]).all().item())
 
     if rank == 0 and world == 1:
         traffic = None
         if not args.no_roofline:
             if args.traffic == "live" and gsr:
                 traffic = live_traffic(args)
-            rstep = step if wl != "stream1s" else eager      # HIP events cannot be recorded inside a graph replay
+            rstep = w.step if wl != "stream1s" else w.eager      # HIP events cannot be recorded inside a graph replay
             if wl == "sharded1024":
-                rstep = lambda: eng.restore_gsr(full[:37])   # one full sub-batch of the shard
-            res["roofline"] = measure_conv_roofline(eng, rstep, args, traffic)
+                rstep = lambda: eng.restore_gsr(w.full[:37])     # one full sub-batch of the shard
+            res["roofline"], whole = measure_conv_roofline(eng, rstep, args, traffic,
+                                                           ms_step=None if wl == "sharded1024" else dt / args.steps * 1e3)
+            if whole:
+                res["step"] = whole
             res["roofline_hbm"] = measure_hbm_stages(eng, min(B, 64), L)
         if args.cpu_baseline_clips > 0:
+            ssr64 = (not gsr) and not args.no_parity     # the ssr parity reference is the float64 oracle
             try:
-                res["cpu_baseline"], ref = cpu_baseline("gsr" if gsr else "ssr", clips, args.cpu_baseline_clips, args.cpu_threads)
+                res["cpu_baseline"], ref = cpu_baseline("gsr" if gsr else "ssr", w.clips, args.cpu_baseline_clips, args.cpu_threads,
+                                                        repeats=args.cpu_repeats, dtype=torch.float64 if ssr64 else None)
             except Exception as e:
                 res["cpu_baseline"], ref = {"error": repr(e)}, None
             if ref is not None and not args.no_parity:
@@ -529,12 +669,14 @@ def main():
                     if res["parity"]["logmel_l1"] > LOGMEL_L1_BAR:
                         failed = "log-mel L1 %.3g exceeds the %.0e bar" % (res["parity"]["logmel_l1"], LOGMEL_L1_BAR)
                 elif wl in ("ssr_sr64", "stream1s"):
-                    res["parity"] = parity_wav(holder[0][:n], ref["wav"][:, 0])
+                    res["parity"] = parity_wav(w.holder[0][:n], ref["wav"][:, 0])
+                    res["parity"]["vs"] = "oracle.pipeline.restore_ssr in FLOAT64 (CPU port of unet_v2.py:86-148)"
         if gsr and wl == "gsr16x10" and args.precision == 2 and not args.no_alt:
             # Same workload with every GEMM-shaped layer on split-bf16 operands (precision 1: 3 MFMAs per product in the
             # vocoder as well): the stricter arithmetic, reported beside `value`, with its own parity.
             try:
-                alt = make_engine(1)
+                alt = w.make_engine(1)
+                wav, out = w.wav, w.out
                 for _ in range(max(args.warmup, 1)):
                     alt.restore_gsr(wav, out=out)
                 torch.cuda.synchronize(device)
@@ -544,7 +686,7 @@ def main():
                 torch.cuda.synchronize(device)
                 dta = time.perf_counter() - t1
                 res["split_bf16_mode"] = {
-                    "value": round(B * args.seconds * args.steps / dta, 2), "unit": "audio-s/s",
+                    "value": round(B * w.seconds * args.steps / dta, 2), "unit": "audio-s/s",
                     "ms_per_step": round(dta / args.steps * 1e3, 3), "outputs_finite": bool(torch.isfinite(out).all().item()),
                     "dtype": "bf16x3 everywhere (split-bf16 operands hi+lo, 3 MFMAs per product, fp32 accumulate)"}
                 if "parity" in res:
@@ -554,6 +696,11 @@ def main():
                 del alt
             except Exception as e:
                 res["split_bf16_mode"] = {"error": repr(e)}
+        if wl == "gsr16x10" and not args.no_aux:
+            # BASELINE.json configs[2] and configs[4], driver-visible: a few steps each in this process
+            del w, eng
+            torch.cuda.empty_cache()
+            res["aux_workloads"] = {name: aux_workload(name, args, device, weights) for name in ("ssr_sr64", "stream1s")}
     if rank == 0:
         if failed:
             res["parity_failed"] = failed
@@ -562,7 +709,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if failed:
-        sys.exit("bench.py: parity check failed: " + failed)
+        sys.exit("bench.py: check failed: " + failed)
 
 
 if __name__ == "__main__":

@@ -38,8 +38,11 @@ enum { VFX_MODEL_UNET_MEL = 0, VFX_MODEL_UNET_SPEC = 1, VFX_MODEL_VOCODER = 2,
 /* sticky device-side flags returned by vfx_take_flags */
 enum {
   VFX_FLAG_NEGATIVE_INPUT = 1, /* to_log saw a negative value (pytorch_util.py:158) */
-  VFX_FLAG_F16_SATURATED = 2   /* precision 2: an activation of the vocoder left the fp16 range (|x| > 65504) and was
-                                  clamped -- the result of that call is not trustworthy; re-run it with precision 1 */
+  VFX_FLAG_F16_SATURATED = 2,  /* precision 2: an activation of the vocoder left the fp16 range (|x| > 65504, or was
+                                  not a number) and was clamped -- the result of that call is not trustworthy; re-run
+                                  it with precision 1 */
+  VFX_FLAG_PEAK_NORMALISED = 4 /* vfx_restore_gsr divided a clip by its peak (> 1): the reference prints "Warning:
+                                  Exceed energy limit" there (eval_gsr_voicefixer.py:68-70); informational */
 };
 
 typedef struct vfx_config {

@@ -26,6 +26,18 @@ def _threads():
     torch.set_num_threads(min(32, torch.get_num_threads()))
 
 
+def _report(key, value):
+    """Measured figures of this run -> gpurun_out/parity_shapes.json (the bars below are set 5 dB under what is measured)."""
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = "gpurun_out/parity_shapes.json"
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d[key] = value
+    with open(path, "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
 @functools.lru_cache(maxsize=None)
 def _gsr_oracle(n_clips, seconds, seed):
     from oracle import pipeline
@@ -87,10 +99,15 @@ def test_reference_segment_1x60s(engine):
     _check_gsr(engine, wav, ref, stages=False)
 
 
+# SI-SDR of the spectrogram path against the FLOAT64 oracle, per arithmetic mode: measured on MI355X (round 3,
+# gpurun_out/parity_shapes.json -> profiles/r03_parity_shapes.json), the bars sit 5 dB under the measurement.
+SSR_SISDR_BAR = {"fp32": 55.0, "split-bf16": 45.0, "fp16-vocoder": 45.0}
+
+
 @pytest.mark.parametrize("n_samples", [132300, 132300 + 200])
 def test_ssr_unet_3s_shape(engine, n_samples):
     """configs[2] shape: T = 301, Tpad = 320, F = 1024; the second length is not a multiple of the hop, so the ISTFT
-    tail (tools/dsp/base.py:196-200) is part of the comparison."""
+    tail (tools/dsp/base.py:196-200) is part of the comparison -- relative to the TAIL's own peak."""
     from voicefixer_main_amd import synth
     from voicefixer_main_amd.engine import MODEL_UNET_SPEC
     wav, ref = _ssr_oracle(2, n_samples, 5)
@@ -101,8 +118,71 @@ def test_ssr_unet_3s_shape(engine, n_samples):
     got = engine.resunet_spec(sp, x).cpu().numpy()
     assert got.shape == (2, n_samples)
     s = _sisdr(got, ref["wav"][:, 0])
-    assert s > (55.0 if engine.tol["name"] == "fp32" else 45.0), s
+    _report("ssr_3s_sisdr_db[%s,%d]" % (engine.tol["name"], n_samples), s)
+    assert s > SSR_SISDR_BAR[engine.tol["name"]], s
     tail = n_samples % 441
     if tail:
         rt = ref["wav"][:, 0, -tail:]
-        assert np.abs(rt).max() > 0 and np.abs(got[:, -tail:] - rt).max() < 2e-2 * max(1e-3, np.abs(ref["wav"]).max())
+        rel = float(np.abs(got[:, -tail:] - rt).max() / np.abs(rt).max())
+        _report("ssr_3s_tail_rel_err[%s]" % engine.tol["name"], rel)
+        assert np.abs(rt).max() > 0 and rel < (1e-3 if engine.tol["name"] == "fp32" else 1e-2), rel
+
+
+@functools.lru_cache(maxsize=None)
+def _ssr_file_oracle(seconds, seed):
+    """A PCM16 file's samples and the float64 oracle's restoration of its 60-s segments (eval_ssr_unet.py:104-140)."""
+    from oracle import pipeline
+    from voicefixer_main_amd import synth
+    _threads()
+    x = synth.make_clips(1, seconds, seed=seed, mode="lowpass")[0, 0]
+    x = (np.asarray(x, np.float64) * 2 ** 15).astype(np.short).astype(np.float32) / 32768.0      # what save_wave / load_wav leave
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in synth.make_resunet_state_dict(2).items()}
+    segs, seg = [], 44100 * 60
+    for lo in range(0, x.shape[0], seg):
+        o = pipeline.restore_ssr(sd, x[None, None, lo:lo + seg], dtype=torch.float64)["wav"][0, 0]
+        peak = np.abs(o).max()
+        segs.append(o / peak if peak > 1.0 else o)
+    return x, segs
+
+
+def test_handler_ssr_unet_two_segments(engine, tmp_path):
+    """`handlers.handler_ssr_unet` (eval_ssr_unet.py:95-143) end to end on a 61-s file: two segments, the first the largest
+    tensor the product path can be asked for (B = 1, T = 6001 frames x 1024 bins, Tpad = 6016: 788 MB per activation),
+    against oracle.pipeline.restore_ssr in FLOAT64, incl. the four metric keys (computed like the reference does, from the
+    LAST segment: the dict is overwritten per segment, eval_ssr_unet.py:118-135)."""
+    if engine.tol["name"] != "split-bf16":
+        pytest.skip("one arithmetic mode: the ResUNet of the 16-bit vocoder mode is this one, the fp32 mode shares the code path")
+    from voicefixer_main_amd import handlers, synth
+    from voicefixer_main_amd.models import SSR_UNet
+    x, segs = _ssr_file_oracle(61.0, 9)
+    assert [len(o) for o in segs] == [44100 * 60, 44100]
+    m = SSR_UNet(None, channels=1, engine=engine)
+    m.load_state_dict({"generator.unet." + k: v for k, v in synth.make_resunet_state_dict(2).items()})
+    handlers._state["model"] = m.eval()
+    src, dst = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    handlers.save_wave(x, src)
+    assert np.array_equal(handlers.load_wav(src), x)
+    metrics = handlers.handler_ssr_unet(src, dst, src, ckpt=None, device=torch.device("cuda:0"), needrefresh=False, meta={})
+    assert set(metrics) == {"mel-lsd", "mel-sispec", "mel-non-log-sispec", "mel-ssim"}           # eval_ssr_unet.py:131-135
+    out = handlers.load_wav(dst)
+    ref = np.concatenate(segs)
+    assert out.shape == ref.shape == x.shape
+    s60, s1 = _sisdr(out[:44100 * 60], segs[0]), _sisdr(out[44100 * 60:], segs[1])
+    _report("ssr_handler_sisdr_db_60s_segment", s60)
+    _report("ssr_handler_sisdr_db_1s_segment", s1)
+    # PCM16 output: quantisation noise alone is ~ -101 dB re full scale
+    assert s60 > SSR_SISDR_BAR["split-bf16"] - 5.0 and s1 > SSR_SISDR_BAR["split-bf16"] - 5.0, (s60, s1)
+    # the metrics of the last segment, from the oracle's waveform with the formulas of evaluation_proc (torch, CPU)
+    from oracle import dsp
+    lo = 44100 * 60
+    _, mel_o = dsp.wav_to_mel(segs[1][None, None].astype(np.float64))
+    _, mel_t = dsp.wav_to_mel(x[None, None, lo:].astype(np.float64))
+    mo, mt = torch.from_numpy(mel_o), torch.from_numpy(mel_t)
+    want = {"mel-lsd": float(handlers.lsd(mo, mt).mean()), "mel-non-log-sispec": float(handlers.sispec(mo, mt)),
+            "mel-sispec": float(handlers.sispec(torch.log10(mo.clip(min=1e-8)), torch.log10(mt.clip(min=1e-8)))),
+            "mel-ssim": float(handlers.ssim(mo, mt))}
+    _report("ssr_handler_metrics", {"got": metrics, "oracle": want})
+    assert abs(metrics["mel-lsd"] - want["mel-lsd"]) < 2e-2 * max(1.0, abs(want["mel-lsd"])), (metrics, want)
+    assert abs(metrics["mel-sispec"] - want["mel-sispec"]) < 0.5 and abs(metrics["mel-non-log-sispec"] - want["mel-non-log-sispec"]) < 0.5, (metrics, want)
+    assert abs(metrics["mel-ssim"] - want["mel-ssim"]) < 2e-2, (metrics, want)
+    assert engine.take_flags() == 0

@@ -109,6 +109,51 @@ def test_handler_end_to_end(voicefixer, unet_sd, voc_sd, tmp_path):
     assert np.abs(out - ref).max() < 1e-3 + 2.0 / 32768
 
 
+def _handler_in_reference_order(model, src, dst):
+    """eval_gsr_voicefixer.py:37-77 exactly as written -- whole-file load, per-segment calls with their host syncs
+    (to_log's assert inside model(), `if torch.max(torch.abs(out)) > 1.0`), torch.cat, save_wave of the whole file."""
+    from voicefixer_main_amd import handlers
+    from voicefixer_main_amd.models import from_log, tensor2numpy
+    dev = torch.device("cuda:0")
+    wav_10k = handlers.load_wav(src, sample_rate=44100)
+    res = []
+    seg_length = 44100 * handlers.SEG_SECONDS
+    break_point = seg_length
+    while break_point < wav_10k.shape[0] + seg_length:
+        segment = wav_10k[break_point - seg_length:break_point]
+        _, mel_noisy, seg_t = handlers._pre(model, segment, dev)
+        out_model = model(mel_noisy)
+        denoised_mel = from_log(out_model["mel"])
+        out = model.vocoder(denoised_mel)
+        if torch.max(torch.abs(out)) > 1.0:
+            out = out / torch.max(torch.abs(out))
+        out, _ = handlers.trim_center(out, seg_t)
+        res.append(out)
+        break_point += seg_length
+    out = torch.cat(res, -1)
+    handlers.save_wave(tensor2numpy(out[0, ...]), fname=dst, sample_rate=44100)
+
+
+def test_handler_streams_segments_but_writes_the_same_file(voicefixer, tmp_path, monkeypatch, capsys):
+    """The shipped handler reads, restores and writes a file segment by segment with ONE host sync per file (flags and
+    peaks checked at the end, PCM conversion on the device); its output file must be byte-identical to the reference
+    control flow with its two syncs per segment.  (The TFGAN generator ends in tanh, so |out| <= 1: the peak-normalising
+    branch and its warning cannot fire on this vocoder; the device-side form of it is value-identical by construction.)"""
+    from voicefixer_main_amd import handlers, synth
+    monkeypatch.setattr(handlers, "SEG_SECONDS", 1)          # 3 segments (the last one short) out of a 2.4-s file
+    wav = synth.make_clips(1, 2.4, seed=33)
+    src, a, b = str(tmp_path / "in.wav"), str(tmp_path / "a.wav"), str(tmp_path / "b.wav")
+    handlers.save_wave(wav[0, 0], src)
+    handlers._state["model"] = voicefixer
+    dev = torch.device("cuda:0")
+    handlers.handler(src, a, None, ckpt=None, device=dev, needrefresh=False, meta={"unify_energy": False})
+    _handler_in_reference_order(voicefixer, src, b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert handlers.load_wav(a).shape == (wav.shape[-1],)
+    assert "Exceed energy limit" not in capsys.readouterr().out
+    assert voicefixer.engine.take_flags() == 0
+
+
 def test_unify_energy_path(engine, unet_sd, voc_sd):
     from oracle import pipeline
     from voicefixer_main_amd import synth

@@ -130,6 +130,12 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
+def test_broadcast_state_dict_world_of_one():
+    from voicefixer_main_amd import dist as vdist
+    sd = {"w": torch.ones(2, 2)}
+    assert vdist.broadcast_state_dict(sd, torch.device("cpu")) is sd
+
+
 def test_shard_bounds():
     from voicefixer_main_amd.dist import shard_bounds
     assert shard_bounds(1024, 8) == [(i * 128, (i + 1) * 128) for i in range(8)]
@@ -162,6 +168,28 @@ if rank == 0:
 else:
     assert back is None
 assert set(t) == {"scatter_ms", "restore_ms", "gather_ms"} and all(v >= 0 for v in t.values())
+# unequal shards with an EMPTY rank (fewer clips than ranks): rank 1 gets nothing, restores nothing, sends nothing
+full1 = torch.arange(L, dtype=torch.float32).reshape(1, L) if rank == 0 else None
+mine = vdist.scatter_clips(full1, 1, L, dev)
+assert mine.shape == ((1, L) if rank == 0 else (0, L))
+back, t = vdist.sharded_step(lambda x: x - 2.0, full1, 1, L, dev)
+if rank == 0:
+    assert torch.equal(back, full1 - 2.0)
+# three clips on two ranks: shards of 2 and 1
+full3 = torch.arange(3 * L, dtype=torch.float32).reshape(3, L) if rank == 0 else None
+back = vdist.restore_sharded(lambda x: x * 0.5, full3, 3, L, dev)
+if rank == 0:
+    assert torch.equal(back, full3 * 0.5)
+# weights: rank 0 holds the state_dict, one flat broadcast, every rank ends up with the same tensors (SURVEY 8e)
+sd = None
+if rank == 0:
+    g = torch.Generator().manual_seed(3)
+    sd = {"a.weight": torch.randn(4, 3, 3, 3, generator=g), "a.bias": torch.randn(4, generator=g),
+          "bn.num_batches_tracked": torch.tensor(7), "s": torch.randn((), generator=g).double()}
+got = vdist.broadcast_state_dict(sd, dev)
+g = torch.Generator().manual_seed(3)
+want = {"a.weight": torch.randn(4, 3, 3, 3, generator=g), "a.bias": torch.randn(4, generator=g), "s": torch.randn((), generator=g)}
+assert set(got) == set(want) and all(got[k].shape == want[k].shape and torch.equal(got[k], want[k].float()) for k in want), rank
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

@@ -16,6 +16,7 @@ VFX_MAX_STAGES = 8
 MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER, MODEL_FRONTEND = 0, 1, 2, 3
 FLAG_NEGATIVE_INPUT = 1
 FLAG_F16_SATURATED = 2   # precision 2: an activation of the vocoder left the fp16 range and was clamped
+FLAG_PEAK_NORMALISED = 4  # vfx_restore_gsr divided a clip by its peak (the reference's "Exceed energy limit" warning)
 
 
 class VfxConfig(ctypes.Structure):

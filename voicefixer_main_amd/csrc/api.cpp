@@ -136,8 +136,29 @@ static inline uint16_t f16_rne(float f) {
 //           -- the weights of a convolution whose source is an activated fp16 tensor (k_conv, H64)
 int conv_chunk(int mode) { return mode == 3 ? 64 : kKC; }
 
+bool& f16_weight_issue() {
+  static thread_local bool issue = false;
+  return issue;
+}
+
 void rows_to_fragments(std::vector<float>& packed, int Cout, int mode) {
   const bool split = mode != 0;
+  if (mode == 2 || mode == 3) {
+    // fp16 operands: f16_rne clamps and flushes silently, and no device flag sees a WEIGHT.  A tensor whose largest weight
+    // is outside the fp16 range, or so deep in fp16's subnormal range (< 2^-17: fewer than 8 significant bits for the
+    // LARGEST weight, less for the others) that the products lose the mode's accuracy, marks the weight set as "needs
+    // strict arithmetic" (f16_weight_issue(); vocoder.cpp): every call on it raises VFX_FLAG_F16_SATURATED, so the
+    // model-level calls re-run on split-bf16 operands and a raw caller sees the flag.  Measured
+    // (tests/test_gpu_models.py): a tensor at 3e-5 (9 bits) still holds 55 dB, one at 3e-7 gives 18 dB.
+    float wmax = 0.f;
+    bool finite = true;
+    for (float v : packed) {
+      finite = finite && std::isfinite(v);
+      wmax = std::max(wmax, std::fabs(v));
+    }
+    VFX_CHECK(finite, "precision 2: a convolution weight is not finite");
+    if (wmax > 65504.f || (wmax != 0.f && wmax < 6.103515625e-05f / 8.f)) f16_weight_issue() = true;
+  }
   const int kc = conv_chunk(mode);
   const size_t blk = (size_t)Cout * kc;         // input floats per (chunk, tap) block
   const size_t oblk = (size_t)Cout * kKC;       // output floats per block: Cout / 32 cout blocks of 1024 floats
@@ -448,7 +469,14 @@ static double conv_algo_bytes(const TapConvParams& q) {
   if (q.out_act) b += out_px * q.Cout * (q.hionly ? 2.0 : 4.0);
   return b;
 }
+// a ResStack layer's algorithmic bytes are x in + y out = 8 bytes per element and LAYER (a pair
+// launch runs two layers).  What the kernel's own design moves on top of that (the fp16 forms xa / ya of the two-form trunk
+// of the wide stacks; half of it for a pair, whose intermediate tensor never leaves the CU) is `resblock_design_bytes`.
 static double resblock_algo_bytes(const ResBlockParams& q) {
+  const double n = (double)q.B * (q.geo2d ? (double)q.H * q.W : (double)q.T) * q.C;
+  return n * 8.0 * (q.dil2 > 0 ? 2.0 : 1.0);
+}
+static double resblock_design_bytes(const ResBlockParams& q) {
   const double n = (double)q.B * (q.geo2d ? (double)q.H * q.W : (double)q.T) * q.C;
   return n * 8.0 + (q.asrc ? n * 2.0 : 0.0) + (q.ya ? n * 2.0 : 0.0);  // x in, y out (+ the fp16 forms: xa in, ya out)
 }
@@ -484,6 +512,7 @@ void PlanBuilder::add_conv(TapConvParams p) {
       c.prof->events.push_back({a, b});
       c.prof->flops.push_back(conv_flops(pl->host_params[idx]));
       c.prof->bytes.push_back(conv_algo_bytes(pl->host_params[idx]));
+      c.prof->design_bytes.push_back(conv_algo_bytes(pl->host_params[idx]));
       c.prof->bn.push_back(pl->host_params[idx].Cout);
       c.prof->desc.push_back(pl->host_params[idx]);
     } else {
@@ -539,6 +568,7 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
       c.prof->events.push_back({a, b});
       c.prof->flops.push_back(resblock_flops(hp));
       c.prof->bytes.push_back(resblock_algo_bytes(hp));
+      c.prof->design_bytes.push_back(resblock_design_bytes(hp));
       c.prof->bn.push_back(hp.C);
       TapConvParams d{};
       d.M = hp.B * hp.T;
@@ -914,7 +944,7 @@ int vfx_istft(vfx_handle* h, const float* re, const float* im, int B, int T, int
 // model stages
 // ---------------------------------------------------------------------------------------------
 static std::shared_ptr<Plan> get_plan(vfx_handle* h, const std::string& key,
-                                      const std::function<void(PlanBuilder&)>& build) {
+                                      const std::function<void(PlanBuilder&)>& build, void* stream = nullptr) {
   auto it = h->plans.find(key);
   std::shared_ptr<Plan> plan;
   if (it == h->plans.end()) {
@@ -923,16 +953,23 @@ static std::shared_ptr<Plan> get_plan(vfx_handle* h, const std::string& key,
     build(pb);
     plan->arena_bytes = pb.arena.high;
     // bounded cache: drop the least recently used plan(s) first (their parameter blocks are hipFree'd, which waits
-    // for the device: nothing in flight still reads them)
+    // for the device: nothing in flight still reads them).  Plans a hipGraph was captured from are never dropped: the
+    // graph's kernel nodes keep the plan's device parameter blocks as arguments (the cache then grows past the bound).
     while (h->plans.size() >= kMaxCachedPlans) {
-      auto victim = h->plans.begin();
+      auto victim = h->plans.end();
       for (auto i = h->plans.begin(); i != h->plans.end(); ++i)
-        if (i->second->last_use < victim->second->last_use) victim = i;
+        if (!i->second->pinned && (victim == h->plans.end() || i->second->last_use < victim->second->last_use)) victim = i;
+      if (victim == h->plans.end()) break;
       h->plans.erase(victim);
     }
     h->plans[key] = plan;
   } else {
     plan = it->second;
+  }
+  if (stream) {  // the legacy (NULL) stream cannot be captured
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) == hipSuccess && st == hipStreamCaptureStatusActive)
+      plan->pinned = true;
   }
   plan->last_use = ++h->plan_tick;
   const char* old = h->arena;
@@ -1026,7 +1063,7 @@ static int vfx_resunet_mel_1(vfx_handle* h, const float* mel_linear, int B, int 
   VFX_CHECK(h && mel_linear && logmel_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL], "vfx_resunet_mel: weights of the mel ResUNet are not finalized");
   auto plan = get_plan(h, key_of("unet_mel", B, T),
-                       [&](PlanBuilder& pb) { build_unet_mel(pb, B, T, ext(0), ext(1)); });
+                       [&](PlanBuilder& pb) { build_unet_mel(pb, B, T, ext(0), ext(1)); }, stream);
   debug_poison(*plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
@@ -1061,7 +1098,7 @@ static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, 
     nm["re"] = pb.alloc_f(nsp);
     nm["im"] = pb.alloc_f(nsp);
     build_unet_spec(pb, B, T, ext(0), arena_buf(nm["cos"]), arena_buf(nm["sin"]), arena_buf(nm["re"]), arena_buf(nm["im"]));
-  });
+  }, stream);
   debug_poison(*plan, stream);
   const size_t off_cos = plan->named["cos"], off_sin = plan->named["sin"], off_re = plan->named["re"],
                off_im = plan->named["im"];
@@ -1095,7 +1132,7 @@ static int vfx_vocoder_1(vfx_handle* h, const float* mel_linear, int B, int T, f
   VFX_API_BEGIN_H(h)
   VFX_CHECK(h && mel_linear && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->voc, "vfx_vocoder: vocoder weights are not finalized");
-  auto plan = get_plan(h, key_of("vocoder", B, T), [&](PlanBuilder& pb) { build_vocoder(pb, B, T, ext(0), ext(1)); });
+  auto plan = get_plan(h, key_of("vocoder", B, T), [&](PlanBuilder& pb) { build_vocoder(pb, B, T, ext(0), ext(1)); }, stream);
   debug_poison(*plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), wav_out}, h->d_flags, &h->prof};
   plan->run(ctx);
@@ -1148,9 +1185,9 @@ static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, floa
     build_vocoder(pb, B, T, arena_buf(o_den), arena_buf(o_long), &peak_buf);
     pl->ops.push_back([=](const RunCtx& c) {
       launch_peak_trim(reinterpret_cast<float*>(pl->bound_base + o_long), B, Llong, L,
-                       reinterpret_cast<float*>(pl->bound_base + o_pk), /*have_peak=*/true, c.ext[1], c.stream);
+                       reinterpret_cast<float*>(pl->bound_base + o_pk), /*have_peak=*/true, c.ext[1], c.stream, c.flags);
     });
-  });
+  }, stream);
   debug_poison(*plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
@@ -1168,6 +1205,7 @@ int vfx_profile_begin(vfx_handle* h) {
   h->prof.events.clear();
   h->prof.flops.clear();
   h->prof.bytes.clear();
+  h->prof.design_bytes.clear();
   h->prof.bn.clear();
   VFX_API_END
 }
@@ -1181,7 +1219,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
   double ms = 0, fl = 0;
   FILE* dump = nullptr;
   if (const char* path = getenv("VFX_PROFILE_DUMP")) dump = fopen(path, "w");
-  if (dump) fprintf(dump, "idx,kernel,M,Cout,K,nseg,ntaps0,C0,Wi,sw,ms,tflops,bytes\n");
+  if (dump) fprintf(dump, "idx,kernel,M,Cout,K,nseg,ntaps0,C0,Wi,sw,ms,tflops,bytes,design_bytes\n");
   for (size_t i = 0; i < h->prof.events.size(); ++i) {
     float t = 0.f;
     VFX_HIP(hipEventElapsedTime(&t, h->prof.events[i].first, h->prof.events[i].second));
@@ -1198,8 +1236,8 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
         snprintf(kname, sizeof(kname), "k_conv<%d; %s; %s>%s", conv_block_n(d), elu ? "true" : "false", d.split ? "true" : "false",
                  d.hionly ? " f16" : "");
       }
-      fprintf(dump, "%zu,%s,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f,%.0f\n", i, kname, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C,
-              d.Wi, d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12, h->prof.bytes[i]);
+      fprintf(dump, "%zu,%s,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f,%.0f,%.0f\n", i, kname, d.M, d.Cout, K, d.nseg, d.seg[0].ntaps, d.seg[0].C,
+              d.Wi, d.sw, t, h->prof.flops[i] / (t * 1e-3) / 1e12, h->prof.bytes[i], h->prof.design_bytes[i]);
     }
     ms += t;
     fl += h->prof.flops[i];
@@ -1214,6 +1252,7 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
   h->prof.events.clear();
   h->prof.flops.clear();
   h->prof.bytes.clear();
+  h->prof.design_bytes.clear();
   h->prof.bn.clear();
   h->prof.enabled = false;
   VFX_API_END

@@ -19,9 +19,13 @@ __device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
+// One predicate for "this value does not survive the conversion" everywhere (kernels, conv_epilogue.h): not inside
+// [-65504, 65504] -- written so that a NaN is flagged too.
+__device__ __forceinline__ bool f16_out_of_range(float x) { return !(__builtin_fabsf(x) <= 65504.f); }
+
 // The same, recording whether the clamp changed a value (VFX_FLAG_F16_SATURATED).
 __device__ __forceinline__ unsigned pack_f16x2(float a, float b, bool& sat) {
-  sat = sat | (__builtin_fabsf(a) > 65504.f) | (__builtin_fabsf(b) > 65504.f);
+  sat = sat | (bool)((int)f16_out_of_range(a) | (int)f16_out_of_range(b));
   return pack_f16x2(a, b);
 }
 // One atomic per wave that saw a clamp (rare path).

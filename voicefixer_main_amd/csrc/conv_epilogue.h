@@ -124,7 +124,9 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
             h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(c01, ce_f16x2));
             h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(c23, ce_f16x2));
             l01 = l23 = 0u;
-            f16_sat = f16_sat | (c01[0] != u[0]) | (c01[1] != u[1]) | (c23[0] != u[2]) | (c23[1] != u[3]);  // clamped
+            // the predicate of conv_common.h's f16_out_of_range (this header is also used without it)
+            f16_sat = f16_sat | !(__builtin_fabsf(u[0]) <= 65504.f) | !(__builtin_fabsf(u[1]) <= 65504.f) |
+                      !(__builtin_fabsf(u[2]) <= 65504.f) | !(__builtin_fabsf(u[3]) <= 65504.f);
           } else {
             h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[0], u[1]}, ce_bf16x2));
             h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[2], u[3]}, ce_bf16x2));

@@ -86,6 +86,8 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
 
   const ResBlockParams& p = *pp;
   const int tid = threadIdx.x;
+  if (p.stagger > 0 && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   int tile;
   {
     const int nwg = gridDim.x, b = blockIdx.x;
@@ -581,6 +583,8 @@ void plan_block2d(ResBlockParams& p) {
 void plan_resblock(ResBlockParams& p) {
   VFX_CHECK(p.asrc ? resblock_act_supported(p.C) : resblock_supported(p.C), "resblock: C=%d is not supported", p.C);
   const int d = p.dil;
+  static const int stagger = getenv("VFX_RB_STAGGER") ? atoi(getenv("VFX_RB_STAGGER")) : 0;
+  p.stagger = stagger;
   // 16-bit mode, C = 64: the persistent register-weights kernel (resblock_rw.hip) with its own tile size
   p.rw = (!p.asrc && p.hionly && p.C == 64 && resblock_rw_tile() != 0) ? 1 : 0;
   if (p.rw) p.tile_m = resblock_rw_tile();

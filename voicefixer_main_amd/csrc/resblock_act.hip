@@ -85,6 +85,8 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
 
   const ResBlockParams& p = *pp;
   const int tid = threadIdx.x;
+  if (p.stagger > 0 && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   int tile;
   {
     const int nwg = gridDim.x, b = blockIdx.x;

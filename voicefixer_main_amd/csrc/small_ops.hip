@@ -371,18 +371,27 @@ __global__ void k_absmax(const float* __restrict__ x, int64_t n_per, unsigned* _
 }
 
 __global__ void k_trim_scale(const float* __restrict__ x, int64_t Llong, int L, int off, const unsigned* __restrict__ peak,
-                             float* __restrict__ out) {
+                             float* __restrict__ out, int* __restrict__ flags) {
   const int b = blockIdx.y;
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= L) return;
   const float p = __uint_as_float(peak[b]);
+  // eval_gsr_voicefixer.py:68-70 prints "Warning: Exceed energy limit" here: the handlers read this sticky bit once per file
+  if (n == 0 && p > 1.0f && flags) atomicOr(flags, VFX_FLAG_PEAK_NORMALISED);
   const float v = x[(int64_t)b * Llong + off + n];
   out[(int64_t)b * L + n] = p > 1.0f ? v / p : v;
 }
 
+__global__ void k_or_flags(int* flags, int bits) { atomicOr(flags, bits); }
+void launch_or_flags(int* flags, int bits, hipStream_t s) {
+  if (!flags) return;
+  hipLaunchKernelGGL(k_or_flags, dim3(1), dim3(1), 0, s, flags, bits);
+  VFX_HIP(hipGetLastError());
+}
+
 // `have_peak`: ws[b] already holds the peak of clip b (written by the vocoder tail).
 void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, bool have_peak, float* out,
-                      hipStream_t s) {
+                      hipStream_t s, int* flags) {
   if (!have_peak) {
     VFX_HIP(hipMemsetAsync(ws, 0, sizeof(unsigned) * B, s));
     const int gx = (int)std::min<int64_t>(64, (Llong + 255) / 256);
@@ -391,7 +400,7 @@ void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float*
   const int64_t diff = Llong - L;
   const int off = (int)(diff / 2);
   hipLaunchKernelGGL(k_trim_scale, dim3((L + 255) / 256, B), dim3(256), 0, s, wav_long, Llong, L, off,
-                     reinterpret_cast<const unsigned*>(ws), out);
+                     reinterpret_cast<const unsigned*>(ws), out, flags);
   VFX_HIP(hipGetLastError());
 }
 

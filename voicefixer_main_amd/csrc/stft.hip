@@ -371,13 +371,15 @@ __global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_istft(const float* __res
       xn[r] = make_float2(ldg32(R, NC - k), ldg32(I, NC - k));
     }
   };
-  // Frames at least D apart touch disjoint samples.  Round r (D rounds, one block barrier each) takes the frames f = r (mod D) of
-  // the workgroup's n frames, wave w those with f / D = w (mod 4): the frames of a round add into the buffer CONCURRENTLY and
-  // never meet, and a sample's contributions arrive in round order -- sums that do not depend on timing.
+  // Frames at least D apart touch disjoint samples.  Round r (D rounds, one block barrier each) takes the frames t = r (mod D)
+  // -- the ABSOLUTE frame index -- of the workgroup's n frames, wave w every fourth of them: the frames of a round add into the
+  // buffer CONCURRENTLY and never meet, and a sample's contributions arrive in the order of t mod D -- sums that depend neither
+  // on timing nor on how the buffer is cut into groups (IH, which the launch picks from the batch size): a clip's samples are
+  // bit-identical whatever batch it is restored in.
   const int D = (NFFT + hop - 1) / hop;
   const int n = t_hi - t_lo + 1;
-  // this wave's frame list in processing order: (r, f) with f = r + D (wave + 4 j)
-  auto first_in_round = [&](int r) __attribute__((always_inline)) { return r + D * wave; };
+  // this wave's frame list in processing order: (r, f) with f = ((r - t_lo) mod D) + D (wave + 4 j), f = t - t_lo
+  auto first_in_round = [&](int r) __attribute__((always_inline)) { return ((r - t_lo) % D + D) % D + D * wave; };
   int r = 0, f = first_in_round(0);
   while (r < D && f >= n) f = first_in_round(++r);  // the first frame of this wave, if any
   if (r < D) load_spectrum(t_lo + f);

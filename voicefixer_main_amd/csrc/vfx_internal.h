@@ -214,6 +214,10 @@ struct ResBlockParams {
   const float* sh2;
   int poff9[9];      // conv1: patch row offset of tap (dy, dx)
   int hoff9[9];      // conv2: h row offset of tap (dy, dx)
+  // Start-up stagger (experiment switch VFX_RB_STAGGER=n, plan_resblock): the blocks of the second residency slot of every CU
+  // (block ids 256 .. 511 of a launch) sleep n x 127 x 64 cycles first, so that the two co-resident blocks of a CU do not run
+  // their memory and arithmetic phases in step.
+  int stagger;
 };
 bool resblock_supported(int C);
 int resblock_block_waves(const ResBlockParams& hp);
@@ -286,7 +290,7 @@ void launch_voc_final(const float* x, int B, int T, int C, const float* w, float
 void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int unify, float* sums, float* mel_out,
                      hipStream_t s);
 void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, bool have_peak, float* out,
-                      hipStream_t s);
+                      hipStream_t s, int* flags = nullptr);  // flags: VFX_FLAG_PEAK_NORMALISED when a clip was divided by its peak
 void launch_spectral_metrics(const float* est, const float* tgt, int B, int T, int F, double* ws, float* out, hipStream_t s);
 int64_t count_nonfinite(const float* p, int64_t n, hipStream_t s);  // debug aid, synchronises
 void launch_chunk_gather(const float* x, int B, int L, int win, int hop, int lead, int n_chunks, float* chunks,
@@ -328,7 +332,8 @@ struct ConvProfile {  // HIP-event timing of every convolution launch (vfx_profi
   bool enabled = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::vector<double> flops;
-  std::vector<double> bytes;  // algorithmic HBM bytes of the launch
+  std::vector<double> bytes;  // algorithmic HBM bytes of the launch (SURVEY.md section 8d)
+  std::vector<double> design_bytes;  // what the kernel's data layout moves (two-form trunks carry their fp16 copies)
   std::vector<int> bn;
   std::vector<TapConvParams> desc;  // fused ResStack layers are described as M = B*T, Cout = C, nseg = 0
 };
@@ -356,6 +361,7 @@ struct Plan {
   int n_conv = 0;
   std::map<std::string, size_t> named;  // named arena offsets (bytes) of stage-level buffers
   uint64_t last_use = 0;                // handle tick of the last call (LRU eviction, get_plan)
+  bool pinned = false;                  // a hipGraph was captured from this plan: its parameter blocks must outlive the graph
   void run(const RunCtx& ctx);  // api.cpp (debug hooks: VFX_POISON_ARENA=2, VFX_DEBUG_NAN)
 };
 
@@ -422,6 +428,7 @@ struct VocoderWeights {
   float* final_w = nullptr;     // [7][C]
   float final_b = 0.f;
   int final_c = 0;
+  bool needs_strict = false;    // 16-bit mode: a weight tensor does not fit fp16 operands (f16_weight_issue)
 };
 
 // Conv weights -> MFMA fragment order [C/chunk][ntaps][Cout/32][1024 floats] (conv.hip); mode: 0 fp32, 1 split-bf16
@@ -434,6 +441,10 @@ std::vector<float> pack_conv(const float* w, int Cout, int CinTotal, int KH, int
 std::vector<float> pack_conv_transposed(const float* w, int Cin, int Cout, int KH, int KW,
                                         const std::vector<std::pair<int, int>>& taps, int mode);
 void rows_to_fragments(std::vector<float>& packed, int Cout, int mode);  // [..][Cout][32] rows -> fragment order
+// Set by rows_to_fragments when a tensor packed as fp16 operands (modes 2, 3) does not fit fp16 (|w| > 65504, or the whole
+// tensor deep in the subnormal range); the weight builders reset it before and read it after packing a model.
+bool& f16_weight_issue();
+void launch_or_flags(int* flags, int bits, hipStream_t s);  // small_ops.hip: flags |= bits, in stream order
 
 }  // namespace vfx
 

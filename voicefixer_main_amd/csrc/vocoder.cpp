@@ -76,6 +76,7 @@ std::vector<std::pair<int, int>> phase_taps(int s, int pad, int r) {
 std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
   const vfx_config& cfg = h->cfg;
   auto W = std::make_shared<VocoderWeights>();
+  f16_weight_issue() = false;  // set by pack_conv when a tensor does not fit the fp16 operands of the 16-bit mode
   int cin = cfg.n_mels;
   char name[96];
   for (int i = 0; i < cfg.voc_cond_layers; ++i) {
@@ -136,6 +137,8 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
   W->final_b = staged(h, std::string(name) + ".bias").data[0];
   W->final_c = c;
   VFX_CHECK(c % 32 == 0, "vocoder: final channel count %d must be a multiple of 32", c);
+  W->needs_strict = f16_weight_issue();
+  f16_weight_issue() = false;
   return W;
 }
 
@@ -157,6 +160,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     pl->ops.push_back([=](const RunCtx& c) {
       launch_voc_prep(resolve(c, mel_linear), B, T, Tp, hh->fe.voc_inv_weight, cfg.voc_amp_floor, cfg.voc_min_db,
                       cfg.voc_norm_range, reinterpret_cast<float*>(pl->bound_base + xo), c.stream);
+      // 16-bit mode on weights that do not fit fp16 operands: every call says so (never silently wrong)
+      if (hh->voc && hh->voc->needs_strict) launch_or_flags(c.flags, VFX_FLAG_F16_SATURATED, c.stream);
     });
   }
 

@@ -77,6 +77,46 @@ def gather_clips(shard, n, length, device, dst=0):
     return full
 
 
+def broadcast_state_dict(sd, device, src=0):
+    """Weights for N ranks ("weights: one broadcast at start"): rank `src` holds `sd` (a
+    state_dict of tensors, e.g. read from a checkpoint file once), every other rank passes None.  The key / shape / dtype
+    table travels as one small object, all floating-point tensors as ONE flat fp32 buffer in ONE `dist.broadcast`
+    (260 MB for the ResUNet, 150 MB for the vocoder: one ring over xGMI instead of 660 small ones); integer tensors
+    (`num_batches_tracked`) are dropped -- the engines ignore them.  Returns a state_dict of CPU tensors on every rank
+    (what `Engine.load_state_dict` takes).  A world of one returns `sd` unchanged."""
+    world, rank = world_rank()
+    if world == 1:
+        return sd
+    meta = [None]
+    if rank == src:
+        items = [(k, v) for k, v in sd.items() if isinstance(v, torch.Tensor) and v.is_floating_point()]
+        meta[0] = [(k, tuple(v.shape)) for k, v in items]
+    dist.broadcast_object_list(meta, src=src)
+    table = meta[0]
+    sizes = [int(torch.Size(shape).numel()) for _, shape in table]
+    total = sum(sizes)
+    if rank == src:
+        flat = torch.cat([v.detach().reshape(-1).to(torch.float32) for _, v in items]) if total else torch.empty(0)
+        flat = flat.to(device)
+    else:
+        flat = torch.empty(total, device=device, dtype=torch.float32)
+    if total:
+        dist.broadcast(flat, src=src)
+    flat = flat.cpu()
+    out, off = {}, 0
+    for (k, shape), n in zip(table, sizes):
+        out[k] = flat[off:off + n].reshape(shape)
+        off += n
+    return out
+
+
+def checked_restore(engine, **kw):
+    """engine_fn for restore_sharded / sharded_step that keeps the 16-bit mode's guarantee on every rank: a batch whose
+    vocoder activations left the fp16 range (VFX_FLAG_F16_SATURATED) is re-run on the split-bf16 twin, a negative
+    mel (to_log's assert) raises (Engine.restore_gsr_checked; one device sync per call)."""
+    return lambda x: engine.restore_gsr_checked(x, **kw)
+
+
 def restore_sharded(engine_fn, full, n, length, device, src=0):
     """scatter -> per-rank restore (engine_fn: (n_r, L) -> (n_r, L)) -> gather on `src`."""
     mine = scatter_clips(full, n, length, device, src)

@@ -252,6 +252,39 @@ class Engine:
                                             self._stream()), "vfx_restore_gsr")
         return (out, logmel) if want_logmel else out
 
+    def check_flags(self, rerun=None):
+        """Reads and clears the handle's sticky device flags (one device sync, like `to_log`'s assert in the reference).
+        A negative value reached a log10 -> AssertionError (pytorch_util.py:158), in every arithmetic mode.  16-bit vocoder
+        (precision 2): an activation beyond the fp16 range was clamped -> the call is repeated on the split-bf16 twin
+        (`rerun(twin_engine)`), or RuntimeError when no `rerun` is given.  Returns rerun's result, or None."""
+        flags = self.take_flags()
+        if flags & _lib.FLAG_NEGATIVE_INPUT:
+            raise AssertionError("to_log: input has negative values")
+        if flags & _lib.FLAG_F16_SATURATED:
+            if rerun is None:
+                raise RuntimeError("16-bit vocoder: an activation left the fp16 range (VFX_FLAG_F16_SATURATED); "
+                                   "re-run with precision 1")
+            import warnings
+            warnings.warn("16-bit vocoder: an activation left the fp16 range; this call is re-run with split-bf16 operands")
+            try:
+                twin = self.strict_twin()
+            except RuntimeError as e:      # a second copy of the weights + its arena on the same GPU, mid-run
+                raise RuntimeError("16-bit vocoder: the split-bf16 twin this call must be re-run on could not be created "
+                                   "(%s); call Engine.strict_twin() once at start-up to reserve it, or use precision 1" % e)
+            return rerun(twin)
+        return None
+
+    def restore_gsr_checked(self, wav, unify_energy=False, out=None):
+        """restore_gsr + check_flags: never silently wrong in the 16-bit mode, whoever the caller is (models, dist, bench)."""
+        res = self.restore_gsr(wav, unify_energy=unify_energy, out=out)
+        again = self.check_flags(lambda e: e.restore_gsr(wav, unify_energy=unify_energy, out=out))
+        return res if again is None else again
+
+    def vocoder_checked(self, mel_linear):
+        res = self.vocoder(mel_linear)
+        again = self.check_flags(lambda e: e.vocoder(mel_linear))
+        return res if again is None else again
+
     def profile_begin(self):
         _lib.check(self.lib.vfx_profile_begin(self.h), "vfx_profile_begin")
 

@@ -152,10 +152,12 @@ class Vocoder:
     def load_state_dict(self, sd, prefix=""):
         self.engine.load_state_dict(MODEL_VOCODER, fold_weight_norm(sd), prefix)
 
-    def __call__(self, mel, cuda=None):
+    def __call__(self, mel, cuda=None, check=True):
+        """`check` = False defers the flag check (one device sync) to the caller: Engine.check_flags, once per file in
+        the handlers."""
         assert mel.size()[-1] == 128
         out = self.engine.vocoder(mel[:, 0])
-        if self.engine.precision == 2:
+        if check:
             out = _rerun_if_saturated(self.engine, out, lambda e: e.vocoder(mel[:, 0]))
         return out[:, None]
 
@@ -163,18 +165,12 @@ class Vocoder:
 
 
 def _rerun_if_saturated(engine, out, call):
-    """16-bit vocoder (precision 2): an activation beyond the fp16 range is clamped by the kernels and reported through
-    a sticky device flag.  Such a call is re-run on the split-bf16 twin of the engine, so the mode is never silently
-    wrong on weights whose activations do not fit fp16 (costs one device sync per call, like `to_log`'s assert)."""
-    import warnings
-    from . import _lib
-    flags = engine.take_flags()
-    if flags & _lib.FLAG_NEGATIVE_INPUT:
-        raise AssertionError("to_log: input has negative values")
-    if flags & _lib.FLAG_F16_SATURATED:
-        warnings.warn("16-bit vocoder: an activation left the fp16 range; this call is re-run with split-bf16 operands")
-        out = call(engine.strict_twin())
-    return out
+    """Every arithmetic mode: a negative value that reached a log10 raises like `to_log`'s assert.  16-bit vocoder
+    (precision 2): an activation beyond the fp16 range is clamped by the kernels and reported through a sticky device flag;
+    such a call is re-run on the split-bf16 twin of the engine, so the mode is never silently wrong on weights whose
+    activations do not fit fp16 (Engine.check_flags: one device sync per call, like `to_log`'s assert)."""
+    again = engine.check_flags(call)
+    return out if again is None else again
 
 
 def fold_weight_norm(sd):
@@ -347,8 +343,8 @@ class VoiceFixer(_Base):
         """mel_orig (B,1,T,128) linear, non-negative -> {'mel': log10 estimate}  (Generator.forward,
         gsr_voicefixer.py:86-91).  `check` reproduces to_log's assert (one device sync)."""
         out = self.engine.resunet_mel(mel_orig[:, 0])[:, None]
-        if check and (self.engine.take_flags() & 1):
-            raise AssertionError("to_log: input has negative values")
+        if check:
+            self.engine.check_flags(lambda e: None)   # raises on a negative input; a saturation flag belongs to the vocoder call
         return {"mel": out}
 
     __call__ = forward
@@ -358,8 +354,7 @@ class VoiceFixer(_Base):
         squeeze = wav.dim() == 3
         x = wav[:, 0] if squeeze else wav
         out = self.engine.restore_gsr(x, unify_energy=unify_energy)
-        if self.engine.precision == 2:
-            out = _rerun_if_saturated(self.engine, out, lambda e: e.restore_gsr(x, unify_energy=unify_energy))
+        out = _rerun_if_saturated(self.engine, out, lambda e: e.restore_gsr(x, unify_energy=unify_energy))
         return out[:, None] if squeeze else out
 
 
