@@ -3,8 +3,8 @@
 k_conv<BN, ELU, SPLIT, ABL, RING, HI>  ->  "k_conv<BN, ELU, SPLIT>" (+ " f16" for the 16-bit launches of precision 2)
 k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
 k_resblock_act<C, NW, MT>              ->  "k_resblock<C, NW> f16"
+k_resblock_w64<C>                      ->  "k_resblock<C, 4> f16"
 k_resblock_rw<NW, PAIR>                ->  "k_resblock<64, NW> f16" / "k_resblock_pair<64, NW> f16"
-k_resblock_pc<C>, k_resblock_rl<C>      ->  "k_resblock<C, 8> f16"
 """
 import re
 
@@ -19,14 +19,12 @@ def short(n, width=40):
         return "k_conv<%s, %s, %s>%s" % (args[0], args[1], args[2], " f16" if hi else "")
     if name == "k_resblock_act" and len(args) >= 2:      # the fused wide layer of the 16-bit mode
         return "k_resblock<%s, %s> f16" % (args[0], args[1])
+    if name == "k_resblock_w64" and args:                # the same layer as 4-wave blocks, two per CU
+        return "k_resblock<%s, 4> f16" % args[0]
     if name == "k_resblock_rw" and args:                 # C = 64, 16-bit mode: persistent, weights in registers
         if len(args) >= 2 and args[1] == "true":         # two layers per launch
             return "k_resblock_pair<64, %s> f16" % args[0]
         return "k_resblock<64, %s> f16" % args[0]
-    if name == "k_resblock_rl" and args:                 # C = 128, 16-bit mode: the patch through registers
-        return "k_resblock<%s, 8> f16" % args[0]
-    if name == "k_resblock_pc" and args:
-        return "k_resblock<%s, 8> f16" % args[0]
     if name == "k_resblock" and len(args) >= 2:
         hi = len(args) >= 3 and args[2] == "true"
         return "k_resblock<%s, %s>%s" % (args[0], args[1], " f16" if hi else "")

@@ -9,7 +9,7 @@ cd /tmp; export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
   timeout 240 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" -o "$name" -- \
-    python "$ROOT/bench.py" --steps 1 --warmup 1 --no-roofline --no-alt --cpu-baseline-clips 0 --traffic off --no-parity "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
+    python "$ROOT/bench.py" --steps 1 --warmup 1 --no-roofline --no-alt --cpu-baseline-clips 0 --traffic off --no-parity --no-aux "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
   echo "$name rc=$?"
 }
 EXTRA=("$@")

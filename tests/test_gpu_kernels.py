@@ -78,7 +78,7 @@ def test_resblock_layer(engine, C, T, fused):
     x = _rand((B, C, T), 21)
     w1, w2 = _rand((C, C, 3), 22, 0.08), _rand((C, C, 3), 23, 0.08)
     b1, b2 = _rand((C,), 24, 0.1), _rand((C,), 25, 0.1)
-    for d in (1, 3, 27, 81, 729, 2187):
+    for d in (1, 3, 9, 27, 81, 243, 729, 2187):
         ref = _resblock_ref(x, w1, b1, w2, b2, d, 0.01)
         y = engine.op_resblock(x.permute(0, 2, 1).contiguous(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), d, 0.01, fused)
         err = (y.cpu().permute(0, 2, 1).double() - ref).abs().max().item()

@@ -101,7 +101,7 @@ def test_reference_segment_1x60s(engine):
 
 # SI-SDR of the spectrogram path against the FLOAT64 oracle, per arithmetic mode: measured on MI355X (round 3,
 # gpurun_out/parity_shapes.json -> profiles/r03_parity_shapes.json), the bars sit 5 dB under the measurement.
-SSR_SISDR_BAR = {"fp32": 55.0, "split-bf16": 45.0, "fp16-vocoder": 45.0}
+SSR_SISDR_BAR = {"fp32": 55.0, "split-bf16": 52.0, "fp16-vocoder": 52.0}   # measured: split-bf16 57.8 dB (both lengths)
 
 
 @pytest.mark.parametrize("n_samples", [132300, 132300 + 200])
@@ -125,7 +125,7 @@ def test_ssr_unet_3s_shape(engine, n_samples):
         rt = ref["wav"][:, 0, -tail:]
         rel = float(np.abs(got[:, -tail:] - rt).max() / np.abs(rt).max())
         _report("ssr_3s_tail_rel_err[%s]" % engine.tol["name"], rel)
-        assert np.abs(rt).max() > 0 and rel < (1e-3 if engine.tol["name"] == "fp32" else 1e-2), rel
+        assert np.abs(rt).max() > 0 and rel < 1e-3, rel            # measured: 8.6e-5 (split-bf16)
 
 
 @functools.lru_cache(maxsize=None)
@@ -165,13 +165,16 @@ def test_handler_ssr_unet_two_segments(engine, tmp_path):
     metrics = handlers.handler_ssr_unet(src, dst, src, ckpt=None, device=torch.device("cuda:0"), needrefresh=False, meta={})
     assert set(metrics) == {"mel-lsd", "mel-sispec", "mel-non-log-sispec", "mel-ssim"}           # eval_ssr_unet.py:131-135
     out = handlers.load_wav(dst)
+    # the oracle's waveform through the file's PCM16 conversion (tools/file/wav.py:10-27 incl. its wrap of exactly +1.0 to
+    # -32768: a peak-normalised segment -- this 60-s one is -- has one such sample, 30 dB of "error" if left out)
+    segs = [(np.asarray(o, np.float64) * 2 ** 15).astype(np.int32).astype(np.short).astype(np.float32) / 32768.0 for o in segs]
     ref = np.concatenate(segs)
     assert out.shape == ref.shape == x.shape
     s60, s1 = _sisdr(out[:44100 * 60], segs[0]), _sisdr(out[44100 * 60:], segs[1])
     _report("ssr_handler_sisdr_db_60s_segment", s60)
     _report("ssr_handler_sisdr_db_1s_segment", s1)
     # PCM16 output: quantisation noise alone is ~ -101 dB re full scale
-    assert s60 > SSR_SISDR_BAR["split-bf16"] - 5.0 and s1 > SSR_SISDR_BAR["split-bf16"] - 5.0, (s60, s1)
+    assert s60 > SSR_SISDR_BAR["split-bf16"] - 4.0 and s1 > SSR_SISDR_BAR["split-bf16"], (s60, s1)
     # the metrics of the last segment, from the oracle's waveform with the formulas of evaluation_proc (torch, CPU)
     from oracle import dsp
     lo = 44100 * 60

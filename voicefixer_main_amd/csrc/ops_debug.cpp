@@ -115,10 +115,8 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
     // two-launch form, 16-bit mode: h travels as an activated fp16 tensor (64-channel stages) when C allows it
     const bool h_f16 = !fused && h->cfg.precision == 2 && C % 64 == 0;
     const bool h_act = !(h->cfg.precision == 2 && !h_f16);
-    // (fused, 16-bit mode, C = 128: resblock_rl.hip reads 64-channel fp16 fragments)
-    const bool rl = fused && h->cfg.precision == 2 && C == 128 && resblock_rl_enabled();
-    float* dw1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, rl ? 3 : pmode));
-    float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, (h_f16 || rl) ? 3 : pmode));
+    float* dw1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, pmode));
+    float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, h_f16 ? 3 : pmode));
     float* db1 = sc.blob.upload(b1, C);
     float* db2 = sc.blob.upload(b2, C);
     if (fused && h->cfg.precision == 2 && resblock_act_supported(C)) {
@@ -224,7 +222,7 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
 // Host-only: the tile geometry plan_resblock() gives one fused ResStack layer (or layer pair, dil2 > 0) of `C` channels over
 // sequences of `T` positions in precision mode `precision` -- so that the CPU test suite can check that the tiles of every
 // kernel family (1-D, folded, pairs; 128- and 256-position tiles) write each output position exactly once.
-// out[12] = fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, tile_m, rw, rl, asrc.  Needs no GPU and no handle.
+// out[12] = fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, tile_m, rw, 0, asrc.  Needs no GPU and no handle.
 extern "C" int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int precision, int* out) {
   try {
     VFX_CHECK(out && T > 0 && dil >= 1 && dil2 >= 0, "bad argument");
@@ -240,7 +238,7 @@ extern "C" int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int p
       rp.tile_m = resblock_act_tile();
     }
     plan_resblock(rp);
-    const int v[12] = {rp.fold, rp.TH, rp.W1, rp.TWo, rp.tiles_h, rp.tiles_w, rp.PW, rp.P, rp.tile_m, rp.rw, rp.rl, rp.asrc};
+    const int v[12] = {rp.fold, rp.TH, rp.W1, rp.TWo, rp.tiles_h, rp.tiles_w, rp.PW, rp.P, rp.tile_m, rp.rw, 0, rp.asrc};
     for (int i = 0; i < 12; ++i) out[i] = v[i];
   } catch (const vfx::Error&) {
     return 1;

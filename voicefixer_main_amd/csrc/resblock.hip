@@ -541,6 +541,7 @@ bool resblock_supported(int C) { return C == 64 || C == 128; }
 int resblock_block_waves(const ResBlockParams& hp) {
   static const bool four32 = getenv("VFX_RB_NW32") && atoi(getenv("VFX_RB_NW32")) == 4;
   if (hp.rw) return hp.tile_m / 32;
+  if (hp.asrc && hp.patch_rows) return 4;
   if (hp.geo2d) return hp.C == 32 && !four32 ? 2 : 4;
   return hp.C >= 128 ? 8 : 4;
 }
@@ -588,9 +589,11 @@ void plan_resblock(ResBlockParams& p) {
   // 16-bit mode, C = 64: the persistent register-weights kernel (resblock_rw.hip) with its own tile size
   p.rw = (!p.asrc && p.hionly && p.C == 64 && resblock_rw_tile() != 0) ? 1 : 0;
   if (p.rw) p.tile_m = resblock_rw_tile();
-  p.rl = (!p.asrc && p.hionly && p.C == 128 && resblock_rl_enabled()) ? 1 : 0;
   const int MT = p.tile_m ? p.tile_m : CBM;  // h positions per tile (resblock_act: 64 or 128; resblock_rw: 128 or 256)
-  const int PR = MT + 64;                    // patch rows per buffer (= kPatchMaxRows for MT = 128)
+  // patch rows per buffer: MT + 64 (= kPatchMaxRows for MT = 128); the 4-wave form of the wide layer keeps four chunk
+  // buffers in half a CU's LDS: 160 rows (resblock_w64.hip)
+  p.patch_rows = (p.asrc && MT == 128 && p.dil2 == 0 && resblock_w64_enabled()) ? resblock_w64_patch_rows() : 0;
+  const int PR = p.patch_rows ? p.patch_rows : MT + 64;
   VFX_CHECK(MT == 64 || MT == 128 || (MT == 256 && p.rw), "resblock: tile of %d positions", MT);
   p.tile_m = MT;
   if (p.dil2 > 0) {
@@ -643,10 +646,6 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
   }
   if (hp.rw) {
     launch_resblock_rw(hp, dparams, stream);
-    return;
-  }
-  if (hp.rl) {
-    launch_resblock_rl(hp, dparams, stream);
     return;
   }
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;

@@ -425,7 +425,7 @@ void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams
   VFX_CHECK(hp.tile_m == 64 || hp.tile_m == 128, "resblock_act: tile of %d positions", hp.tile_m);
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock_act: bad grid");
-  if (hp.tile_m == 128 && resblock_pc_enabled()) return launch_resblock_pc(hp, dparams, stream);
+  if (hp.tile_m == 128 && hp.patch_rows) return launch_resblock_w64(hp, dparams, stream);
   if (hp.tile_m == 64) launch_rba<64>((int)grid, stream, dparams);
   else launch_rba<128>((int)grid, stream, dparams);
   VFX_HIP(hipGetLastError());

@@ -1,0 +1,393 @@
+// resblock_w64.hip -- the fused wide ResStack layer of the 16-bit mode (C = 256, two-form trunk, cf. resblock_act.hip)
+//
+//     y  = x + conv2(LeakyReLU(conv1(xa) + b1)) + b2,      ya = fp16(LeakyReLU_next(y))
+//
+// as FOUR-wave blocks with TWO blocks per CU.
+//
+// Why (round-3 measurements): the 8-wave / one-block-per-CU form (k_resblock_act) runs a layer in the
+// SUM of its memory phases (0.50 ms with all arithmetic removed) and its arithmetic (0.48 ms).  The memory phases are not
+// latency chains: a CU streams HBM at ~22 GB/s (10 B/clk) whatever the rest of the chip does, and a tile moves 384 KB -- 17 us
+// during which the MFMA pipe idles, because the block that owns the CU's LDS is the one that waits.  And its arithmetic phase is
+// operand-bound: every MFMA takes a 1 KB pixel fragment from LDS (wave tile 32 couts x 128 positions).
+// Here a wave owns 64 couts x 128 positions (128 accumulator registers): a pixel fragment read from LDS feeds TWO MFMAs, a weight
+// fragment four; the block is 4 waves (one per SIMD, <= 256 registers), its LDS fits twice into a CU (80 KB: the xa patch as four
+// chunk buffers of 160 rows; h and the staged accumulators overlay them), so two blocks share a CU and the memory phases of one
+// run under the arithmetic of the other -- each block has its own waves, hence its own vmcnt queues.  With one wave per SIMD
+// nobody hides a wave's own LDS latency, so the compute phases carry no scheduling barriers: the fragment reads of the next K step
+// are free to move above the MFMAs of this one (the weight registers are ordered by their `use` statements alone).
+//
+// Tile geometry: plan_resblock with patch_rows = 160 (1-D tiles for d <= 16, folded rows of d samples above; d = 27 folds here).
+#include "conv_common.h"
+#include "vfx_internal.h"
+
+namespace vfx {
+
+namespace {
+constexpr int W64_PR = 160;  // patch rows per chunk buffer
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* __restrict__ pp) {
+  constexpr int NW = 4, NTHR = NW * 64, MT = 128;
+  constexpr int NCH = C / 64;                // 64-channel chunks: 128-byte rows of fp16
+  static_assert(NCH == NW, "one wave per 64 output channels");
+  constexpr int PR = W64_PR;
+  constexpr int PBYTES = PR * CROW;
+  constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
+  constexpr int NG = PR / RG;                // DMA instructions per wave and chunk
+  static_assert(PR % RG == 0 && (RG / 2) % 8 == 0, "patch rows must split into whole DMA groups with one swizzle key");
+  constexpr int WM = MT / 32;                // 32-position blocks per wave
+  constexpr int WL = 8;                      // weight loads per tap and wave: 2 cout blocks x 4 K steps
+  constexpr int HROW = C * 2;                // bytes per h row (fp16)
+  constexpr int NT1 = 3 * NCH;               // taps of conv1 (chunk-major); conv2 has as many
+  constexpr int EPC = 128, NEP = C / EPC;    // epilogue passes of 128 channels (two waves each)
+  constexpr int LDO = EPC + 4;               // staged output row (floats)
+  constexpr int V = EPC / 4, RPP = NTHR / V; // 32 float4 per staged row, 8 rows per step
+  constexpr int SUB = 4;                     // steps per sub-pass (32 rows): the residual of a sub-pass is requested one ahead
+  constexpr int NSUB = MT / (RPP * SUB);     // 4 sub-passes per pass
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds = reinterpret_cast<char*>(smem);
+
+  const ResBlockParams& p = *pp;
+  const int tid = threadIdx.x;
+  int tile;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tj = tile % p.tiles_w;
+  const int ti = (tile / p.tiles_w) % p.tiles_h;
+  const int img = tile / (p.tiles_w * p.tiles_h);
+  const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
+  const int rowstride = p.fold ? d : 0;
+  const int j0 = tj * p.TWo;
+  const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
+  const int base_x = base_h - d;                                // position of patch pixel (0, 0)
+  const float slope = p.slope;
+
+  const int lr = tid >> 3, cg = tid & 7;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int key_l = (lr >> 1) & 7;  // swizzle key of patch rows lr + RG * q
+
+  // ---- the xa patch: every chunk at once (ONE round trip per tile; the other block of the CU computes meanwhile) -------------
+  {
+    unsigned voff[NG];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const int prow = lr + RG * q;
+      const int pi = prow / PW, pj = prow - pi * PW;
+      const int pos = base_x + pi * rowstride + pj;
+      const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
+      voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 2);
+      okmask |= ok ? (1u << q) : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.xa + c * kKC), 0, (int)(unsigned)((int64_t)p.B * T * C * 2 - (int64_t)c * kKC * 4), 0x00020000);
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        // the lane's 16 bytes land in slot cg of its row: fetch source piece cg ^ key (piece p sits at slot p ^ key)
+        const unsigned o = (okmask & (1u << q)) ? voff[q] + ((unsigned)(cg ^ key_l) << 4) : 0xfffffff0u;
+        VFX_LDS void* l = (VFX_LDS void*)(lds + c * PBYTES + (RG * q + 8 * wave_u) * CROW);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
+      }
+    }
+  }
+
+  int arow1[WM];   // A row of this lane's h pixel in the patch (tap offset to be added)
+  bool hval[WM];   // that h pixel lies inside the tile's h grid and inside the sequence
+#pragma unroll
+  for (int a = 0; a < WM; ++a) {
+    const int ml = a * 32 + l31;
+    const int li = ml / W1, lj = ml - li * W1;
+    arow1[a] = li < TH ? li * PW + lj : 0;
+    const int pos = base_h + li * rowstride + lj;
+    hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
+  }
+  // weights: (64-channel chunk, tap) blocks of C / 32 cout blocks x 1024 floats; this wave's cout blocks are 2 w, 2 w + 1
+  const unsigned nb_off = (unsigned)(2 * wave_u * 1024 + lane * 4) * 4u;
+  const int64_t ts = (int64_t)C * kKC;
+
+  f32x16 acc[2][WM];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][a][r] = 0.f;
+
+  // Everything the compute phases read from the parameter block, once: the waits below are `asm volatile` statements, and a
+  // reload of p.poff / p.w1 behind one of them would be a scalar load + lgkmcnt(0) -- which also drains the LDS reads in flight.
+  const float* const w1p = p.w1;
+  const float* const w2p = p.w2;
+  const int poff0 = p.poff[0], poff1 = p.poff[1], poff2 = p.poff[2];
+
+  // ---- weight ring: global tap g (conv1: 0 .. NT1-1, conv2: NT1 .. 2*NT1-1) in register group g & 1, one tap ahead -----------
+  // (no "memory" clobbers in the compute phases: an LDS fragment read may move across a weight fetch / wait)
+  BFrag R0a = {}, R0b = {}, R1a = {}, R1b = {};  // [ring slot][cout block]
+  auto load_w = [&](BFrag& R, const float* wtap) __attribute__((always_inline)) {
+    asm volatile(
+        "s_nop 4\n\t"
+        "global_load_dwordx4 %0, %4, %5\n\t"
+        "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+        "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+        "global_load_dwordx4 %3, %4, %5 offset:3072"
+        : "=&v"(R.f[0]), "=&v"(R.f[1]), "=&v"(R.f[2]), "=&v"(R.f[3])
+        : "v"(nb_off), "s"(wtap));
+  };
+  auto fetch = [&](int g) __attribute__((always_inline)) {
+    const float* w = g < NT1 ? w1p + g * ts : w2p + (g - NT1) * ts;
+    if (g & 1) {
+      load_w(R1a, w);
+      load_w(R1b, w + 1024);
+    } else {
+      load_w(R0a, w);
+      load_w(R0b, w + 1024);
+    }
+  };
+  // The registers of ring slot s are readable behind this statement (a counted s_waitcnt precedes it in program order: asm
+  // volatile statements keep their order); every reader depends on its outputs, so no scheduling barrier is needed.
+  auto use_slot = [&](int s) __attribute__((always_inline)) {
+    if (s) {
+      asm volatile("" : "+v"(R1a.f[0]), "+v"(R1a.f[1]), "+v"(R1a.f[2]), "+v"(R1a.f[3]), "+v"(R1b.f[0]), "+v"(R1b.f[1]), "+v"(R1b.f[2]),
+                   "+v"(R1b.f[3]));
+    } else {
+      asm volatile("" : "+v"(R0a.f[0]), "+v"(R0a.f[1]), "+v"(R0a.f[2]), "+v"(R0a.f[3]), "+v"(R0b.f[0]), "+v"(R0b.f[1]), "+v"(R0b.f[2]),
+                   "+v"(R0b.f[3]));
+    }
+  };
+
+  // ---- pixel fragments: software-pipelined one K step (8 MFMAs = 256 cycles) ahead -----------------------------------------------
+  // Step (g, s) = K step s of tap g reads the four fragments of the NEXT step into the other register set before it issues its
+  // own eight MFMAs.  rb / kx: byte offset of the lane's row of position block a in the LDS image of tap g, and its swizzle key
+  // xor the lane's half (recomputed per tap behind an opaque statement: kept for all taps they would be 200 registers).
+  int rb[2][WM], kx[2][WM];
+  auto prep1 = [&](int g) __attribute__((always_inline)) {  // conv1: the patch chunk of tap g, rows arow1 + tap offset
+    const int c = g / 3, k = g % 3;
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      int r = arow1[a];
+      asm volatile("" : "+v"(r));
+      const int row = r + (k == 0 ? poff0 : (k == 1 ? poff1 : poff2));
+      rb[g & 1][a] = c * PBYTES + row * CROW;
+      kx[g & 1][a] = swz_key(row) ^ (16 * lh);
+    }
+  };
+  auto prep2 = [&](int g) __attribute__((always_inline)) {  // conv2: h rows m + k - 1; chunk c of row r sits at chunk position c ^ (r & 1)
+    const int c = (g - NT1) / 3, k = (g - NT1) % 3;
+    int lrow = l31;
+    asm volatile("" : "+v"(lrow));
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const int r0 = a * 32 + lrow + k - 1;
+      const int row = r0 < 0 ? 0 : (r0 > MT - 1 ? MT - 1 : r0);  // clamped rows only feed outputs that are masked anyway
+      rb[g & 1][a] = row * HROW + (c ^ (row & 1)) * CROW;
+      kx[g & 1][a] = swz_key(row) ^ (16 * lh);
+    }
+  };
+  f16x8 pxE[WM], pxO[WM];
+  auto rd = [&](f16x8 (&px)[WM], int g, int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < WM; ++a) px[a] = *reinterpret_cast<const f16x8*>(lds + rb[g & 1][a] + (kx[g & 1][a] ^ (32 * st)));
+  };
+  // one K step of tap g on ring slot g & 1: D = W (A operand: rows = couts) x image rows (B operand: columns = pixels): lane =
+  // pixel, registers = four runs of 4 consecutive couts
+  auto mm = [&](const f16x8 (&px)[WM], int g, int st) __attribute__((always_inline)) {
+    const BFrag& Ra = (g & 1) ? R1a : R0a;
+    const BFrag& Rb = (g & 1) ? R1b : R0b;
+    const f16x8 wa = __builtin_bit_cast(f16x8, Ra.f[st]);
+    const f16x8 wb = __builtin_bit_cast(f16x8, Rb.f[st]);
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      acc[0][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, px[a], acc[0][a], 0, 0, 0);
+      acc[1][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb, px[a], acc[1][a], 0, 0, 0);
+    }
+  };
+  // taps g0 .. g1-1 of one convolution (prep = prep1 / prep2); tap g1 (if it exists in this launch) is fetched but not used here
+  auto conv = [&](auto prep, int g0, int g1, bool fetch_past) __attribute__((always_inline)) {
+    prep(g0);
+    rd(pxE, g0, 0);
+#pragma unroll
+    for (int g = g0; g < g1; ++g) {
+      if (g + 1 < g1 || fetch_past) {
+        fetch(g + 1);
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL));
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)");
+      }
+      use_slot(g & 1);
+      if (g + 1 < g1) prep(g + 1);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const bool last = g + 1 == g1 && st == 3;
+        if (st & 1) {
+          if (!last) { if (st == 3) rd(pxE, g + 1, 0); else rd(pxE, g, st + 1); }
+          mm(pxO, g, st);
+        } else {
+          rd(pxO, g, st + 1);
+          mm(pxE, g, st);
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {  // 1 fragment read, then 2 MFMAs, four times
+          if (!last) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+      }
+    }
+  };
+
+  fetch(0);
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // the patch and tap 0 have landed (this wave's share)
+  __syncthreads();                                     // ... and everybody else's
+
+  // ---- phase 1: conv1 (its last tap fetches the first tap of conv2) -------------------------------------------------------------
+  conv(prep1, 0, NT1, true);
+  __syncthreads();  // every wave is done reading the patch buffers that h overlays
+
+  // ---- phase 2: h = LeakyReLU(conv1 + b1) as fp16, zero outside the sequence ---------------------------------------------------
+  // Lane (l31, lh) of position block a holds h pixel m = a*32 + l31 and, in registers 4j .. 4j+3 of cout block cb, channels
+  // (2w + cb)*32 + 8j + 4lh .. +3: chunk w of the pixel's row, piece cb*4 + j, half lh.
+  {
+    bool f16_sat = false;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      f32x4 b1v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1v[j] = *(const VFX_GLOBAL f32x4*)(p.b1 + (2 * wave_u + cb) * 32 + 8 * j + 4 * lh);
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const int m = a * 32 + l31;
+        char* rowp = lds + m * HROW + (wave_u ^ (m & 1)) * CROW + 8 * lh;  // chunk parity swap: see prep2()
+        const int key = (m >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = acc[cb][a][4 * j + e] + b1v[j][e];
+            u[e] = hval[a] ? fmaxf(t, t * slope) : 0.f;
+            acc[cb][a][4 * j + e] = 0.f;
+          }
+          *reinterpret_cast<uint2*>(rowp + (((cb * 4 + j) ^ key) << 4)) =
+              make_uint2(pack_f16x2(u[0], u[1], f16_sat), pack_f16x2(u[2], u[3], f16_sat));
+        }
+      }
+    }
+    report_f16_saturation(f16_sat, p.flags);
+  }
+  __syncthreads();  // h is complete
+
+  // ---- phase 3: conv2 from the resident h (tap NT1 was fetched by conv1's last tap: its wait is the first one of conv()) ----------
+  conv(prep2, NT1, 2 * NT1, false);
+
+  // ---- phase 4: y = conv2 + b2 + x, raw fp32 and (optionally) activated fp16 -----------------------------------------------------
+  // Two passes of 128 channels (the pass of waves 0, 1, then the one of waves 2, 3) through a staged tile in LDS; every pass in
+  // NSUB sub-passes of 32 rows whose residual is requested one sub-pass ahead (the loads of sub-pass s + 1 are issued BEFORE
+  // the stores of sub-pass s, so no load waits behind a store: vmcnt counts both, in order).
+  const int c4 = tid % V, r0 = tid / V;
+  const bool even = (tid & 1) == 0;
+  const float aslope = p.act_slope;
+  int opix[NSUB][SUB];
+#pragma unroll
+  for (int sp = 0; sp < NSUB; ++sp)
+#pragma unroll
+    for (int q = 0; q < SUB; ++q) {
+      const int m = r0 + (sp * SUB + q) * RPP;  // h pixel of the staged row
+      const int li = m / W1, lj = m - li * W1;
+      const int pos = base_h + li * rowstride + lj;
+      const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
+      opix[sp][q] = ok ? img * T + pos : -1;
+    }
+  f32x4 resA[SUB], resB[SUB];
+  auto request_res = [&](f32x4 (&res)[SUB], int pass, int sp) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < SUB; ++q) {
+      const int op = opix[sp][q];
+      res[q] = *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(op < 0 ? 0 : op) * C + pass * EPC + 4 * c4);
+    }
+  };
+  request_res(resA, 0, 0);
+  __syncthreads();  // every wave is done with h
+  bool ya_sat = false;
+#pragma unroll
+  for (int pass = 0; pass < NEP; ++pass) {
+    if ((wave_u >> 1) == pass) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = a * 32 + l31;
+            *reinterpret_cast<f32x4*>(smem + row * LDO + (wave_u & 1) * 64 + cb * 32 + 8 * j + 4 * lh) =
+                f32x4{acc[cb][a][4 * j], acc[cb][a][4 * j + 1], acc[cb][a][4 * j + 2], acc[cb][a][4 * j + 3]};
+          }
+    }
+    __syncthreads();  // the pass is staged
+    const int ncol = pass * EPC + 4 * c4;
+    const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + ncol);
+#pragma unroll
+    for (int sp = 0; sp < NSUB; ++sp) {
+      const int idx = pass * NSUB + sp;  // sub-passes alternate between the two residual register sets
+      f32x4 (&cur)[SUB] = (idx & 1) ? resB : resA;
+      f32x4 (&nxt)[SUB] = (idx & 1) ? resA : resB;
+      if (idx + 1 < NEP * NSUB) request_res(nxt, (idx + 1) / NSUB, (idx + 1) % NSUB);
+      f32x4 val[SUB];
+#pragma unroll
+      for (int q = 0; q < SUB; ++q)
+        val[q] = *reinterpret_cast<const f32x4*>(smem + (r0 + (sp * SUB + q) * RPP) * LDO + 4 * c4) + bv + cur[q];
+#pragma unroll
+      for (int q = 0; q < SUB; ++q)
+        if (opix[sp][q] >= 0) *(VFX_GLOBAL f32x4*)(p.y + (int64_t)opix[sp][q] * C + ncol) = val[q];
+      if (p.ya) {
+#pragma unroll
+        for (int q = 0; q < SUB; ++q) {
+          f32x4 u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] = fmaxf(val[q][e], val[q][e] * aslope);
+          const unsigned h01 = pack_f16x2(u[0], u[1], ya_sat), h23 = pack_f16x2(u[2], u[3], ya_sat);
+          // quad_perm [1,0,3,2]: the even lane of a pair collects the pair's 8 consecutive channels (16 bytes)
+          const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)h01, 0xB1, 0xf, 0xf, false);
+          const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)h23, 0xB1, 0xf, 0xf, false);
+          const u32x4 w = {h01, h23, g0, g1};
+          if (opix[sp][q] >= 0 && even)
+            *(VFX_GLOBAL f32x4*)(p.ya + (int64_t)opix[sp][q] * (C / 2) + (ncol >> 1)) = __builtin_bit_cast(f32x4, w);
+        }
+      }
+    }
+    if (pass + 1 < NEP) __syncthreads();  // the staged pass has been consumed
+  }
+  if (p.ya) report_f16_saturation(ya_sat, p.flags);
+}
+
+int resblock_w64_patch_rows() { return W64_PR; }
+
+// The four-wave form runs the wide layers by default; VFX_RBA_W64=0 selects the 8-wave / one-block-per-CU kernel (A/B runs).
+bool resblock_w64_enabled() {
+  static const bool on = !(getenv("VFX_RBA_W64") && atoi(getenv("VFX_RBA_W64")) == 0);
+  return on;
+}
+
+void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
+  VFX_CHECK(hp.asrc && hp.hionly && hp.C == 256 && hp.xa && hp.tile_m == 128 && hp.patch_rows == W64_PR,
+            "resblock_w64: needs the 16-bit mode, C = 256, 128-position tiles planned with %d patch rows", W64_PR);
+  const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
+  VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock_w64: bad grid");
+  // 4 chunk buffers of 160 rows = 80 KB (h: 64 KB and the staged pass: 66 KB overlay them): exactly two blocks per CU
+  const size_t lds = (size_t)(256 / 64) * W64_PR * CROW;
+  static_assert((256 / 64) * W64_PR * CROW >= 128 * (128 + 4) * 4 && (256 / 64) * W64_PR * CROW >= 128 * 256 * 2, "overlays must fit");
+  static uint64_t attr_devices = 0;
+  if (first_use_on_current_device(attr_devices)) {
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_w64<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL((k_resblock_w64<256>), dim3((int)grid), dim3(256), lds, stream, dparams);
+  VFX_HIP(hipGetLastError());
+}
+
+}  // namespace vfx

@@ -200,8 +200,6 @@ struct ResBlockParams {
   const float* w2b;
   const float* b1b;
   const float* b2b;
-  int rl;           // set by plan_resblock: the register-loaded-patch kernel runs this layer (resblock_rl.hip: 16-bit mode, C = 128;
-                    // weights: pack_conv mode 3)
   int rw;           // set by plan_resblock: the persistent register-weights kernel runs this layer (resblock_rw.hip: 16-bit mode, C = 64)
   const float* xa;
   float* ya;
@@ -218,19 +216,18 @@ struct ResBlockParams {
   // (block ids 256 .. 511 of a launch) sleep n x 127 x 64 cycles first, so that the two co-resident blocks of a CU do not run
   // their memory and arithmetic phases in step.
   int stagger;
+  int patch_rows;    // set by plan_resblock: rows of a patch buffer when they are not tile_m + 64 (resblock_w64.hip: 160)
 };
 bool resblock_supported(int C);
 int resblock_block_waves(const ResBlockParams& hp);
 bool resblock_act_supported(int C);
 int resblock_act_tile();
 void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
-// resblock_pc.hip: the same layer as a persistent producer / consumer kernel (one block per CU walks a range of tiles)
-bool resblock_pc_enabled();
-void launch_resblock_pc(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 // resblock_rw.hip: C = 64, 16-bit mode -- persistent blocks, weights in registers, next patch prefetched into registers
-// resblock_rl.hip: C = 128, 16-bit mode -- the whole patch through registers in one round trip, x read once
-bool resblock_rl_enabled();
-void launch_resblock_rl(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
+// resblock_w64.hip: the wide layer (C = 256, 16-bit mode) as 4-wave blocks of 64-cout waves, two blocks per CU
+bool resblock_w64_enabled();
+int resblock_w64_patch_rows();
+void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 int resblock_rw_tile();
 bool resblock_rw_pair_ok(int C, int dil, int dil2);  // this pair of consecutive layers can run as one launch
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);

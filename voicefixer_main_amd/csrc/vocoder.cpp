@@ -117,9 +117,7 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
       snprintf(a, sizeof(a), "generator.%d.res_layers.%d.1", idx + 1, i);
       snprintf(b, sizeof(b), "generator.%d.res_layers.%d.3", idx + 1, i);
       // unfused layers read the activated trunk / the activated h; the fused kernel transforms raw patches itself
-      // (16-bit mode, C = 128: the fused kernel of resblock_rl.hip builds 64-channel fp16 rows itself -- the fragment order of
-      // an activated source)
-      const bool act = !stack_fused(cfg, c) || (cfg.precision == 2 && c == 128 && resblock_rl_enabled());
+      const bool act = !stack_fused(cfg, c);
       stack.push_back({load_conv1d(h, a, c, c, 3, act), load_conv1d(h, b, c, c, 3, act)});
     }
     W->res.push_back(stack);
@@ -314,7 +312,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.dil = dil;
         rp.hionly = cfg.precision == 2;
         VFX_CHECK(layer.first.mode == layer.second.mode &&
-                      layer.first.mode == (rp.hionly && up.cout == 128 && resblock_rl_enabled() ? 3 : pack_mode(cfg, false)),
+                      layer.first.mode == pack_mode(cfg, false),
                   "vocoder plan: the weights of a fused %d-channel layer are packed for another kernel", up.cout);
         // 16-bit mode, C = 64: two layers of small dilation as one launch -- the tensor between them is never stored
         if (rp.hionly && li + 1 < nlayers && resblock_rw_tile() != 0 && resblock_rw_pair_ok(up.cout, dil, dil * cfg.voc_dilation_base)) {
