@@ -45,6 +45,19 @@ enum {
                                   Exceed energy limit" there (eval_gsr_voicefixer.py:68-70); informational */
 };
 
+/* vfx_config.tuning: kernel-selection switches for A/B measurements and bisecting (0 = the shipped configuration; every
+ * bit selects an older / simpler form of the same arithmetic, results stay within the mode's tolerances).  Read when a
+ * plan is built; vfx_create reports a non-zero mask on stderr.  Every bit is exercised by the GPU test suite. */
+enum {
+  VFX_TUNE_NO_FUSED_STACKS = 1,    /* vocoder ResStack layers (C = 64, 128) as two tap-convolution launches per layer */
+  VFX_TUNE_NO_FUSED_WIDE = 2,      /* ... the C = 256 layers of the 16-bit mode as two launches per layer */
+  VFX_TUNE_NO_FUSED_UNET = 4,      /* identity-shortcut ConvBlockRes of the ResUNets (C = 32, 64) as two launches */
+  VFX_TUNE_NO_PERSISTENT_C64 = 8,  /* 16-bit mode, C = 64 layers on k_resblock instead of the persistent kernel */
+  VFX_TUNE_NO_PAIRS = 16,          /* 16-bit mode, C = 64: one launch per layer (no layer pairs) */
+  VFX_TUNE_NO_SPLITK = 32,         /* no split-K in the deep ResUNet levels */
+  VFX_TUNE_WIDE_8WAVE = 64         /* C = 256 layers on the 8-wave / one-block-per-CU kernel (resblock_act.hip) */
+};
+
 typedef struct vfx_config {
   /* front-end: config/vctk_base_voicefixer_unet.json:68-78 */
   int sample_rate;  /* 44100 */
@@ -75,6 +88,7 @@ typedef struct vfx_config {
    *     saturating conversion).  BASELINE.json's 16-bit operand mode for config 2; fp16 rather
    *     than bf16 because bf16 operands hold the waveform to 40 dB SI-SDR only. */
   int precision;
+  int tuning;  /* mask of VFX_TUNE_*; 0 = default */
 } vfx_config;
 
 /* Fill *cfg with the reference's hyper-parameters. */

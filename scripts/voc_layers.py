@@ -3,7 +3,7 @@
 library named by VFX_LIB_PATH / the VFX_* switches of the environment, HIP events around every GEMM-shaped launch
 (VFX_PROFILE_DUMP), and prints one line per (kernel, dilation): median / min ms over the repeats, plus the per-stack sums.
 
-    [VFX_...=...] python scripts/voc_layers.py TAG [--reps=5] [--precision=2] [--json=out.jsonl]
+    [VFX_LIB_PATH=...] python scripts/voc_layers.py TAG [--reps=5] [--precision=2] [--tuning=MASK] [--json=out.jsonl]
 """
 import collections
 import csv
@@ -27,7 +27,7 @@ def opt(name, default):
 def main():
     tag = ([a for a in sys.argv[1:] if not a.startswith("--")] or ["run"])[0]
     reps, precision = int(opt("reps", "5")), int(opt("precision", "2"))
-    eng = Engine("cuda:0", config={"precision": precision})
+    eng = Engine("cuda:0", config={"precision": precision, "tuning": int(opt("tuning", "0"), 0)})
     eng.load_state_dict(MODEL_VOCODER, synth.make_vocoder_state_dict(1))
     g = torch.Generator(device="cuda").manual_seed(1)
     mel = torch.rand(16, 1001, 128, device="cuda", generator=g) * 0.1

@@ -109,8 +109,6 @@ def test_resblock_layer_pair(engine, T):
     than every halo.  The tensor between the layers exists only inside the kernel."""
     if engine.tol['name'] != 'fp16-vocoder':
         pytest.skip("layer pairs exist in the 16-bit mode only")
-    if os.environ.get("VFX_RB_PAIR") == "0" or os.environ.get("VFX_RB_RW") == "0" or os.environ.get("VFX_RB_RW_MT") == "128":
-        pytest.skip("layer pairs are switched off in this A/B run")
     B, C = 3, 64
     x = _rand((B, C, T), 51)
     la = (_rand((C, C, 3), 52, 0.08), _rand((C,), 53, 0.1), _rand((C, C, 3), 54, 0.08), _rand((C,), 55, 0.1))

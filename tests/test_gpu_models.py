@@ -233,3 +233,44 @@ def test_fp16_vocoder_dynamic_range_flag_and_rerun(unet_sd, voc_sd):
     with open("gpurun_out/fp16_robustness.json", "w") as f:
         json.dump({k: float(v) for k, v in res.items()}, f, indent=1)
     print(res)
+
+
+# vfx_config.tuning (include/vfx.h): every kernel-selection switch of the product path, exercised in process.  Each bit
+# replaces one kernel family by an older / simpler form of the same arithmetic; the results must stay within the mode's bars.
+TUNING = [("NO_FUSED_STACKS", 1, 2), ("NO_FUSED_WIDE", 2, 2), ("NO_FUSED_UNET", 4, 1), ("NO_PERSISTENT_C64", 8, 2),
+          ("NO_PAIRS", 16, 2), ("NO_SPLITK", 32, 1), ("WIDE_8WAVE", 64, 2), ("NO_FUSED_STACKS", 1, 1)]
+
+
+@pytest.mark.parametrize("name,bit,precision", TUNING, ids=["%s-p%d" % (n, p) for n, _, p in TUNING])
+def test_tuning_switches(name, bit, precision, unet_sd, voc_sd, capfd):
+    """One Engine per switch: the whole restore path (mel ResUNet + vocoder at 3 x 1.5 s: T' = 7350 at C = 256, 66 150 at
+    C = 64 -- several tiles per block, folded dilations) and a single wide / C = 64 / C = 128 layer against the oracle, and
+    vfx_create's announcement of the non-default selection."""
+    from oracle import pipeline
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_VOCODER
+    from conftest import TOL
+    tol = TOL[precision]
+    eng = Engine("cuda:0", config={"precision": precision, "tuning": bit})
+    assert "VFX_TUNE_" + name in capfd.readouterr().err
+    eng.load_state_dict(MODEL_UNET_MEL, unet_sd)
+    eng.load_state_dict(MODEL_VOCODER, voc_sd)
+    wav = synth.make_clips(3, 1.5, seed=77)
+    ref = _tuning_oracle()
+    out, logmel = eng.restore_gsr(torch.from_numpy(wav[:, 0]), want_logmel=True)
+    d = np.abs(logmel.cpu().numpy() - ref["logmel"][:, 0])
+    assert d.mean() < tol["logmel_l1"] and d.max() < tol["logmel_max"], (d.mean(), d.max())
+    assert _sisdr(out.cpu().numpy(), ref["wav"][:, 0]) > tol["sisdr"]
+    assert eng.take_flags() == 0
+
+
+_TUNING_REF = {}
+
+
+def _tuning_oracle():
+    if not _TUNING_REF:
+        from oracle import pipeline
+        from voicefixer_main_amd import synth
+        _TUNING_REF.update(pipeline.restore_gsr(synth.make_resunet_state_dict(0), synth.make_vocoder_state_dict(1),
+                                                synth.make_clips(3, 1.5, seed=77)))
+    return _TUNING_REF

@@ -14,6 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 
 VFX_MAX_STAGES = 8
 MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER, MODEL_FRONTEND = 0, 1, 2, 3
+# vfx_config.tuning bits (include/vfx.h)
+TUNE_NO_FUSED_STACKS, TUNE_NO_FUSED_WIDE, TUNE_NO_FUSED_UNET, TUNE_NO_PERSISTENT_C64, TUNE_NO_PAIRS, TUNE_NO_SPLITK, \
+    TUNE_WIDE_8WAVE = 1, 2, 4, 8, 16, 32, 64
 FLAG_NEGATIVE_INPUT = 1
 FLAG_F16_SATURATED = 2   # precision 2: an activation of the vocoder left the fp16 range and was clamped
 FLAG_PEAK_NORMALISED = 4  # vfx_restore_gsr divided a clip by its peak (the reference's "Exceed energy limit" warning)
@@ -26,7 +29,7 @@ class VfxConfig(ctypes.Structure):
         ("voc_n_stages", c_int), ("voc_scales", c_int * VFX_MAX_STAGES), ("voc_depth", c_int * VFX_MAX_STAGES),
         ("voc_dilation_base", c_int), ("voc_min_db", c_float), ("voc_amp_floor", c_float),
         ("voc_norm_range", c_float), ("voc_up_slope", c_float), ("voc_res_slope", c_float),
-        ("precision", c_int),
+        ("precision", c_int), ("tuning", c_int),
     ]
 
 

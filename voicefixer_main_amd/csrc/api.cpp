@@ -483,6 +483,7 @@ static double resblock_design_bytes(const ResBlockParams& q) {
 
 void PlanBuilder::add_conv(TapConvParams p) {
   p.split = h->cfg.precision != 0;
+  p.tuning = h->cfg.tuning;
   finish_params(p);
   p.ksplit = choose_ksplit(p);
   size_t ws_off = ~size_t(0);
@@ -549,6 +550,7 @@ void PlanBuilder::add_conv_phased(TapConvParams p, const std::vector<TapSeg>& ph
 }
 
 void PlanBuilder::add_resblock(ResBlockParams p) {
+  p.tuning = h->cfg.tuning;
   if (p.geo2d) plan_block2d(p);
   else plan_resblock(p);
   const size_t idx = plan->host_rb.size();
@@ -795,6 +797,16 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   h->device = device;
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
   VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
+  VFX_CHECK((h->cfg.tuning & ~127) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
+  if (h->cfg.tuning) {  // never silent: a non-default kernel selection is announced
+    static const char* names[] = {"NO_FUSED_STACKS", "NO_FUSED_WIDE", "NO_FUSED_UNET", "NO_PERSISTENT_C64", "NO_PAIRS", "NO_SPLITK",
+                                  "WIDE_8WAVE"};
+    std::string msg;
+    for (int b = 0; b < 7; ++b)
+      if (h->cfg.tuning & (1 << b)) msg += std::string(msg.empty() ? "" : " | ") + "VFX_TUNE_" + names[b];
+    fprintf(stderr, "[libvfx] handle on device %d uses non-default kernel selection: tuning = 0x%x (%s)\n", device, h->cfg.tuning,
+            msg.c_str());
+  }
   init_front_end(h.get());
   {
     std::vector<float> ones(kIdentityLen, 1.f), zeros(kIdentityLen, 0.f);

@@ -567,7 +567,7 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
 // is restored in.  Parallelism of a clip = spatial tiles x 32-cout blocks; below ~128 the launch is cut into up to 8
 // stage ranges of at least 3 stages (27 taps of a 3x3 convolution) each.
 int choose_ksplit(const TapConvParams& p) {
-  if (p.hionly || p.nphase > 1 || p.per_tap || getenv("VFX_NO_SPLITK")) return 1;
+  if (p.hionly || p.nphase > 1 || p.per_tap || (p.tuning & VFX_TUNE_NO_SPLITK)) return 1;
   // the reduce pass rewrites the whole output tensor: only launches that own all of it (not the parity classes of a
   // transposed convolution, whose launches interleave their pixels)
   if (p.sh != 1 || p.sw != 1 || p.oh0 != 0 || p.ow0 != 0 || p.Hg != p.Ho || p.Wg != p.Wo) return 1;

@@ -24,6 +24,7 @@ void run_one(vfx_handle* h, TapConvParams& p, DeviceBlob& blob, hipStream_t s) {
   p.split = h->cfg.precision != 0;
   p.hionly = h->cfg.precision == 2;
   p.flags = h->d_flags;
+  p.tuning = h->cfg.tuning;
   finish_params(p);
   std::vector<ConvStage> st(p.nstages);
   build_stages(p, h->d_ones, h->d_zeros, st.data());
@@ -133,6 +134,7 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       float* dya = static_cast<float*>(sc.blob.alloc(ha.size() * sizeof(_Float16)));
       ResBlockParams rp{};
       rp.asrc = 1;
+      rp.tuning = h->cfg.tuning;
       rp.tile_m = resblock_act_tile();
       rp.x = x;
       rp.xa = static_cast<const float*>(dxa);
@@ -169,6 +171,7 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       rp.T = T;
       rp.C = C;
       rp.hionly = h->cfg.precision == 2;
+      rp.tuning = h->cfg.tuning;
       rp.flags = h->d_flags;
       rp.dil = dil;
       float* dya = nullptr;
@@ -255,7 +258,7 @@ extern "C" int vfx_op_resblock_pair(vfx_handle* h, const float* x, int B, int T,
   try {
     VFX_CHECK(h && x && y && wa1 && ba1 && wa2 && ba2 && wb1 && bb1 && wb2 && bb2 && B > 0 && T > 0, "bad argument");
     DeviceGuard device_guard_(h->device);
-    VFX_CHECK(h->cfg.precision == 2 && resblock_rw_pair_ok(C, dil, dil2), "vfx_op_resblock_pair: needs the 16-bit mode, C = 64 and small dilations");
+    VFX_CHECK(h->cfg.precision == 2 && resblock_rw_pair_ok(C, dil, dil2, h->cfg.tuning), "vfx_op_resblock_pair: needs the 16-bit mode, C = 64 and small dilations");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scratch sc;
     std::vector<std::pair<int, int>> taps = {{0, 0}, {0, 1}, {0, 2}};

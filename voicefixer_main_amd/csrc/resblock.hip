@@ -86,8 +86,6 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
 
   const ResBlockParams& p = *pp;
   const int tid = threadIdx.x;
-  if (p.stagger > 0 && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   int tile;
   {
     const int nwg = gridDim.x, b = blockIdx.x;
@@ -524,9 +522,7 @@ static size_t resblock_lds_bytes(int C) {
 
 template <int C, int NW, bool HI, bool G2 = false>
 static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
-  // VFX_RB_LDS_PAD (bytes): occupancy experiments -- extra LDS per block lowers the blocks per CU
-  static const size_t pad = getenv("VFX_RB_LDS_PAD") ? (size_t)atoi(getenv("VFX_RB_LDS_PAD")) : 0;
-  const size_t lds = resblock_lds_bytes(C) + pad;
+  const size_t lds = resblock_lds_bytes(C);
   static uint64_t attr_devices = 0;  // one static per instantiation
   if (first_use_on_current_device(attr_devices)) {
     VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI, G2>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -539,10 +535,9 @@ bool resblock_supported(int C) { return C == 64 || C == 128; }
 
 // Waves per block of the kernel that runs this (planned) layer: the second template argument in the kernel tables
 int resblock_block_waves(const ResBlockParams& hp) {
-  static const bool four32 = getenv("VFX_RB_NW32") && atoi(getenv("VFX_RB_NW32")) == 4;
   if (hp.rw) return hp.tile_m / 32;
   if (hp.asrc && hp.patch_rows) return 4;
-  if (hp.geo2d) return hp.C == 32 && !four32 ? 2 : 4;
+  if (hp.geo2d) return hp.C == 32 ? 2 : 4;
   return hp.C >= 128 ? 8 : 4;
 }
 bool block2d_supported(int C) { return C == 32 || C == 64; }
@@ -584,21 +579,19 @@ void plan_block2d(ResBlockParams& p) {
 void plan_resblock(ResBlockParams& p) {
   VFX_CHECK(p.asrc ? resblock_act_supported(p.C) : resblock_supported(p.C), "resblock: C=%d is not supported", p.C);
   const int d = p.dil;
-  static const int stagger = getenv("VFX_RB_STAGGER") ? atoi(getenv("VFX_RB_STAGGER")) : 0;
-  p.stagger = stagger;
   // 16-bit mode, C = 64: the persistent register-weights kernel (resblock_rw.hip) with its own tile size
-  p.rw = (!p.asrc && p.hionly && p.C == 64 && resblock_rw_tile() != 0) ? 1 : 0;
-  if (p.rw) p.tile_m = resblock_rw_tile();
+  p.rw = (!p.asrc && p.hionly && p.C == 64 && resblock_rw_tile(p.tuning) != 0) ? 1 : 0;
+  if (p.rw) p.tile_m = resblock_rw_tile(p.tuning);
   const int MT = p.tile_m ? p.tile_m : CBM;  // h positions per tile (resblock_act: 64 or 128; resblock_rw: 128 or 256)
   // patch rows per buffer: MT + 64 (= kPatchMaxRows for MT = 128); the 4-wave form of the wide layer keeps four chunk
   // buffers in half a CU's LDS: 160 rows (resblock_w64.hip)
-  p.patch_rows = (p.asrc && MT == 128 && p.dil2 == 0 && resblock_w64_enabled()) ? resblock_w64_patch_rows() : 0;
+  p.patch_rows = (p.asrc && MT == 128 && p.dil2 == 0 && resblock_w64_enabled(p.tuning)) ? resblock_w64_patch_rows() : 0;
   const int PR = p.patch_rows ? p.patch_rows : MT + 64;
   VFX_CHECK(MT == 64 || MT == 128 || (MT == 256 && p.rw), "resblock: tile of %d positions", MT);
   p.tile_m = MT;
   if (p.dil2 > 0) {
     // layer pair: both layers over the MT-index space of the tile, MT - 4 - 2 dil2 outputs per tile (resblock_rw.hip)
-    VFX_CHECK(p.rw && resblock_rw_pair_ok(p.C, d, p.dil2), "resblock: layers of dilation %d, %d cannot run as a pair", d, p.dil2);
+    VFX_CHECK(p.rw && resblock_rw_pair_ok(p.C, d, p.dil2, p.tuning), "resblock: layers of dilation %d, %d cannot run as a pair", d, p.dil2);
     p.fold = 0;
     p.TH = 1;
     p.W1 = MT;
@@ -652,10 +645,9 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock: bad grid");
   if (hp.geo2d) {
     VFX_CHECK(!hp.hionly, "block2d: split-bf16 only");
-    // C = 32: two waves of 64 pixels (VFX_RB_NW32=4: four of 32) -- every wave of a block fetches ALL the weight fragments,
-    // so fewer, larger waves halve that traffic (the timing-only build without weight refreshes ran this block 25 % faster)
-    if (hp.C == 32 && resblock_block_waves(hp) == 2) launch_rb<32, 2, false, true>((int)grid, stream, dparams);
-    else if (hp.C == 32) launch_rb<32, 4, false, true>((int)grid, stream, dparams);
+    // C = 32: two waves of 64 pixels, not four of 32 -- every wave of a block fetches ALL the weight fragments, so fewer,
+    // larger waves halve that traffic (measured -12 %; the timing-only build without weight refreshes ran this block 25 % faster)
+    if (hp.C == 32) launch_rb<32, 2, false, true>((int)grid, stream, dparams);
     else launch_rb<64, 4, false, true>((int)grid, stream, dparams);
     VFX_HIP(hipGetLastError());
     return;

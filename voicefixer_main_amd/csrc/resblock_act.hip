@@ -85,8 +85,6 @@ __global__ __launch_bounds__(NW * 64, MT == 128 ? 2 : 4) void k_resblock_act(con
 
   const ResBlockParams& p = *pp;
   const int tid = threadIdx.x;
-  if (p.stagger > 0 && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   int tile;
   {
     const int nwg = gridDim.x, b = blockIdx.x;
@@ -402,12 +400,9 @@ static size_t resblock_act_lds_bytes(int C, int MT) {
 
 bool resblock_act_supported(int C) { return C == 256; }
 
-// h positions per tile of the fused wide layer: 128; VFX_RBA_MT=64 = two blocks per CU (measured 11 % slower: the co-resident
-// blocks run their phases in step, and a 64-position tile re-fetches more halo and more weights per result)
-int resblock_act_tile() {
-  static const int mt = (getenv("VFX_RBA_MT") && atoi(getenv("VFX_RBA_MT")) == 64) ? 64 : 128;
-  return mt;
-}
+// h positions per tile of the fused wide layer.  (A 64-position form with two blocks per CU was 34 % slower in round 3 --
+// twice the weight traffic per result, a register budget that spilled -- and is gone; resblock_w64.hip is the two-block form.)
+int resblock_act_tile() { return 128; }
 
 template <int MT>
 static void launch_rba(int grid, hipStream_t stream, const ResBlockParams* dparams) {
@@ -422,12 +417,11 @@ static void launch_rba(int grid, hipStream_t stream, const ResBlockParams* dpara
 
 void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   VFX_CHECK(hp.asrc && hp.hionly && resblock_act_supported(hp.C) && hp.xa, "resblock_act: needs the 16-bit mode, C = 256 and the activated trunk");
-  VFX_CHECK(hp.tile_m == 64 || hp.tile_m == 128, "resblock_act: tile of %d positions", hp.tile_m);
+  VFX_CHECK(hp.tile_m == 128, "resblock_act: tile of %d positions", hp.tile_m);
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock_act: bad grid");
   if (hp.tile_m == 128 && hp.patch_rows) return launch_resblock_w64(hp, dparams, stream);
-  if (hp.tile_m == 64) launch_rba<64>((int)grid, stream, dparams);
-  else launch_rba<128>((int)grid, stream, dparams);
+  launch_rba<128>((int)grid, stream, dparams);
   VFX_HIP(hipGetLastError());
 }
 

@@ -390,20 +390,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   }
 }
 
-// h positions per tile of the register-weights kernel: 256 (default), 128 (VFX_RB_RW_MT=128), 0 = off (VFX_RB_RW=0: k_resblock)
-int resblock_rw_tile() {
-  static const int mt = [] {
-    if (getenv("VFX_RB_RW") && atoi(getenv("VFX_RB_RW")) == 0) return 0;
-    return (getenv("VFX_RB_RW_MT") && atoi(getenv("VFX_RB_RW_MT")) == 128) ? 128 : 256;
-  }();
-  return mt;
-}
+// h positions per tile of the register-weights kernel: 256; 0 = off (VFX_TUNE_NO_PERSISTENT_C64: k_resblock runs the layer)
+int resblock_rw_tile(int tuning) { return (tuning & VFX_TUNE_NO_PERSISTENT_C64) ? 0 : 256; }
 
 // Two consecutive layers as one launch: 256-position tiles, the first layer's patch must fit (d <= 32) and a tile must still
-// advance by at least half of its positions (d2 <= 62).  VFX_RB_PAIR=0: one launch per layer.
-bool resblock_rw_pair_ok(int C, int dil, int dil2) {
-  static const bool on = !(getenv("VFX_RB_PAIR") && atoi(getenv("VFX_RB_PAIR")) == 0);
-  return on && C == 64 && resblock_rw_tile() == 256 && dil >= 1 && dil <= 32 && dil2 >= 1 && 256 - 4 - 2 * dil2 >= 128;
+// advance by at least half of its positions (d2 <= 62).  VFX_TUNE_NO_PAIRS: one launch per layer.
+bool resblock_rw_pair_ok(int C, int dil, int dil2, int tuning) {
+  return !(tuning & VFX_TUNE_NO_PAIRS) && C == 64 && resblock_rw_tile(tuning) == 256 && dil >= 1 && dil <= 32 && dil2 >= 1 &&
+         256 - 4 - 2 * dil2 >= 128;
 }
 
 int cu_count_of_current_device() {

@@ -368,11 +368,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
 
 int resblock_w64_patch_rows() { return W64_PR; }
 
-// The four-wave form runs the wide layers by default; VFX_RBA_W64=0 selects the 8-wave / one-block-per-CU kernel (A/B runs).
-bool resblock_w64_enabled() {
-  static const bool on = !(getenv("VFX_RBA_W64") && atoi(getenv("VFX_RBA_W64")) == 0);
-  return on;
-}
+// The four-wave form runs the wide layers by default; VFX_TUNE_WIDE_8WAVE selects the 8-wave / one-block-per-CU kernel.
+bool resblock_w64_enabled(int tuning) { return !(tuning & VFX_TUNE_WIDE_8WAVE); }
 
 void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   VFX_CHECK(hp.asrc && hp.hionly && hp.C == 256 && hp.xa && hp.tile_m == 128 && hp.patch_rows == W64_PR,

@@ -211,8 +211,8 @@ struct TrunkBuilder {
                   const Act4* pre_sc = nullptr) {
     const Act4& g = srcs ? srcs[0] : *pre_h;
     // Identity-shortcut blocks of the C = 32 / 64 levels run as ONE launch of k_resblock's 2-D mode: h stays in LDS, 402
-    // instead of 872 HBM bytes per output pixel (VFX_FUSE_UNET=0: the two-launch form, for A/B runs).
-    static const bool fuse2d = !(getenv("VFX_FUSE_UNET") && atoi(getenv("VFX_FUSE_UNET")) == 0);
+    // instead of 872 HBM bytes per output pixel (VFX_TUNE_NO_FUSED_UNET: the two-launch form).
+    const bool fuse2d = !(pb.h->cfg.tuning & VFX_TUNE_NO_FUSED_UNET);
     if (fuse2d && srcs && nsrc == 1 && !w.shortcut && !pre_h && block2d_supported(w.cout) && pb.h->cfg.precision != 0) {
       Act4 y = make(g.H, g.W, w.cout);
       ResBlockParams rp{};

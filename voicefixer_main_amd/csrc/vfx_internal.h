@@ -168,6 +168,7 @@ struct TapConvParams {
   // results do not depend on how clips are batched.
   int ksplit;
   float* ws;
+  int tuning;            // vfx_config.tuning of the handle (choose_ksplit)
 };
 
 // One fused TFGAN ResStack layer (resblock.hip): y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2.
@@ -212,11 +213,8 @@ struct ResBlockParams {
   const float* sh2;
   int poff9[9];      // conv1: patch row offset of tap (dy, dx)
   int hoff9[9];      // conv2: h row offset of tap (dy, dx)
-  // Start-up stagger (experiment switch VFX_RB_STAGGER=n, plan_resblock): the blocks of the second residency slot of every CU
-  // (block ids 256 .. 511 of a launch) sleep n x 127 x 64 cycles first, so that the two co-resident blocks of a CU do not run
-  // their memory and arithmetic phases in step.
-  int stagger;
   int patch_rows;    // set by plan_resblock: rows of a patch buffer when they are not tile_m + 64 (resblock_w64.hip: 160)
+  int tuning;        // vfx_config.tuning of the handle: which kernel family runs the layer (plan_resblock)
 };
 bool resblock_supported(int C);
 int resblock_block_waves(const ResBlockParams& hp);
@@ -225,11 +223,11 @@ int resblock_act_tile();
 void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 // resblock_rw.hip: C = 64, 16-bit mode -- persistent blocks, weights in registers, next patch prefetched into registers
 // resblock_w64.hip: the wide layer (C = 256, 16-bit mode) as 4-wave blocks of 64-cout waves, two blocks per CU
-bool resblock_w64_enabled();
+bool resblock_w64_enabled(int tuning);
 int resblock_w64_patch_rows();
 void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
-int resblock_rw_tile();
-bool resblock_rw_pair_ok(int C, int dil, int dil2);  // this pair of consecutive layers can run as one launch
+int resblock_rw_tile(int tuning);
+bool resblock_rw_pair_ok(int C, int dil, int dil2, int tuning);  // this pair of consecutive layers can run as one launch
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 // compute units of the current device (cached per device): grid size of the persistent kernels
 int cu_count_of_current_device();

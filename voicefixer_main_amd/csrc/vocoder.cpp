@@ -38,9 +38,9 @@ int pack_mode(const vfx_config& cfg, bool src_act) {
 }
 
 // HBM-bound stacks (C = 64, 128) run each layer as ONE fused launch on the raw trunk (resblock.hip); the wide stacks
-// run two launches per layer on a trunk kept in both forms.  `VFX_NO_FUSE` forces the latter (A/B runs).
+// run two launches per layer on a trunk kept in both forms.  VFX_TUNE_NO_FUSED_STACKS forces the latter.
 bool stack_fused(const vfx_config& cfg, int channels) {
-  return cfg.precision != 0 && resblock_supported(channels) && !getenv("VFX_NO_FUSE");
+  return cfg.precision != 0 && resblock_supported(channels) && !(cfg.tuning & VFX_TUNE_NO_FUSED_STACKS);
 }
 
 // Conv1d weight (Cout, Cin, K) -> packed with taps k = 0..K-1
@@ -233,8 +233,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     const VocConvW& up = W->up[st];
     const int Tout = Tlen * s;
     const bool fuse = stack_fused(cfg, up.cout);
-    // 16-bit mode, C = 256: fused as well, on the two-form trunk (resblock_act.hip); `VFX_NO_FUSE_ACT`: two launches
-    const bool fuse_act = !fuse && cfg.precision == 2 && resblock_act_supported(up.cout) && !getenv("VFX_NO_FUSE_ACT");
+    // 16-bit mode, C = 256: fused as well, on the two-form trunk (resblock_w64.hip); VFX_TUNE_NO_FUSED_WIDE: two launches
+    const bool fuse_act = !fuse && cfg.precision == 2 && resblock_act_supported(up.cout) && !(cfg.tuning & VFX_TUNE_NO_FUSED_WIDE);
     const bool last_stage = st + 1 == cfg.voc_n_stages;
     Forms y;
     y.raw = pb.alloc_f((int64_t)B * Tout * up.cout);
@@ -311,11 +311,12 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.C = up.cout;
         rp.dil = dil;
         rp.hionly = cfg.precision == 2;
+        rp.tuning = cfg.tuning;
         VFX_CHECK(layer.first.mode == layer.second.mode &&
                       layer.first.mode == pack_mode(cfg, false),
                   "vocoder plan: the weights of a fused %d-channel layer are packed for another kernel", up.cout);
         // 16-bit mode, C = 64: two layers of small dilation as one launch -- the tensor between them is never stored
-        if (rp.hionly && li + 1 < nlayers && resblock_rw_tile() != 0 && resblock_rw_pair_ok(up.cout, dil, dil * cfg.voc_dilation_base)) {
+        if (rp.hionly && li + 1 < nlayers && resblock_rw_pair_ok(up.cout, dil, dil * cfg.voc_dilation_base, cfg.tuning)) {
           auto& next = W->res[st][li + 1];
           dil *= cfg.voc_dilation_base;
           ++li;
@@ -347,6 +348,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         VFX_CHECK(layer.first.mode == 3 && layer.second.mode == 3, "vocoder plan: the fused wide layer needs fp16 64-channel weights");
         ResBlockParams rp{};
         rp.asrc = 1;
+        rp.tuning = cfg.tuning;
         rp.tile_m = resblock_act_tile();
         rp.x = rel_ptr(cur.raw);
         rp.xa = rel_ptr(cur.act);
