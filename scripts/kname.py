@@ -4,6 +4,7 @@ k_conv<BN, ELU, SPLIT, ABL, RING, HI>  ->  "k_conv<BN, ELU, SPLIT>" (+ " f16" fo
 k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
 k_resblock_act<C, NW, MT>              ->  "k_resblock<C, NW> f16"
 k_resblock_w64<C>                      ->  "k_resblock<C, 4> f16"
+k_resblock_r128                        ->  "k_resblock<128, 4> f16"
 k_resblock_rw<NW, PAIR>                ->  "k_resblock<64, NW> f16" / "k_resblock_pair<64, NW> f16"
 """
 import re
@@ -21,6 +22,8 @@ def short(n, width=40):
         return "k_resblock<%s, %s> f16" % (args[0], args[1])
     if name == "k_resblock_w64" and args:                # the same layer as 4-wave blocks, two per CU
         return "k_resblock<%s, 4> f16" % args[0]
+    if name == "k_resblock_r128":                        # C = 128, 16-bit mode: 4-wave blocks, x read once
+        return "k_resblock<128, 4> f16"
     if name == "k_resblock_rw" and args:                 # C = 64, 16-bit mode: persistent, weights in registers
         if len(args) >= 2 and args[1] == "true":         # two layers per launch
             return "k_resblock_pair<64, %s> f16" % args[0]

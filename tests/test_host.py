@@ -221,7 +221,7 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
     # kernels that are allowed a few bytes of scratch: opt-in experiments and the opt-in 64-position form of the C = 256 layer
     # (and k_conv<64, ELU, split, ring 3>: 8 bytes since round 1, split-bf16 mode of the vocoder's ELU convolutions only)
     may_spill = ("k_resblock_actILi256ELi8ELi64E", "k_convILi64ELb1ELb1ELi0ELi3ELb0ELb0E")
-    for name in ("conv.hip", "resblock.hip", "resblock_act.hip", "resblock_w64.hip", "resblock_rw.hip", "stft.hip"):
+    for name in ("conv.hip", "resblock.hip", "resblock_act.hip", "resblock_w64.hip", "resblock_r128.hip", "resblock_rw.hip", "stft.hip"):
         out = str(tmp_path / (name + ".s"))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                         "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, name)], check=True,
@@ -392,6 +392,7 @@ def test_profile_kernel_names():
     assert short(ns + "k_resblock_rw<4, false>(vfx::ResBlockParams const*, int, int)") == "k_resblock<64, 4> f16"
     assert short(ns + "k_resblock_act<256, 8, 128>(vfx::ResBlockParams const*)") == "k_resblock<256, 8> f16"
     assert short(ns + "k_resblock_w64<256>(vfx::ResBlockParams const*)") == "k_resblock<256, 4> f16"
+    assert short(ns + "k_resblock_r128(vfx::ResBlockParams const*)") == "k_resblock<128, 4> f16"
     assert short(ns + "k_resblock<32, 2, false, true>(vfx::ResBlockParams const*)") == "k_resblock<32, 2>"
     assert short(ns + "k_resblock<128, 8, true, false>(vfx::ResBlockParams const*)") == "k_resblock<128, 8> f16"
     assert short(ns + "k_stft_mel<false>(float const*, int)") == "k_stft_mel<false>"

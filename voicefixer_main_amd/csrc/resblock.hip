@@ -536,7 +536,7 @@ bool resblock_supported(int C) { return C == 64 || C == 128; }
 // Waves per block of the kernel that runs this (planned) layer: the second template argument in the kernel tables
 int resblock_block_waves(const ResBlockParams& hp) {
   if (hp.rw) return hp.tile_m / 32;
-  if (hp.asrc && hp.patch_rows) return 4;
+  if ((hp.asrc && hp.patch_rows) || hp.r128) return 4;
   if (hp.geo2d) return hp.C == 32 ? 2 : 4;
   return hp.C >= 128 ? 8 : 4;
 }
@@ -586,6 +586,8 @@ void plan_resblock(ResBlockParams& p) {
   // patch rows per buffer: MT + 64 (= kPatchMaxRows for MT = 128); the 4-wave form of the wide layer keeps four chunk
   // buffers in half a CU's LDS: 160 rows (resblock_w64.hip)
   p.patch_rows = (p.asrc && MT == 128 && p.dil2 == 0 && resblock_w64_enabled(p.tuning)) ? resblock_w64_patch_rows() : 0;
+  p.r128 = (!p.asrc && !p.rw && p.hionly && p.C == 128 && MT == 128 && p.dil2 == 0 && resblock_r128_enabled(p.tuning)) ? 1 : 0;
+  if (p.r128) p.patch_rows = resblock_r128_patch_rows();
   const int PR = p.patch_rows ? p.patch_rows : MT + 64;
   VFX_CHECK(MT == 64 || MT == 128 || (MT == 256 && p.rw), "resblock: tile of %d positions", MT);
   p.tile_m = MT;
@@ -616,7 +618,10 @@ void plan_resblock(ResBlockParams& p) {
     p.fold = 1;
     // tile width: the widest (<= 16) that cuts a row of d samples into equal parts -- d = 81 as 6 x 16 wastes 15 of 96 columns
     // (the d = 81 layers ran 15 % longer than the other folded ones), as 6 x 14 it wastes 3; the h tile is 16 x 16 instead of 14 x 18
-    const int TW = d >= 16 ? (d + (d + 15) / 16 - 1) / ((d + 15) / 16) : d;
+    // (160-row patches: 14-wide tiles at most -- the h tile is then 8 x 16 = all 128 positions; 16-wide tiles would be 6 x 18)
+    const int twmax = p.patch_rows ? 14 : 16;
+    const int nparts = (d + twmax - 1) / twmax;
+    const int TW = d >= twmax ? (d + nparts - 1) / nparts : d;
     p.W1 = TW + 2;
     const int rows = (p.T + d - 1) / d;
     const int th_max = std::min(MT / p.W1, PR / p.W1 - 2);
@@ -639,6 +644,10 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
   }
   if (hp.rw) {
     launch_resblock_rw(hp, dparams, stream);
+    return;
+  }
+  if (hp.r128) {
+    launch_resblock_r128(hp, dparams, stream);
     return;
   }
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;

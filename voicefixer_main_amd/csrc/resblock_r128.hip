@@ -1,0 +1,377 @@
+// resblock_r128.hip -- one fused TFGAN ResStack layer of the 16-bit mode at C = 128 (raw fp32 trunk, cf. resblock.hip)
+//
+//     y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2        conv1: k3, dilation d;  conv2: k3, dilation 1
+//
+// as FOUR-wave blocks, two per CU, that read x ONCE.
+//
+// Why (round-3 PMC, profiles/r03_*): k_resblock<128, 8> moves 3.6-3.7 GB per layer through the fabric for 2.42 GB of tensors
+// -- the epilogue's re-read of the residual finds its lines evicted (2.35-2.7 GB read for a 1.21 GB tensor) -- at ~4.1 TB/s:
+// the stack is bandwidth-bound on bytes it does not need.  Here every thread keeps the raw values of the tile's 128 centre rows
+// that it fetched for the patch (64 registers; a block is 4 waves = one per SIMD with 256 registers each) and adds them to the
+// staged conv2 result in LDS: the epilogue issues no load at all.  The rest follows resblock_w64.hip: the raw patch (4 chunks of
+// 32 channels x 160 rows x 128 B = 80 KB = half a CU's LDS, so two blocks share a CU and the memory phases of one run under the
+// arithmetic of the other) arrives in ONE LDS-DMA round trip and is turned into fp16 operand rows in place; a wave owns 32 couts x
+// all 128 positions (a weight fragment feeds four MFMAs and is fetched once per tile); the weight ring runs three taps ahead (a
+// tap is only 8 MFMAs here); the pixel fragments are software-pipelined one K step ahead; no scheduling barriers and no memory
+// clobbers in the compute phases.
+//
+// Tile geometry: plan_resblock with patch_rows = 160 (1-D tiles for d <= 16, folded rows of d samples with 14-wide tiles above).
+// Weights: pack_conv mode 2 (fp16 in the hi fragments of 32-channel chunks), the packing of k_resblock<128, 8, HI>.
+#include "conv_common.h"
+#include "vfx_internal.h"
+
+namespace vfx {
+
+namespace {
+constexpr int R128_PR = 160;  // patch rows per chunk buffer
+}
+
+__global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* __restrict__ pp) {
+  constexpr int C = 128, NW = 4, NTHR = NW * 64, MT = 128;
+  constexpr int NCH = C / 32;                // 32-channel chunks = waves along the couts
+  constexpr int PR = R128_PR;
+  constexpr int PBYTES = PR * CROW;
+  constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
+  constexpr int NG = PR / RG;                // DMA instructions per wave and chunk (5)
+  static_assert(PR % RG == 0 && (RG / 2) % 8 == 0 && NCH == NW, "geometry");
+  constexpr int WM = MT / 32;                // 32-position blocks per wave
+  constexpr int WL = 2;                      // weight loads per tap and wave (the hi fragments f[0], f[2])
+  constexpr int RING = 4, AHEAD = RING - 1;  // weight taps in flight: a tap is 8 MFMAs (256 cycles), an L2 round trip ~3 of them
+  constexpr int HROW = C * 4;                // bytes per h row (operand form: 128-byte chunk rows, fp16 in the first half)
+  constexpr int NT1 = 3 * NCH;               // taps of conv1 (chunk-major); conv2 has as many
+  constexpr int LDO = C + 4;                 // staged output row (floats)
+  constexpr int KEEP = MT / RG;              // centre rows per thread and chunk (4)
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds = reinterpret_cast<char*>(smem);
+
+  const ResBlockParams& p = *pp;
+  const int tid = threadIdx.x;
+  int tile;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tj = tile % p.tiles_w;
+  const int ti = (tile / p.tiles_w) % p.tiles_h;
+  const int img = tile / (p.tiles_w * p.tiles_h);
+  const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
+  const int rowstride = p.fold ? d : 0;
+  const int j0 = tj * p.TWo;
+  const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
+  const int base_x = base_h - d;                                // position of patch pixel (0, 0)
+  const float slope = p.slope;
+
+  const int lr = tid >> 3, cg = tid & 7;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int key_l = (lr >> 1) & 7;  // swizzle key of patch rows lr + RG * q
+
+  // ---- the raw x patch: every chunk at once ---------------------------------------------------------------------------------
+  {
+    unsigned voff[NG];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const int prow = lr + RG * q;
+      const int pi = prow / PW, pj = prow - pi * PW;
+      const int pos = base_x + pi * rowstride + pj;
+      const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
+      voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 4);
+      okmask |= ok ? (1u << q) : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.x + c * kKC), 0, (int)(unsigned)((int64_t)p.B * T * C * 4 - (int64_t)c * kKC * 4), 0x00020000);
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        const unsigned o = (okmask & (1u << q)) ? voff[q] + 16u * cg : 0xfffffff0u;  // out of the sequence: zero fill
+        VFX_LDS void* l = (VFX_LDS void*)(lds + c * PBYTES + (RG * q + 8 * wave_u) * CROW);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
+      }
+    }
+  }
+
+  int arow1[WM];   // A row of this lane's h pixel in the patch (tap offset to be added)
+  bool hval[WM];   // that h pixel lies inside the tile's h grid and inside the sequence
+#pragma unroll
+  for (int a = 0; a < WM; ++a) {
+    const int ml = a * 32 + l31;
+    const int li = ml / W1, lj = ml - li * W1;
+    arow1[a] = li < TH ? li * PW + lj : 0;
+    const int pos = base_h + li * rowstride + lj;
+    hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
+  }
+  // weights: (32-channel chunk, tap) blocks of C / 32 cout blocks x 1024 floats; this wave's cout block is w
+  const unsigned nb_off = (unsigned)(wave_u * 1024 + lane * 4) * 4u;
+  const int64_t ts = (int64_t)C * kKC;
+  const float* const w1p = p.w1;
+  const float* const w2p = p.w2;
+  const int poff0 = p.poff[0], poff1 = p.poff[1], poff2 = p.poff[2];
+
+  f32x16 acc[WM];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  // ---- weight ring: global tap g in register pair g % RING, AHEAD taps ahead (no "memory" clobbers in the compute phases) -------
+  f32x4 Wa0 = {}, Wb0 = {}, Wa1 = {}, Wb1 = {}, Wa2 = {}, Wb2 = {}, Wa3 = {}, Wb3 = {};  // (k 0..15, k 16..31) of ring slot 0..3
+  auto load_w = [&](f32x4& A, f32x4& B, const float* wtap) __attribute__((always_inline)) {
+    asm volatile(
+        "s_nop 4\n\t"
+        "global_load_dwordx4 %0, %2, %3\n\t"
+        "global_load_dwordx4 %1, %2, %3 offset:2048"
+        : "=&v"(A), "=&v"(B)
+        : "v"(nb_off), "s"(wtap));
+  };
+  auto fetch = [&](int g) __attribute__((always_inline)) {
+    const float* w = g < NT1 ? w1p + g * ts : w2p + (g - NT1) * ts;
+    switch (g % RING) {
+      case 0: load_w(Wa0, Wb0, w); break;
+      case 1: load_w(Wa1, Wb1, w); break;
+      case 2: load_w(Wa2, Wb2, w); break;
+      default: load_w(Wa3, Wb3, w); break;
+    }
+  };
+  // The registers of a ring slot are readable behind this statement (a counted s_waitcnt precedes it in program order: asm
+  // volatile statements keep their order); every reader depends on its outputs.
+  auto use_slot = [&](int s) __attribute__((always_inline)) {
+    switch (s) {
+      case 0: asm volatile("" : "+v"(Wa0), "+v"(Wb0)); break;
+      case 1: asm volatile("" : "+v"(Wa1), "+v"(Wb1)); break;
+      case 2: asm volatile("" : "+v"(Wa2), "+v"(Wb2)); break;
+      default: asm volatile("" : "+v"(Wa3), "+v"(Wb3)); break;
+    }
+  };
+
+#pragma unroll
+  for (int g = 0; g < AHEAD; ++g) fetch(g);
+  // the patch has landed (this wave's share = the rows its threads transform); the AHEAD weight fetches may stay in flight
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
+
+  // ---- raw fp32 -> fp16 operand rows, in place; the 128 centre rows stay in registers as the residual -----------------------------
+  // Patch row pr of chunk c: 32 floats; thread (lr, cg) owns floats 4 cg .. 4 cg + 3 of rows lr + 32 q.  Operand form (k_conv's
+  // 16-bit rows): the 8 bytes of those four channels at slot ((cg >> 1) ^ key), half cg & 1, of the same 128-byte row.
+  // Centre rows = the x samples of h pixels 0 .. 127: patch rows off .. off + 127, off = d (1-D) or PW (folded, one patch row up):
+  // of a thread's rows lr + 32 q exactly four lie in that window, q = q0 .. q0 + 3 with q0 = (lr < off) (off <= 32).
+  const int off = p.fold ? PW : d;
+  const bool q1 = lr < off;
+  f32x4 keep[NCH][KEEP];
+  {
+    bool f16_sat = false;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      char* row0 = lds + c * PBYTES + lr * CROW;
+      f32x4 raw[NG];
+#pragma unroll
+      for (int q = 0; q < NG; ++q) raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
+#pragma unroll
+      for (int j = 0; j < KEEP; ++j) keep[c][j] = q1 ? raw[j + 1] : raw[j];
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[q][e], raw[q][e] * slope);  // LeakyReLU(0) = 0: the DMA's zero fill stays zero
+        *reinterpret_cast<uint2*>(row0 + RG * q * CROW + (((cg >> 1) ^ key_l) << 4) + 8 * (cg & 1)) =
+            make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
+      }
+    }
+    report_f16_saturation(f16_sat, p.flags);
+  }
+  __syncthreads();  // the operand rows of every wave are visible
+
+  // ---- pixel fragments: software-pipelined one K step (4 MFMAs) ahead ------------------------------------------------------------
+  int rb[2][WM], kx[2][WM];
+  auto prep1 = [&](int g) __attribute__((always_inline)) {  // conv1: the patch chunk of tap g, rows arow1 + tap offset
+    const int c = g / 3, k = g % 3;
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      int r = arow1[a];
+      asm volatile("" : "+v"(r));  // per-tap addresses are recomputed, not kept
+      const int row = r + (k == 0 ? poff0 : (k == 1 ? poff1 : poff2));
+      rb[g & 1][a] = c * PBYTES + row * CROW;
+      kx[g & 1][a] = swz_key(row) ^ (16 * lh);
+    }
+  };
+  auto prep2 = [&](int g) __attribute__((always_inline)) {  // conv2: h rows m + k - 1; chunk c of row r sits at chunk position c ^ (r & 1)
+    const int c = (g - NT1) / 3, k = (g - NT1) % 3;
+    int lrow = l31;
+    asm volatile("" : "+v"(lrow));
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const int r0 = a * 32 + lrow + k - 1;
+      const int row = r0 < 0 ? 0 : (r0 > MT - 1 ? MT - 1 : r0);  // clamped rows only feed outputs that are masked anyway
+      rb[g & 1][a] = row * HROW + (c ^ (row & 1)) * CROW;
+      kx[g & 1][a] = swz_key(row) ^ (16 * lh);
+    }
+  };
+  f16x8 pxE[WM], pxO[WM];
+  auto rd = [&](f16x8 (&px)[WM], int g, int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < WM; ++a) px[a] = *reinterpret_cast<const f16x8*>(lds + rb[g & 1][a] + (kx[g & 1][a] ^ (32 * st)));
+  };
+  // K step st (0, 1) of tap g: D = W (A operand: rows = couts) x image rows (B operand: columns = pixels)
+  auto mm = [&](const f16x8 (&px)[WM], int g, int st) __attribute__((always_inline)) {
+    f32x4 w;
+    switch (g % RING) {
+      case 0: w = st ? Wb0 : Wa0; break;
+      case 1: w = st ? Wb1 : Wa1; break;
+      case 2: w = st ? Wb2 : Wa2; break;
+      default: w = st ? Wb3 : Wa3; break;
+    }
+    const f16x8 wf = __builtin_bit_cast(f16x8, w);
+#pragma unroll
+    for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, px[a], acc[a], 0, 0, 0);
+  };
+  // taps g0 .. g1-1 of one convolution; `more`: the launch has taps behind g1 (conv1: conv2's), fetched ahead from here
+  auto conv = [&](auto prep, int g0, int g1, bool more) __attribute__((always_inline)) {
+    prep(g0);
+    rd(pxE, g0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, WM, 0);  // the prologue's reads are a group of their own: the pattern below starts behind them
+#pragma unroll
+    for (int g = g0; g < g1; ++g) {
+      const int gmax = more ? 2 * NT1 : g1;  // taps that exist
+      // fetch tap g + AHEAD if it exists; then tap g's loads are older than the fetches issued after them
+      const int younger = (g + AHEAD < gmax ? AHEAD : gmax - 1 - g);
+      if (g + AHEAD < gmax) fetch(g + AHEAD);
+      if (younger == 3) asm volatile("s_waitcnt vmcnt(6)");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)");
+      else asm volatile("s_waitcnt vmcnt(0)");
+      use_slot(g % RING);
+      if (g + 1 < g1) prep(g + 1);
+      // step 0 (fragments in pxE): read step 1 of this tap; step 1 (pxO): read step 0 of the next tap
+      // (the four reads of the next step FIRST, then this step's four MFMAs: a step is only 128 cycles, about one LDS latency --
+      // interleaved one by one, the youngest read would be 32 cycles old when the next step waits for it)
+      rd(pxO, g, 1);
+      mm(pxE, g, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, WM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);
+      const bool last = g + 1 == g1;
+      if (!last) rd(pxE, g + 1, 0);
+      mm(pxO, g, 1);
+      if (!last) __builtin_amdgcn_sched_group_barrier(0x100, WM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);
+    }
+  };
+
+  // ---- phase 1: conv1 (its last taps fetch the first taps of conv2) --------------------------------------------------------------
+  conv(prep1, 0, NT1, true);
+  __syncthreads();  // every wave is done reading the patch buffers that h overlays
+
+  // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------------------------
+  // Lane (l31, lh) of position block a holds h pixel m = a*32 + l31 and, in registers 4j .. 4j+3, channels w*32 + 8j + 4lh .. +3:
+  // chunk w of the pixel's row, piece j, half lh.
+  {
+    bool f16_sat = false;
+    f32x4 b1v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b1v[j] = *(const VFX_GLOBAL f32x4*)(p.b1 + wave_u * 32 + 8 * j + 4 * lh);
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const int m = a * 32 + l31;
+      char* rowp = lds + m * HROW + (wave_u ^ (m & 1)) * CROW + 8 * lh;  // chunk parity swap: see prep2()
+      const int key = (m >> 1) & 7;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = acc[a][4 * j + e] + b1v[j][e];
+          u[e] = hval[a] ? fmaxf(t, t * slope) : 0.f;
+          acc[a][4 * j + e] = 0.f;
+        }
+        *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1], f16_sat), pack_f16x2(u[2], u[3], f16_sat));
+      }
+    }
+    report_f16_saturation(f16_sat, p.flags);
+  }
+  __syncthreads();  // h is complete
+
+  // ---- phase 3: conv2 from the resident h ----------------------------------------------------------------------------------------
+  conv(prep2, NT1, 2 * NT1, false);
+  __syncthreads();  // every wave is done with h
+
+  // ---- phase 4: y = conv2 + b2 + x: the accumulators staged in LDS, the kept centre rows added there, whole rows stored -----------
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = a * 32 + l31;
+      *reinterpret_cast<f32x4*>(smem + row * LDO + wave_u * 32 + 8 * j + 4 * lh) =
+          f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
+    }
+  __syncthreads();
+  {
+    // patch row lr + 32 (q0 + j) is the input sample of h pixel m = that row - off: every staged (row, 4 channels) is touched by
+    // exactly one thread
+    const int m0 = lr + (q1 ? RG : 0) - off;
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        f32x4* s4 = reinterpret_cast<f32x4*>(smem + (m0 + RG * j) * LDO + c * 32 + 4 * cg);
+        *s4 = *s4 + keep[c][j];
+      }
+  }
+  __syncthreads();
+  {
+    constexpr int V = C / 4, RPP = NTHR / V, NPASS = MT / RPP;  // 32 float4 per row, 8 rows per step, 16 steps
+    const int c4 = tid % V, r0 = tid / V;
+    const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
+    const float aslope = p.act_slope;
+    const bool even = (tid & 1) == 0;
+    bool ya_sat = false;
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int m = r0 + q * RPP;  // h pixel of the staged row
+      const int li = m / W1, lj = m - li * W1;
+      const int pos = base_h + li * rowstride + lj;
+      const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
+      const f32x4 val = *reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * c4) + bv;
+      const int64_t op = (int64_t)img * T + pos;
+      if (ok) *(VFX_GLOBAL f32x4*)(p.y + op * C + 4 * c4) = val;
+      if (p.ya) {
+        // last layer of the stack: also the activated fp16 form for the upsampler that follows (2 bytes per element)
+        f32x4 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = fmaxf(val[e], val[e] * aslope);
+        const unsigned h01 = pack_f16x2(u[0], u[1], ya_sat), h23 = pack_f16x2(u[2], u[3], ya_sat);
+        // quad_perm [1,0,3,2]: the even lane of a pair collects the pair's 8 consecutive channels (16 bytes)
+        const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)h01, 0xB1, 0xf, 0xf, false);
+        const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)h23, 0xB1, 0xf, 0xf, false);
+        const u32x4 w = {h01, h23, g0, g1};
+        if (ok && even) *(VFX_GLOBAL f32x4*)(p.ya + op * (C / 2) + 2 * c4) = __builtin_bit_cast(f32x4, w);
+      }
+    }
+    if (p.ya) report_f16_saturation(ya_sat, p.flags);
+  }
+}
+
+int resblock_r128_patch_rows() { return R128_PR; }
+
+// The four-wave, read-x-once form runs the C = 128 layers of the 16-bit mode by default; VFX_TUNE_C128_8WAVE selects k_resblock<128, 8>.
+bool resblock_r128_enabled(int tuning) { return !(tuning & VFX_TUNE_C128_8WAVE); }
+
+void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
+  VFX_CHECK(!hp.asrc && hp.hionly && hp.C == 128 && !hp.geo2d && hp.dil2 == 0 && hp.tile_m == 128 && hp.patch_rows == R128_PR,
+            "resblock_r128: needs the 16-bit mode, C = 128, 128-position tiles planned with %d patch rows", R128_PR);
+  VFX_CHECK((hp.fold ? hp.PW : hp.dil) <= 32, "resblock_r128: the residual window starts beyond patch row 32");
+  const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
+  VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock_r128: bad grid");
+  // 4 chunk buffers of 160 rows = 80 KB (h: 64 KB and the staged tile: 66 KB overlay them): exactly two blocks per CU
+  const size_t lds = (size_t)(128 / 32) * R128_PR * CROW;
+  static_assert((128 / 32) * R128_PR * CROW >= 128 * (128 + 4) * 4 && (128 / 32) * R128_PR * CROW >= 128 * 128 * 4, "overlays must fit");
+  static uint64_t attr_devices = 0;
+  if (first_use_on_current_device(attr_devices)) {
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(k_resblock_r128, dim3((int)grid), dim3(256), lds, stream, dparams);
+  VFX_HIP(hipGetLastError());
+}
+
+}  // namespace vfx

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   auto conv = [&](auto prep, int g0, int g1, bool fetch_past) __attribute__((always_inline)) {
     prep(g0);
     rd(pxE, g0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, WM, 0);  // the prologue's reads are a group of their own: the pattern below starts behind them
 #pragma unroll
     for (int g = g0; g < g1; ++g) {
       if (g + 1 < g1 || fetch_past) {

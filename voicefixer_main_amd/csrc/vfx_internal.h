@@ -201,6 +201,7 @@ struct ResBlockParams {
   const float* w2b;
   const float* b1b;
   const float* b2b;
+  int r128;         // set by plan_resblock: resblock_r128.hip runs this layer (16-bit mode, C = 128)
   int rw;           // set by plan_resblock: the persistent register-weights kernel runs this layer (resblock_rw.hip: 16-bit mode, C = 64)
   const float* xa;
   float* ya;
@@ -224,6 +225,10 @@ void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams
 // resblock_rw.hip: C = 64, 16-bit mode -- persistent blocks, weights in registers, next patch prefetched into registers
 // resblock_w64.hip: the wide layer (C = 256, 16-bit mode) as 4-wave blocks of 64-cout waves, two blocks per CU
 bool resblock_w64_enabled(int tuning);
+// resblock_r128.hip: C = 128, 16-bit mode -- 4-wave blocks, two per CU, x read once (the residual stays in registers)
+bool resblock_r128_enabled(int tuning);
+int resblock_r128_patch_rows();
+void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 int resblock_w64_patch_rows();
 void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 int resblock_rw_tile(int tuning);
