@@ -66,6 +66,9 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
   const int base_x = base_h - d;                                // position of patch pixel (0, 0)
   const float slope = p.slope;
+  // m / W1 and prow / PW as multiply-shift (rows < 512, divisors <= 320: exact; cf. resblock_rw.hip): an integer division is ~25 VALU
+  // instructions, a tile has 25 of them per thread
+  const unsigned inv_pw = ((1u << 20) + PW - 1) / PW, inv_w1 = ((1u << 20) + W1 - 1) / W1;
 
   const int lr = tid >> 3, cg = tid & 7;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       const int prow = lr + RG * q;
-      const int pi = prow / PW, pj = prow - pi * PW;
+      const int pi = (int)(((unsigned)prow * inv_pw) >> 20), pj = prow - pi * PW;
       const int pos = base_x + pi * rowstride + pj;
       const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
       voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 2);
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
     const int ml = a * 32 + l31;
-    const int li = ml / W1, lj = ml - li * W1;
+    const int li = (int)(((unsigned)ml * inv_w1) >> 20), lj = ml - li * W1;
     arow1[a] = li < TH ? li * PW + lj : 0;
     const int pos = base_h + li * rowstride + lj;
     hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
 #pragma unroll
     for (int q = 0; q < SUB; ++q) {
       const int m = r0 + (sp * SUB + q) * RPP;  // h pixel of the staged row
-      const int li = m / W1, lj = m - li * W1;
+      const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
       const int pos = base_h + li * rowstride + lj;
       const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
       opix[sp][q] = ok ? img * T + pos : -1;
