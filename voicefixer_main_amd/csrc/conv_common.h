@@ -33,6 +33,22 @@ __device__ __forceinline__ void report_f16_saturation(bool sat, int* flags) {
   if (__any(sat) && flags && (threadIdx.x & 63) == 0) atomicOr(flags, VFX_FLAG_F16_SATURATED);
 }
 
+// Phase stamps of the timing builds (-DVFX_TIMING; the shipped build compiles them away): lane 0 of every wave keeps
+// s_memtime at the phase boundaries and writes them out at the end of the tile.
+#ifdef VFX_TIMING
+#define VFX_TS_DECL unsigned long long vfx_ts_[16] = {}
+#define VFX_TS(i) vfx_ts_[i] = __builtin_readcyclecounter()
+#define VFX_TS_FLUSH(ptr, tile, wave, nwaves)                                                          \
+  do {                                                                                                 \
+    if ((ptr) && (threadIdx.x & 63) == 0)                                                              \
+      for (int i_ = 0; i_ < 16; ++i_) (ptr)[((size_t)(tile) * (nwaves) + (wave)) * 16 + i_] = vfx_ts_[i_]; \
+  } while (0)
+#else
+#define VFX_TS_DECL
+#define VFX_TS(i)
+#define VFX_TS_FLUSH(ptr, tile, wave, nwaves)
+#endif
+
 constexpr int CBM = 128;                     // pixels per tile
 constexpr int CROW = 128;                    // bytes per patch row (32 channels)
 constexpr int CNQ = kPatchMaxRows / 32;      // patch row groups (one DMA instruction / register group each)

@@ -579,6 +579,9 @@ void plan_block2d(ResBlockParams& p) {
 void plan_resblock(ResBlockParams& p) {
   VFX_CHECK(p.asrc ? resblock_act_supported(p.C) : resblock_supported(p.C), "resblock: C=%d is not supported", p.C);
   const int d = p.dil;
+#ifdef VFX_TIMING
+  p.timing = getenv("VFX_TIMING_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("VFX_TIMING_PTR"), nullptr, 0)) : nullptr;
+#endif
   // 16-bit mode, C = 64: the persistent register-weights kernel (resblock_rw.hip) with its own tile size
   p.rw = (!p.asrc && p.hionly && p.C == 64 && resblock_rw_tile(p.tuning) != 0) ? 1 : 0;
   if (p.rw) p.tile_m = resblock_rw_tile(p.tuning);

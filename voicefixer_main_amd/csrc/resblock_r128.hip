@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  VFX_TS_DECL;
+  VFX_TS(0);
   const int tj = tile % p.tiles_w;
   const int ti = (tile / p.tiles_w) % p.tiles_h;
   const int img = tile / (p.tiles_w * p.tiles_h);
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     }
   }
 
+  VFX_TS(1);  // patch requested
   int arow1[WM];   // A row of this lane's h pixel in the patch (tap offset to be added)
   bool hval[WM];   // that h pixel lies inside the tile's h grid and inside the sequence
 #pragma unroll
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   // the patch has landed (this wave's share = the rows its threads transform); the AHEAD weight fetches may stay in flight
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
 
+  VFX_TS(2);  // patch landed
   // ---- raw fp32 -> fp16 operand rows, in place; the 128 centre rows stay in registers as the residual -----------------------------
   // Patch row pr of chunk c: 32 floats; thread (lr, cg) owns floats 4 cg .. 4 cg + 3 of rows lr + 32 q.  Operand form (k_conv's
   // 16-bit rows): the 8 bytes of those four channels at slot ((cg >> 1) ^ key), half cg & 1, of the same 128-byte row.
@@ -185,7 +189,9 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     }
     report_f16_saturation(f16_sat, p.flags);
   }
+  VFX_TS(3);  // transformed
   __syncthreads();  // the operand rows of every wave are visible
+  VFX_TS(4);
 
   // ---- pixel fragments: software-pipelined one K step (4 MFMAs) ahead ------------------------------------------------------------
   int rb[2][WM], kx[2][WM];
@@ -264,7 +270,9 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 
   // ---- phase 1: conv1 (its last taps fetch the first taps of conv2) --------------------------------------------------------------
   conv(prep1, 0, NT1, true);
+  VFX_TS(5);  // conv1 done
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
+  VFX_TS(6);
 
   // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------------------------
   // Lane (l31, lh) of position block a holds h pixel m = a*32 + l31 and, in registers 4j .. 4j+3, channels w*32 + 8j + 4lh .. +3:
@@ -293,11 +301,15 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     }
     report_f16_saturation(f16_sat, p.flags);
   }
+  VFX_TS(7);  // h written
   __syncthreads();  // h is complete
+  VFX_TS(8);
 
   // ---- phase 3: conv2 from the resident h ----------------------------------------------------------------------------------------
   conv(prep2, NT1, 2 * NT1, false);
+  VFX_TS(9);  // conv2 done
   __syncthreads();  // every wave is done with h
+  VFX_TS(10);
 
   // ---- phase 4: y = conv2 + b2 + x: the accumulators staged in LDS, the kept centre rows added there, whole rows stored -----------
 #pragma unroll
@@ -322,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       }
   }
   __syncthreads();
+  VFX_TS(11);  // staged + residual added
   {
     constexpr int V = C / 4, RPP = NTHR / V, NPASS = MT / RPP;  // 32 float4 per row, 8 rows per step, 16 steps
     const int c4 = tid % V, r0 = tid / V;
@@ -353,6 +366,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     }
     if (p.ya) report_f16_saturation(ya_sat, p.flags);
   }
+  VFX_TS(12);  // stores issued
+  VFX_TS_FLUSH(p.timing, tile, wave_u, NW);
 }
 
 int resblock_r128_patch_rows() { return R128_PR; }

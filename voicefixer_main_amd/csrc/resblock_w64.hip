@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  VFX_TS_DECL;
+  VFX_TS(0);
   const int tj = tile % p.tiles_w;
   const int ti = (tile / p.tiles_w) % p.tiles_h;
   const int img = tile / (p.tiles_w * p.tiles_h);
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
     }
   }
 
+  VFX_TS(1);  // patch requested
   int arow1[WM];   // A row of this lane's h pixel in the patch (tap offset to be added)
   bool hval[WM];   // that h pixel lies inside the tile's h grid and inside the sequence
 #pragma unroll
@@ -248,11 +251,16 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
 
   fetch(0);
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // the patch and tap 0 have landed (this wave's share)
+  VFX_TS(2);
+  VFX_TS(3);
   __syncthreads();                                     // ... and everybody else's
+  VFX_TS(4);
 
   // ---- phase 1: conv1 (its last tap fetches the first tap of conv2) -------------------------------------------------------------
   conv(prep1, 0, NT1, true);
+  VFX_TS(5);
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
+  VFX_TS(6);
 
   // ---- phase 2: h = LeakyReLU(conv1 + b1) as fp16, zero outside the sequence ---------------------------------------------------
   // Lane (l31, lh) of position block a holds h pixel m = a*32 + l31 and, in registers 4j .. 4j+3 of cout block cb, channels
@@ -285,10 +293,13 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
     }
     report_f16_saturation(f16_sat, p.flags);
   }
+  VFX_TS(7);
   __syncthreads();  // h is complete
+  VFX_TS(8);
 
   // ---- phase 3: conv2 from the resident h (tap NT1 was fetched by conv1's last tap: its wait is the first one of conv()) ----------
   conv(prep2, NT1, 2 * NT1, false);
+  VFX_TS(9);
 
   // ---- phase 4: y = conv2 + b2 + x, raw fp32 and (optionally) activated fp16 -----------------------------------------------------
   // Two passes of 128 channels (the pass of waves 0, 1, then the one of waves 2, 3) through a staged tile in LDS; every pass in
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   };
   request_res(resA, 0, 0);
   __syncthreads();  // every wave is done with h
+  VFX_TS(10);
   bool ya_sat = false;
 #pragma unroll
   for (int pass = 0; pass < NEP; ++pass) {
@@ -365,9 +377,12 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
         }
       }
     }
+    if (pass == 0) { VFX_TS(11); }  // pass 0 stored
     if (pass + 1 < NEP) __syncthreads();  // the staged pass has been consumed
   }
   if (p.ya) report_f16_saturation(ya_sat, p.flags);
+  VFX_TS(12);
+  VFX_TS_FLUSH(p.timing, tile, wave_u, NW);
 }
 
 int resblock_w64_patch_rows() { return W64_PR; }

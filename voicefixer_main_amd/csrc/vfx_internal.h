@@ -216,6 +216,8 @@ struct ResBlockParams {
   int hoff9[9];      // conv2: h row offset of tap (dy, dx)
   int patch_rows;    // set by plan_resblock: rows of a patch buffer when they are not tile_m + 64 (resblock_w64.hip: 160)
   int tuning;        // vfx_config.tuning of the handle: which kernel family runs the layer (plan_resblock)
+  // Timing builds only (-DVFX_TIMING, scripts/phase_timing.py): [tile][wave][16] s_memtime stamps of the 4-wave kernels' phases
+  unsigned long long* timing;
 };
 bool resblock_supported(int C);
 int resblock_block_waves(const ResBlockParams& hp);
