@@ -637,6 +637,13 @@ void plan_resblock(ResBlockParams& p) {
     for (int k = 0; k < 3; ++k) p.poff[k] = k * p.W1;
   }
   VFX_CHECK(p.P <= PR && p.TH * p.W1 <= MT && p.TH >= 1, "resblock: bad tile geometry (dil=%d)", d);
+  p.inv_pw = ((1u << 20) + p.PW - 1) / p.PW;
+  p.inv_w1 = ((1u << 20) + p.W1 - 1) / p.W1;
+  const int64_t tpi = (int64_t)p.tiles_w * p.tiles_h;
+  p.inv_tiles_w = (unsigned)((((uint64_t)1 << 32) + p.tiles_w - 1) / p.tiles_w);
+  p.inv_tiles_per_img = (unsigned)((((uint64_t)1 << 32) + tpi - 1) / tpi);
+  // exact while n * d < 2^32: n = tile index < B * tpi, d = tpi
+  VFX_CHECK(!p.patch_rows || (double)p.B * (double)tpi * (double)tpi < 4294967296.0, "resblock: too many tiles for the reciprocal tile split");
   VFX_CHECK((int64_t)p.B * p.T * p.C * 4 < ((int64_t)1 << 32) - 4096, "resblock: tensor exceeds 4 GiB");
 }
 

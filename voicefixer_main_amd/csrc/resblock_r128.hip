@@ -55,9 +55,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   }
   VFX_TS_DECL;
   VFX_TS(0);
-  const int tj = tile % p.tiles_w;
-  const int ti = (tile / p.tiles_w) % p.tiles_h;
-  const int img = tile / (p.tiles_w * p.tiles_h);
+  // tile -> (image, tile row, tile column) with the host's reciprocals (plan_resblock): three integer divisions otherwise
+  const int img = (int)(((unsigned long long)(unsigned)tile * p.inv_tiles_per_img) >> 32);
+  const int trem = tile - img * (p.tiles_w * p.tiles_h);
+  const int ti = (int)(((unsigned long long)(unsigned)trem * p.inv_tiles_w) >> 32);
+  const int tj = trem - ti * p.tiles_w;
   const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
   const int rowstride = p.fold ? d : 0;
   const int j0 = tj * p.TWo;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   const float slope = p.slope;
   // m / W1 and prow / PW as multiply-shift (rows < 512, divisors <= 320: exact; cf. resblock_rw.hip): an integer division is ~25 VALU
   // instructions, a tile has 25 of them per thread
-  const unsigned inv_pw = ((1u << 20) + PW - 1) / PW, inv_w1 = ((1u << 20) + W1 - 1) / W1;
+  const unsigned inv_pw = p.inv_pw, inv_w1 = p.inv_w1;
 
   const int lr = tid >> 3, cg = tid & 7;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -342,6 +344,12 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     const float aslope = p.act_slope;
     const bool even = (tid & 1) == 0;
     bool ya_sat = false;
+    // y and ya through buffer descriptors: 32-bit offsets, and a masked row is an offset beyond the bound (its stores are dropped)
+    // -- no exec-mask juggling around 16 (+ 16) stores per thread
+    constexpr unsigned kOob = 0xfffffff0u;  // beyond every descriptor (plan_resblock: tensors < 4 GiB - 4096); nothing is added to it
+    const unsigned ybytes = (unsigned)((int64_t)p.B * T * C * 4);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(p.ya, 0, p.ya ? (int)(ybytes / 2) : 0, 0x00020000);
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
       const int m = r0 + q * RPP;  // h pixel of the staged row
@@ -349,8 +357,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       const int pos = base_h + li * rowstride + lj;
       const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
       const f32x4 val = *reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * c4) + bv;
-      const int64_t op = (int64_t)img * T + pos;
-      if (ok) *(VFX_GLOBAL f32x4*)(p.y + op * C + 4 * c4) = val;
+      const unsigned off = (unsigned)(img * T + pos) * (unsigned)(C * 4) + 16u * c4;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ry, (int)(ok ? off : kOob), 0, 0);
       if (p.ya) {
         // last layer of the stack: also the activated fp16 form for the upsampler that follows (2 bytes per element)
         f32x4 u;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)h01, 0xB1, 0xf, 0xf, false);
         const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)h23, 0xB1, 0xf, 0xf, false);
         const u32x4 w = {h01, h23, g0, g1};
-        if (ok && even) *(VFX_GLOBAL f32x4*)(p.ya + op * (C / 2) + 2 * c4) = __builtin_bit_cast(f32x4, w);
+        __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)((ok && even) ? off / 2 : kOob), 0, 0);
       }
     }
     if (p.ya) report_f16_saturation(ya_sat, p.flags);

@@ -59,9 +59,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   }
   VFX_TS_DECL;
   VFX_TS(0);
-  const int tj = tile % p.tiles_w;
-  const int ti = (tile / p.tiles_w) % p.tiles_h;
-  const int img = tile / (p.tiles_w * p.tiles_h);
+  // tile -> (image, tile row, tile column) with the host's reciprocals (plan_resblock): three integer divisions otherwise
+  const int img = (int)(((unsigned long long)(unsigned)tile * p.inv_tiles_per_img) >> 32);
+  const int trem = tile - img * (p.tiles_w * p.tiles_h);
+  const int ti = (int)(((unsigned long long)(unsigned)trem * p.inv_tiles_w) >> 32);
+  const int tj = trem - ti * p.tiles_w;
   const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
   const int rowstride = p.fold ? d : 0;
   const int j0 = tj * p.TWo;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   const float slope = p.slope;
   // m / W1 and prow / PW as multiply-shift (rows < 512, divisors <= 320: exact; cf. resblock_rw.hip): an integer division is ~25 VALU
   // instructions, a tile has 25 of them per thread
-  const unsigned inv_pw = ((1u << 20) + PW - 1) / PW, inv_w1 = ((1u << 20) + W1 - 1) / W1;
+  const unsigned inv_pw = p.inv_pw, inv_w1 = p.inv_w1;
 
   const int lr = tid >> 3, cg = tid & 7;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -305,10 +307,20 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   // Two passes of 128 channels (the pass of waves 0, 1, then the one of waves 2, 3) through a staged tile in LDS; every pass in
   // NSUB sub-passes of 32 rows whose residual is requested one sub-pass ahead (the loads of sub-pass s + 1 are issued BEFORE
   // the stores of sub-pass s, so no load waits behind a store: vmcnt counts both, in order).
-  const int c4 = tid % V, r0 = tid / V;
-  const bool even = (tid & 1) == 0;
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));  // the epilogue's index math stays behind conv2 (hoisted into its last taps it spills)
+  const int c4 = tid_e % V, r0 = tid_e / V;
+  const bool even = (tid_e & 1) == 0;
   const float aslope = p.act_slope;
-  int opix[NSUB][SUB];
+  // Residual, y and ya go through buffer descriptors: 32-bit byte offsets (half the address registers of 64-bit pointers: the
+  // epilogue runs beside the 128 accumulators of the waves that stage second), and a masked row is simply an offset beyond the
+  // descriptor's bound -- its load returns zeros, its stores are dropped.
+  const unsigned ybytes = (unsigned)((int64_t)p.B * T * C * 4);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(p.ya, 0, p.ya ? (int)(ybytes / 2) : 0, 0x00020000);
+  constexpr unsigned kOob = 0xC0000000u;  // beyond every descriptor (the launch checks the tensors are < 2 GiB), + 1 KB does not wrap
+  unsigned ooff[NSUB][SUB];  // byte offset of the row's first channel in y (fp32); ya: half of it
 #pragma unroll
   for (int sp = 0; sp < NSUB; ++sp)
 #pragma unroll
@@ -317,17 +329,22 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
       const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
       const int pos = base_h + li * rowstride + lj;
       const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
-      opix[sp][q] = ok ? img * T + pos : -1;
+      ooff[sp][q] = ok ? (unsigned)(img * T + pos) * (unsigned)(C * 4) : kOob;
     }
-  f32x4 resA[SUB], resB[SUB];
-  auto request_res = [&](f32x4 (&res)[SUB], int pass, int sp) __attribute__((always_inline)) {
+  // The residual runs THREE sub-passes (12 loads, 48 registers) ahead: the first three are requested here, before the staging
+  // barriers, sub-pass i + 3 as soon as sub-pass i has consumed its registers.  (Round 3, phase stamps: with the residual
+  // requested ONE sub-pass ahead -- and the compiler moving that request behind the stores -- the epilogue was eight exposed
+  // memory latencies: 32 k of a block's 91 k cycles.  A whole pass ahead (64 registers) spills beside the 128 accumulators.)
+  constexpr int NRB = 3;  // residual register sets: sub-pass i uses set i % NRB and then requests sub-pass i + NRB into it
+  u32x4 res[NRB][SUB];
+  auto request_res = [&](int idx) __attribute__((always_inline)) {  // idx = pass * NSUB + sub-pass
+    const int pass = idx / NSUB, sp = idx % NSUB;
 #pragma unroll
-    for (int q = 0; q < SUB; ++q) {
-      const int op = opix[sp][q];
-      res[q] = *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(op < 0 ? 0 : op) * C + pass * EPC + 4 * c4);
-    }
+    for (int q = 0; q < SUB; ++q)
+      res[idx % NRB][q] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ooff[sp][q] + (unsigned)(pass * EPC * 4 + 16 * c4)), 0, 0);
   };
-  request_res(resA, 0, 0);
+#pragma unroll
+  for (int i = 0; i < NRB; ++i) request_res(i);
   __syncthreads();  // every wave is done with h
   VFX_TS(10);
   bool ya_sat = false;
@@ -350,17 +367,15 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
     const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + ncol);
 #pragma unroll
     for (int sp = 0; sp < NSUB; ++sp) {
-      const int idx = pass * NSUB + sp;  // sub-passes alternate between the two residual register sets
-      f32x4 (&cur)[SUB] = (idx & 1) ? resB : resA;
-      f32x4 (&nxt)[SUB] = (idx & 1) ? resA : resB;
-      if (idx + 1 < NEP * NSUB) request_res(nxt, (idx + 1) / NSUB, (idx + 1) % NSUB);
       f32x4 val[SUB];
 #pragma unroll
       for (int q = 0; q < SUB; ++q)
-        val[q] = *reinterpret_cast<const f32x4*>(smem + (r0 + (sp * SUB + q) * RPP) * LDO + 4 * c4) + bv + cur[q];
+        val[q] = *reinterpret_cast<const f32x4*>(smem + (r0 + (sp * SUB + q) * RPP) * LDO + 4 * c4) + bv +
+                 __builtin_bit_cast(f32x4, res[(pass * NSUB + sp) % NRB][q]);
+      if (pass * NSUB + sp + NRB < NEP * NSUB) request_res(pass * NSUB + sp + NRB);  // into the registers just consumed
 #pragma unroll
       for (int q = 0; q < SUB; ++q)
-        if (opix[sp][q] >= 0) *(VFX_GLOBAL f32x4*)(p.y + (int64_t)opix[sp][q] * C + ncol) = val[q];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val[q]), ry, (int)(ooff[sp][q] + (unsigned)(ncol * 4)), 0, 0);
       if (p.ya) {
 #pragma unroll
         for (int q = 0; q < SUB; ++q) {
@@ -372,8 +387,9 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
           const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)h01, 0xB1, 0xf, 0xf, false);
           const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)h23, 0xB1, 0xf, 0xf, false);
           const u32x4 w = {h01, h23, g0, g1};
-          if (opix[sp][q] >= 0 && even)
-            *(VFX_GLOBAL f32x4*)(p.ya + (int64_t)opix[sp][q] * (C / 2) + (ncol >> 1)) = __builtin_bit_cast(f32x4, w);
+          // (half of a masked row's offset could land INSIDE ya: the odd lanes and the masked rows get the out-of-bounds offset itself)
+          const unsigned ao = (even && ooff[sp][q] != kOob) ? ooff[sp][q] / 2 + (unsigned)(ncol * 2) : kOob;
+          __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)ao, 0, 0);
         }
       }
     }
@@ -395,6 +411,8 @@ void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams
             "resblock_w64: needs the 16-bit mode, C = 256, 128-position tiles planned with %d patch rows", W64_PR);
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock_w64: bad grid");
+  // the epilogue addresses x / y / ya with 32-bit offsets and masks rows with an offset of 3 GiB
+  VFX_CHECK((int64_t)hp.B * hp.T * hp.C * 4 < ((int64_t)1 << 31), "resblock_w64: tensor exceeds 2 GiB");
   // 4 chunk buffers of 160 rows = 80 KB (h: 64 KB and the staged pass: 66 KB overlay them): exactly two blocks per CU
   const size_t lds = (size_t)(256 / 64) * W64_PR * CROW;
   static_assert((256 / 64) * W64_PR * CROW >= 128 * (128 + 4) * 4 && (256 / 64) * W64_PR * CROW >= 128 * 256 * 2, "overlays must fit");

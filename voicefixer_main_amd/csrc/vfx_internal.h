@@ -214,6 +214,10 @@ struct ResBlockParams {
   const float* sh2;
   int poff9[9];      // conv1: patch row offset of tap (dy, dx)
   int hoff9[9];      // conv2: h row offset of tap (dy, dx)
+  // set by plan_resblock: multiply-shift reciprocals, n / d = (n * inv) >> 20 (exact for n < 512, d <= 320), and the tile ->
+  // (image, tile row, tile column) split as (tile * inv_tpi) >> 32 etc. (exact for tile < 2^32 / d)
+  unsigned inv_pw, inv_w1;
+  unsigned inv_tiles_w, inv_tiles_per_img;
   int patch_rows;    // set by plan_resblock: rows of a patch buffer when they are not tile_m + 64 (resblock_w64.hip: 160)
   int tuning;        // vfx_config.tuning of the handle: which kernel family runs the layer (plan_resblock)
   // Timing builds only (-DVFX_TIMING, scripts/phase_timing.py): [tile][wave][16] s_memtime stamps of the 4-wave kernels' phases
