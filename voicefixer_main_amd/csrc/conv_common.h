@@ -15,7 +15,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // fp16 operand form of the 16-bit mode (TapConvParams::hionly): round to nearest, saturate instead of overflowing
 __device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
-  const f32x2 v = {__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f)};
+  // v_med3_f32 = the clamp in one instruction (a NaN comes out as min3 = -65504, exactly what fmin(fmax(x, -65504), 65504) gives)
+  const f32x2 v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   constexpr int HROW = C * 4;                // bytes per h row (operand form: 128-byte chunk rows, fp16 in the first half)
   constexpr int NT1 = 3 * NCH;               // taps of conv1 (chunk-major); conv2 has as many
   constexpr int LDO = C + 4;                 // staged output row (floats)
-  constexpr int KEEP = MT / RG;              // centre rows per thread and chunk (4)
+  constexpr int KEEP = MT / 8;               // centre rows per thread (16: rows rt + 8 j of one chunk)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = reinterpret_cast<char*>(smem);
@@ -74,7 +74,6 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int key_l = (lr >> 1) & 7;  // swizzle key of patch rows lr + RG * q
 
   // ---- the raw x patch: every chunk at once ---------------------------------------------------------------------------------
   {
@@ -158,36 +157,45 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 
 #pragma unroll
   for (int g = 0; g < AHEAD; ++g) fetch(g);
-  // the patch has landed (this wave's share = the rows its threads transform); the AHEAD weight fetches may stay in flight
+  // the patch has landed (this wave's share); the AHEAD weight fetches may stay in flight
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
 
   VFX_TS(2);  // patch landed
+  __syncthreads();  // ... and everybody else's: a thread transforms rows that other waves requested
   // ---- raw fp32 -> fp16 operand rows, in place; the 128 centre rows stay in registers as the residual -----------------------------
-  // Patch row pr of chunk c: 32 floats; thread (lr, cg) owns floats 4 cg .. 4 cg + 3 of rows lr + 32 q.  Operand form (k_conv's
-  // 16-bit rows): the 8 bytes of those four channels at slot ((cg >> 1) ^ key), half cg & 1, of the same 128-byte row.
-  // Centre rows = the x samples of h pixels 0 .. 127: patch rows off .. off + 127, off = d (1-D) or PW (folded, one patch row up):
-  // of a thread's rows lr + 32 q exactly four lie in that window, q = q0 .. q0 + 3 with q0 = (lr < off) (off <= 32).
-  const int off = p.fold ? PW : d;
-  const bool q1 = lr < off;
-  f32x4 keep[NCH][KEEP];
+  // Patch row pr of chunk c: 32 floats.  Thread (rt, ct, cgt) = (tid / 32, chunk, 4-float piece) -- the thread that will STORE
+  // channels 32 ct + 4 cgt .. + 3 of the output rows m = rt + 8 j in the epilogue -- transforms, of chunk ct, the x samples of
+  // exactly those rows (patch rows m + off, off = d for 1-D tiles, PW = one patch row up for folded ones: the centre window of the
+  // patch) and keeps their raw values: the residual is added in the output pass from registers, no thread ever hands it to
+  // another one.  The up to 32 halo rows around the window are shared out four per thread.  Operand form (k_conv's 16-bit rows):
+  // the 8 bytes of the four channels at slot ((cgt >> 1) ^ key(row)), half cgt & 1, of the same 128-byte row; the threads of a
+  // row's chunk are 8 consecutive lanes, which read all their raw values before any of them writes.
+  const int off = p.fold ? PW : d;  // <= 32 (launch_resblock_r128)
+  const int rt = tid >> 5, ct = (tid >> 3) & 3, cgt = tid & 7;
+  constexpr int NROW = PR / 8;      // rows per thread: 16 centre + 4 halo
+  f32x4 keep[KEEP];
   {
     bool f16_sat = false;
+    char* const cb = lds + ct * PBYTES + 16 * cgt;
+    int prow[NROW];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      char* row0 = lds + c * PBYTES + lr * CROW;
-      f32x4 raw[NG];
+    for (int j = 0; j < NROW; ++j) {
+      const int hh = rt + 8 * (j - KEEP);
+      prow[j] = j < KEEP ? rt + 8 * j + off : (hh < off ? hh : hh + MT);
+    }
+    f32x4 raw[NROW];
 #pragma unroll
-      for (int q = 0; q < NG; ++q) raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
+    for (int j = 0; j < NROW; ++j) raw[j] = *reinterpret_cast<const f32x4*>(cb + prow[j] * CROW);
 #pragma unroll
-      for (int j = 0; j < KEEP; ++j) keep[c][j] = q1 ? raw[j + 1] : raw[j];
+    for (int j = 0; j < KEEP; ++j) keep[j] = raw[j];
 #pragma unroll
-      for (int q = 0; q < NG; ++q) {
-        f32x4 v;
+    for (int j = 0; j < NROW; ++j) {
+      f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[q][e], raw[q][e] * slope);  // LeakyReLU(0) = 0: the DMA's zero fill stays zero
-        *reinterpret_cast<uint2*>(row0 + RG * q * CROW + (((cg >> 1) ^ key_l) << 4) + 8 * (cg & 1)) =
-            make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
-      }
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[j][e], raw[j][e] * slope);  // LeakyReLU(0) = 0: the DMA's zero fill stays zero
+      const int key = (prow[j] >> 1) & 7;
+      *reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((cgt >> 1) ^ key) << 4) + 8 * (cgt & 1)) =
+          make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
     }
     report_f16_saturation(f16_sat, p.flags);
   }
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   __syncthreads();  // every wave is done with h
   VFX_TS(10);
 
-  // ---- phase 4: y = conv2 + b2 + x: the accumulators staged in LDS, the kept centre rows added there, whole rows stored -----------
+  // ---- phase 4: y = conv2 + b2 + x: the accumulators staged in LDS, whole rows read back, the kept x rows added, stored ----------
 #pragma unroll
   for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -323,23 +331,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
           f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
     }
   __syncthreads();
-  {
-    // patch row lr + 32 (q0 + j) is the input sample of h pixel m = that row - off: every staged (row, 4 channels) is touched by
-    // exactly one thread
-    const int m0 = lr + (q1 ? RG : 0) - off;
-#pragma unroll
-    for (int j = 0; j < KEEP; ++j)
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        f32x4* s4 = reinterpret_cast<f32x4*>(smem + (m0 + RG * j) * LDO + c * 32 + 4 * cg);
-        *s4 = *s4 + keep[c][j];
-      }
-  }
-  __syncthreads();
-  VFX_TS(11);  // staged + residual added
+  VFX_TS(11);  // staged
   {
     constexpr int V = C / 4, RPP = NTHR / V, NPASS = MT / RPP;  // 32 float4 per row, 8 rows per step, 16 steps
-    const int c4 = tid % V, r0 = tid / V;
+    const int c4 = tid % V, r0 = tid / V;  // = (ct * 8 + cgt, rt) of the transform: keep[q] is x at row r0 + 8 q, channels 4 c4 ..
+    static_assert(V == 32 && RPP == 8 && NPASS == KEEP, "the output pass must walk the rows the transform kept");
     const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
     const float aslope = p.act_slope;
     const bool even = (tid & 1) == 0;
@@ -356,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
       const int pos = base_h + li * rowstride + lj;
       const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
-      const f32x4 val = *reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * c4) + bv;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * c4) + bv + keep[q];  // + x: this thread's own rows
       const unsigned off = (unsigned)(img * T + pos) * (unsigned)(C * 4) + 16u * c4;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ry, (int)(ok ? off : kOob), 0, 0);
       if (p.ya) {

@@ -204,7 +204,10 @@ class _WavWriter:
     being computed."""
 
     def __init__(self, fname, sample_rate=44100):
-        self.f = wave.open(fname, "wb")
+        # like the reference's save_wave at the END of handler(), the output file only changes when the whole file went
+        # through: the segments go to `fname + ".part"`, renamed by close(ok=True), removed otherwise
+        self.fname, self.part = fname, fname + ".part"
+        self.f = wave.open(self.part, "wb")
         self.f.setnchannels(1)
         self.f.setsampwidth(2)
         self.f.setframerate(sample_rate)
@@ -226,19 +229,36 @@ class _WavWriter:
             ev.synchronize()
             self.f.writeframes(host.numpy().tobytes())
 
-    def close(self):
-        self.flush(block=True)
-        self.f.close()
+    def close(self, ok=True):
+        import os
+        try:
+            if ok:
+                self.flush(block=True)
+        finally:
+            self.f.close()
+            if ok:
+                os.replace(self.part, self.fname)
+            elif os.path.exists(self.part):
+                os.remove(self.part)
 
 
-def _finish_file(model, peaks, input, rerun):
-    """The checks of a whole file with ONE device sync: to_log's assert (pytorch_util.py:158) and the 16-bit mode's
-    saturation flag (-> `rerun()` on the split-bf16 twin) from the sticky device flags, the "Exceed energy limit" warning
-    (eval_gsr_voicefixer.py:68-70) from the per-segment peaks."""
-    again = model.engine.check_flags(rerun)
+def _file_flags_ok(model, writer):
+    """The checks of a whole file, once its last segment is enqueued: wait for the device (the writer's last download), then
+    to_log's assert (pytorch_util.py:158; raises -- the output file is not touched, as in the reference where the assert fires
+    before save_wave) and the 16-bit mode's saturation flag from the sticky device flags (-> False: the caller repeats the
+    file on the split-bf16 twin)."""
+    from . import _lib
+    writer.flush(block=True)
+    flags = model.engine.take_flags()
+    if flags & _lib.FLAG_NEGATIVE_INPUT:
+        raise AssertionError("to_log: input has negative values")
+    return not (flags & _lib.FLAG_F16_SATURATED)
+
+
+def _warn_peaks(peaks, input):
+    """eval_gsr_voicefixer.py:68-70's warning, once per file from the per-segment peaks."""
     if peaks and bool((torch.stack(peaks) > 1.0).any()):
         print("Warning: Exceed energy limit,", input)
-    return again
 
 
 def _peak_normalise(out):
@@ -268,6 +288,7 @@ def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=Fals
         peaks = []
         seg_length = 44100 * SEG_SECONDS
         break_point = seg_length
+        done = False
         try:
             while break_point < len(reader) + seg_length:
                 segment = reader.read(seg_length)
@@ -296,20 +317,24 @@ def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=Fals
                 out, _ = trim_center(out, seg_t)
                 writer.put(out[0, 0])
                 break_point += seg_length
+            done = _file_flags_ok(model, writer)
         finally:
             reader.close()
-            writer.close()
-        return peaks
+            writer.close(ok=done)
+        return peaks if done else None
 
     with torch.no_grad():
         peaks = run(model, output)
-
-        def rerun(twin_engine):
+        if peaks is None:
             # the 16-bit vocoder clamped an activation somewhere in this file: the whole file again on split-bf16 operands
-            strict = models.VoiceFixer(model.hp, channels=model.channels, type_target=model.type_target, engine=twin_engine)
-            run(strict, output)
-            twin_engine.check_flags(None)
-        _finish_file(model, peaks, input, rerun)
+            import warnings
+            warnings.warn("16-bit vocoder: an activation left the fp16 range; %s is restored again with split-bf16 operands" % input)
+            strict = models.VoiceFixer(model.hp, channels=model.channels, type_target=model.type_target,
+                                       engine=model.engine.strict_twin())
+            peaks = run(strict, output)
+            if peaks is None:
+                raise RuntimeError("the split-bf16 twin reported a clamped activation")
+        _warn_peaks(peaks, input)
     return metrics
 
 
@@ -326,6 +351,7 @@ def handler_ssr_unet(input, output, target, ckpt, device, needrefresh=False, met
         peaks = []
         seg_length = 44100 * SEG_SECONDS
         break_point = seg_length
+        done = False
         try:
             while break_point < len(reader) + seg_length:
                 segment = reader.read(seg_length)
@@ -347,10 +373,11 @@ def handler_ssr_unet(input, output, target, ckpt, device, needrefresh=False, met
                 out, _ = trim_center(out, seg_t)
                 writer.put(out[0, 0])
                 break_point += seg_length
+            done = _file_flags_ok(model, writer)      # (no fp16 arithmetic on this path: only to_log's assert can fire)
         finally:
             reader.close()
-            writer.close()
-        _finish_file(model, peaks, input, None)
+            writer.close(ok=done)
+        _warn_peaks(peaks, input)
     return metrics
 
 
