@@ -29,6 +29,18 @@ __device__ __forceinline__ unsigned pack_f16x2(float a, float b, bool& sat) {
   sat = sat | (bool)((int)f16_out_of_range(a) | (int)f16_out_of_range(b));
   return pack_f16x2(a, b);
 }
+// The same with the record kept in a VECTOR register: `sat` = max over the converted values of bits(|x|) as an unsigned integer
+// (one v_and per value + one v_max3_u32 per pair).  |x| > 65504, infinities and NaNs all have larger bit patterns than 65504.0f
+// (0x477fe000), so `f16_sat_bits_bad(sat)` is the predicate of f16_out_of_range over everything converted -- without the
+// v_cmp -> s_or chain of the bool form, whose VALU-to-SALU dependency per value made the conversion loops of the 4-wave
+// ResStack kernels issue-latency-bound (round 3, phase stamps: 7 k cycles for 80 values per lane).
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b, unsigned& sat) {
+  const unsigned ua = __builtin_bit_cast(unsigned, a) & 0x7fffffffu, ub = __builtin_bit_cast(unsigned, b) & 0x7fffffffu;
+  sat = max(sat, max(ua, ub));
+  return pack_f16x2(a, b);
+}
+__device__ __forceinline__ bool f16_sat_bits_bad(unsigned sat) { return sat > 0x477fe000u; }
+
 // One atomic per wave that saw a clamp (rare path).
 __device__ __forceinline__ void report_f16_saturation(bool sat, int* flags) {
   if (__any(sat) && flags && (threadIdx.x & 63) == 0) atomicOr(flags, VFX_FLAG_F16_SATURATED);

@@ -26,7 +26,12 @@ namespace {
 constexpr int R128_PR = 160;  // patch rows per chunk buffer
 }
 
-__global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* __restrict__ pp) {
+// PERSIST: a block walks a contiguous range of `per_block` tiles (one block per residency slot: 2 per CU): the parameter loads and
+// the tile-independent index math are paid once, and a tile's output stores drain while the next tile's patch is already
+// requested (round 3, phase stamps of the one-tile-per-block form: 11 % of a block's life before its patch request, 17 % in
+// the output pass at the CU's share of the HBM write bandwidth).  !PERSIST: one tile per block (A/B, VFX_TUNE_NO_PERSISTENT_WIDE).
+template <bool PERSIST>
+__global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* __restrict__ pp, int ntiles, int per_block) {
   constexpr int C = 128, NW = 4, NTHR = NW * 64, MT = 128;
   constexpr int NCH = C / 32;                // 32-channel chunks = waves along the couts
   constexpr int PR = R128_PR;
@@ -46,34 +51,47 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   char* const lds = reinterpret_cast<char*>(smem);
 
   const ResBlockParams& p = *pp;
-  const int tid = threadIdx.x;
-  int tile;
-  {
+  int t_begin, n_mine;
+  if constexpr (PERSIST) {
+    t_begin = blockIdx.x * per_block;
+    n_mine = min(per_block, ntiles - t_begin);
+  } else {
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    t_begin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    n_mine = 1;
   }
-  VFX_TS_DECL;
-  VFX_TS(0);
-  // tile -> (image, tile row, tile column) with the host's reciprocals (plan_resblock): three integer divisions otherwise
-  const int img = (int)(((unsigned long long)(unsigned)tile * p.inv_tiles_per_img) >> 32);
-  const int trem = tile - img * (p.tiles_w * p.tiles_h);
-  const int ti = (int)(((unsigned long long)(unsigned)trem * p.inv_tiles_w) >> 32);
-  const int tj = trem - ti * p.tiles_w;
   const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
   const int rowstride = p.fold ? d : 0;
-  const int j0 = tj * p.TWo;
-  const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
-  const int base_x = base_h - d;                                // position of patch pixel (0, 0)
   const float slope = p.slope;
   // m / W1 and prow / PW as multiply-shift (rows < 512, divisors <= 320: exact; cf. resblock_rw.hip): an integer division is ~25 VALU
   // instructions, a tile has 25 of them per thread
   const unsigned inv_pw = p.inv_pw, inv_w1 = p.inv_w1;
+  const int tiles_w = p.tiles_w, tiles_per_img = p.tiles_w * p.tiles_h, TWo = p.TWo;
+  const unsigned inv_tiles_w = p.inv_tiles_w, inv_tiles_per_img = p.inv_tiles_per_img;
 
+  const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  for (int it = 0; it < n_mine; ++it) {  // ---- one tile -----------------------------------------------------------------------------
+  const int tile = t_begin + it;
+  // everything a thread derives from its id is re-derived per tile behind an opaque statement: hoisted out of the tile loop, the
+  // per-lane addresses and masks of all phases would be live across it (38 spilled registers)
+  int tid_i = threadIdx.x;
+  asm volatile("" : "+v"(tid_i));
+  const int tid = tid_i;
   const int lr = tid >> 3, cg = tid & 7;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int l31 = lane & 31, lh = lane >> 5;
+  VFX_TS_DECL;
+  VFX_TS(0);
+  // tile -> (image, tile row, tile column) with the host's reciprocals (plan_resblock): three integer divisions otherwise
+  const int img = (int)(((unsigned long long)(unsigned)tile * inv_tiles_per_img) >> 32);
+  const int trem = tile - img * tiles_per_img;
+  const int ti = (int)(((unsigned long long)(unsigned)trem * inv_tiles_w) >> 32);
+  const int tj = trem - ti * tiles_w;
+  const int j0 = tj * TWo;
+  const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
+  const int base_x = base_h - d;                                // position of patch pixel (0, 0)
 
   // ---- the raw x patch: every chunk at once ---------------------------------------------------------------------------------
   {
@@ -175,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   constexpr int NROW = PR / 8;      // rows per thread: 16 centre + 4 halo
   f32x4 keep[KEEP];
   {
-    bool f16_sat = false;
+    unsigned f16_sat = 0;
     char* const cb = lds + ct * PBYTES + 16 * cgt;
     int prow[NROW];
 #pragma unroll
@@ -197,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       *reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((cgt >> 1) ^ key) << 4) + 8 * (cgt & 1)) =
           make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
     }
-    report_f16_saturation(f16_sat, p.flags);
+    report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
   }
   VFX_TS(3);  // transformed
   __syncthreads();  // the operand rows of every wave are visible
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   // Lane (l31, lh) of position block a holds h pixel m = a*32 + l31 and, in registers 4j .. 4j+3, channels w*32 + 8j + 4lh .. +3:
   // chunk w of the pixel's row, piece j, half lh.
   {
-    bool f16_sat = false;
+    unsigned f16_sat = 0;
     f32x4 b1v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) b1v[j] = *(const VFX_GLOBAL f32x4*)(p.b1 + wave_u * 32 + 8 * j + 4 * lh);
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1], f16_sat), pack_f16x2(u[2], u[3], f16_sat));
       }
     }
-    report_f16_saturation(f16_sat, p.flags);
+    report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
   }
   VFX_TS(7);  // h written
   __syncthreads();  // h is complete
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
     const float aslope = p.act_slope;
     const bool even = (tid & 1) == 0;
-    bool ya_sat = false;
+    unsigned ya_sat = 0;
     // y and ya through buffer descriptors: 32-bit offsets, and a masked row is an offset beyond the bound (its stores are dropped)
     // -- no exec-mask juggling around 16 (+ 16) stores per thread
     constexpr unsigned kOob = 0xfffffff0u;  // beyond every descriptor (plan_resblock: tensors < 4 GiB - 4096); nothing is added to it
@@ -368,10 +386,12 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)((ok && even) ? off / 2 : kOob), 0, 0);
       }
     }
-    if (p.ya) report_f16_saturation(ya_sat, p.flags);
+    if (p.ya) report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
   }
   VFX_TS(12);  // stores issued
   VFX_TS_FLUSH(p.timing, tile, wave_u, NW);
+  if constexpr (PERSIST) __syncthreads();  // every wave has read the staged tile: the next tile's patch may overwrite it
+  }  // tile loop
 }
 
 int resblock_r128_patch_rows() { return R128_PR; }
@@ -390,9 +410,17 @@ void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparam
   static_assert((128 / 32) * R128_PR * CROW >= 128 * (128 + 4) * 4 && (128 / 32) * R128_PR * CROW >= 128 * 128 * 4, "overlays must fit");
   static uint64_t attr_devices = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL(k_resblock_r128, dim3((int)grid), dim3(256), lds, stream, dparams);
+  if (hp.tuning & VFX_TUNE_NO_PERSISTENT_WIDE) {
+    hipLaunchKernelGGL(k_resblock_r128<false>, dim3((int)grid), dim3(256), lds, stream, dparams, (int)grid, 1);
+  } else {
+    const int slots = cu_count_of_current_device() * 2;  // two blocks per CU (LDS, 256 registers per wave)
+    const int per_block = (int)((grid + slots - 1) / slots);
+    const int nblocks = (int)((grid + per_block - 1) / per_block);
+    hipLaunchKernelGGL(k_resblock_r128<true>, dim3(nblocks), dim3(256), lds, stream, dparams, (int)grid, per_block);
+  }
   VFX_HIP(hipGetLastError());
 }
 
