@@ -56,8 +56,7 @@ enum {
   VFX_TUNE_NO_PAIRS = 16,          /* 16-bit mode, C = 64: one launch per layer (no layer pairs) */
   VFX_TUNE_NO_SPLITK = 32,         /* no split-K in the deep ResUNet levels */
   VFX_TUNE_WIDE_8WAVE = 64,        /* C = 256 layers on the 8-wave / one-block-per-CU kernel (resblock_act.hip) */
-  VFX_TUNE_C128_8WAVE = 128,       /* 16-bit mode, C = 128 layers on k_resblock<128, 8> (re-reads the residual) */
-  VFX_TUNE_NO_PERSISTENT_WIDE = 256 /* the 4-wave C = 128 / 256 kernels with one tile per block instead of a tile range */
+  VFX_TUNE_C128_8WAVE = 128        /* 16-bit mode, C = 128 layers on k_resblock<128, 8> (re-reads the residual) */
 };
 
 typedef struct vfx_config {

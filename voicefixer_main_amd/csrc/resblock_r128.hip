@@ -26,12 +26,7 @@ namespace {
 constexpr int R128_PR = 160;  // patch rows per chunk buffer
 }
 
-// PERSIST: a block walks a contiguous range of `per_block` tiles (one block per residency slot: 2 per CU): the parameter loads and
-// the tile-independent index math are paid once, and a tile's output stores drain while the next tile's patch is already
-// requested (round 3, phase stamps of the one-tile-per-block form: 11 % of a block's life before its patch request, 17 % in
-// the output pass at the CU's share of the HBM write bandwidth).  !PERSIST: one tile per block (A/B, VFX_TUNE_NO_PERSISTENT_WIDE).
-template <bool PERSIST>
-__global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* __restrict__ pp, int ntiles, int per_block) {
+__global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* __restrict__ pp) {
   constexpr int C = 128, NW = 4, NTHR = NW * 64, MT = 128;
   constexpr int NCH = C / 32;                // 32-channel chunks = waves along the couts
   constexpr int PR = R128_PR;
@@ -51,47 +46,34 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   char* const lds = reinterpret_cast<char*>(smem);
 
   const ResBlockParams& p = *pp;
-  int t_begin, n_mine;
-  if constexpr (PERSIST) {
-    t_begin = blockIdx.x * per_block;
-    n_mine = min(per_block, ntiles - t_begin);
-  } else {
+  const int tid = threadIdx.x;
+  int tile;
+  {
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    t_begin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    n_mine = 1;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  VFX_TS_DECL;
+  VFX_TS(0);
+  // tile -> (image, tile row, tile column) with the host's reciprocals (plan_resblock): three integer divisions otherwise
+  const int img = (int)(((unsigned long long)(unsigned)tile * p.inv_tiles_per_img) >> 32);
+  const int trem = tile - img * (p.tiles_w * p.tiles_h);
+  const int ti = (int)(((unsigned long long)(unsigned)trem * p.inv_tiles_w) >> 32);
+  const int tj = trem - ti * p.tiles_w;
   const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
   const int rowstride = p.fold ? d : 0;
+  const int j0 = tj * p.TWo;
+  const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
+  const int base_x = base_h - d;                                // position of patch pixel (0, 0)
   const float slope = p.slope;
   // m / W1 and prow / PW as multiply-shift (rows < 512, divisors <= 320: exact; cf. resblock_rw.hip): an integer division is ~25 VALU
   // instructions, a tile has 25 of them per thread
   const unsigned inv_pw = p.inv_pw, inv_w1 = p.inv_w1;
-  const int tiles_w = p.tiles_w, tiles_per_img = p.tiles_w * p.tiles_h, TWo = p.TWo;
-  const unsigned inv_tiles_w = p.inv_tiles_w, inv_tiles_per_img = p.inv_tiles_per_img;
 
-  const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-  for (int it = 0; it < n_mine; ++it) {  // ---- one tile -----------------------------------------------------------------------------
-  const int tile = t_begin + it;
-  // everything a thread derives from its id is re-derived per tile behind an opaque statement: hoisted out of the tile loop, the
-  // per-lane addresses and masks of all phases would be live across it (38 spilled registers)
-  int tid_i = threadIdx.x;
-  asm volatile("" : "+v"(tid_i));
-  const int tid = tid_i;
   const int lr = tid >> 3, cg = tid & 7;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int l31 = lane & 31, lh = lane >> 5;
-  VFX_TS_DECL;
-  VFX_TS(0);
-  // tile -> (image, tile row, tile column) with the host's reciprocals (plan_resblock): three integer divisions otherwise
-  const int img = (int)(((unsigned long long)(unsigned)tile * inv_tiles_per_img) >> 32);
-  const int trem = tile - img * tiles_per_img;
-  const int ti = (int)(((unsigned long long)(unsigned)trem * inv_tiles_w) >> 32);
-  const int tj = trem - ti * tiles_w;
-  const int j0 = tj * TWo;
-  const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
-  const int base_x = base_h - d;                                // position of patch pixel (0, 0)
 
   // ---- the raw x patch: every chunk at once ---------------------------------------------------------------------------------
   {
@@ -390,8 +372,6 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   }
   VFX_TS(12);  // stores issued
   VFX_TS_FLUSH(p.timing, tile, wave_u, NW);
-  if constexpr (PERSIST) __syncthreads();  // every wave has read the staged tile: the next tile's patch may overwrite it
-  }  // tile loop
 }
 
 int resblock_r128_patch_rows() { return R128_PR; }
@@ -410,17 +390,9 @@ void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparam
   static_assert((128 / 32) * R128_PR * CROW >= 128 * (128 + 4) * 4 && (128 / 32) * R128_PR * CROW >= 128 * 128 * 4, "overlays must fit");
   static uint64_t attr_devices = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  if (hp.tuning & VFX_TUNE_NO_PERSISTENT_WIDE) {
-    hipLaunchKernelGGL(k_resblock_r128<false>, dim3((int)grid), dim3(256), lds, stream, dparams, (int)grid, 1);
-  } else {
-    const int slots = cu_count_of_current_device() * 2;  // two blocks per CU (LDS, 256 registers per wave)
-    const int per_block = (int)((grid + slots - 1) / slots);
-    const int nblocks = (int)((grid + per_block - 1) / per_block);
-    hipLaunchKernelGGL(k_resblock_r128<true>, dim3(nblocks), dim3(256), lds, stream, dparams, (int)grid, per_block);
-  }
+  hipLaunchKernelGGL(k_resblock_r128, dim3((int)grid), dim3(256), lds, stream, dparams);
   VFX_HIP(hipGetLastError());
 }
 
