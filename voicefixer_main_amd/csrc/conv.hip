@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     const float pslope = S.slope;
     char* row0 = lds + dst + lr * CROW;
     f32x4 raw[CNQ];
-    bool f16_sat = false;  // 16-bit mode: a value left the fp16 range and was clamped (reported per patch: no loop-carried state)
+    unsigned f16_sat = 0;  // 16-bit mode: a value left the fp16 range and was clamped (reported per patch: no loop-carried state)
 #pragma unroll
     for (int q = 0; q < CNQ; ++q)
       if (q < 4 || q < nq) raw[q] = *reinterpret_cast<const f32x4*>(row0 + 32 * q * CROW + 16 * cg);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
           *reinterpret_cast<f32x4*>(rowp + ((cg ^ keyq[q]) << 4)) = v;
         }
       }
-    if constexpr (SPLIT && HI) report_f16_saturation(f16_sat, p.flags);
+    if constexpr (SPLIT && HI) report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
   };
 
   // `tap` = ConvStage::poff entry: patch row offset of the tap in bits 0..15, its column shift in 16..23, row shift in 24..31

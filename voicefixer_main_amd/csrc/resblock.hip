@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
       psh = *(const VFX_GLOBAL f32x4*)(p.sh1 + c * kKC + 4 * cg);
     }
     f32x4 raw[NG];
-    bool f16_sat = false;  // 16-bit mode: a value left the fp16 range and was clamped (reported per patch)
+    unsigned f16_sat = 0;  // 16-bit mode: a value left the fp16 range and was clamped (reported per patch)
 #pragma unroll
     for (int q = 0; q < NG; ++q)
       if (q * RG < 128 || q < nq) {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
         *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ keyq[q]) << 4) + half) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ keyq[q]) << 4) + half) = make_uint2(l01, l23);
       }
-    if constexpr (HI) report_f16_saturation(f16_sat, p.flags);
+    if constexpr (HI) report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
   };
 
   // ---- MFMA step: 32 channels of one tap; A rows `row[a]` of an LDS image with `stride` bytes per row ------
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
   // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------
   // Lane (l31, lh) of M block a holds h pixel m = (wm*WM + a)*32 + l31 and, in registers 4j .. 4j+3, channels
   // wn*32 + 8j + 4lh .. +3: their 4 hi bf16 are half `lh` of piece j of the pixel's chunk row, the 4 lo of piece j+4.
-  bool f16_sat = false;  // 16-bit mode: a value of h left the fp16 range and was clamped
+  unsigned f16_sat = 0;  // 16-bit mode: a value of h left the fp16 range and was clamped
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
     const int m = (wm * WM + a) * 32 + l31;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
       *reinterpret_cast<uint2*>(rowp + (((j + 4) ^ key) << 4)) = make_uint2(l01, l23);
     }
   }
-  if constexpr (HI) report_f16_saturation(f16_sat, p.flags);
+  if constexpr (HI) report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
   __syncthreads();  // h is complete
 
   // ---- phase 3: conv2 from the resident h ------------------------------------------------------------------
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
       if (p.ya) {
         const float aslope = p.act_slope;
         const bool even = (tid & 1) == 0;
-        bool f16_sat = false;
+        unsigned f16_sat = 0;
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {
           f32x4 u;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
           if (opix[q] >= 0 && even)
             *(VFX_GLOBAL f32x4*)(p.ya + (int64_t)opix[q] * (C / 2) + 2 * c4) = __builtin_bit_cast(f32x4, w);
         }
-        report_f16_saturation(f16_sat, p.flags);
+        report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
       }
     }
   }

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     }
   };
   // raw row -> LeakyReLU -> fp16 -> this thread's 8 bytes of the patch row: piece cg >> 1 (8 channels) at slot piece ^ key
-  auto to_patch = [&](char* patch, const f32x4& raw, int pr, bool& sat) __attribute__((always_inline)) {
+  auto to_patch = [&](char* patch, const f32x4& raw, int pr, unsigned& sat) __attribute__((always_inline)) {
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[e], raw[e] * slope);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       }
     // h = LeakyReLU(conv1 + b1) as fp16 operands, zero outside the sequence
     {
-      bool sat = false;
+      unsigned sat = 0;
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
         const int m = (wm * WM + a) * 32 + l31_v;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
           *reinterpret_cast<uint2*>(rowp + (((wn * 4 + j) ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1], sat), pack_f16x2(u[2], u[3], sat));
         }
       }
-      report_f16_saturation(sat, p.flags);
+      report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
     }
     __syncthreads();  // h is complete
     // conv2 from the resident h
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     // ---- the landed patch: to LDS as operands; its centre stays as the residual --------------------------------------
     f32x4 K[NCQ];
     {
-      bool sat = false;
+      unsigned sat = 0;
 #pragma unroll
       for (int q = 0; q < NCQ; ++q) {
         K[q] = PC[q];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
 #pragma unroll
       for (int q = 0; q < NHQ; ++q)
         if (hrow(q) < P) to_patch(lds + R0, PH[q], hrow(q), sat);
-      report_f16_saturation(sat, p.flags);
+      report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
     }
     __syncthreads();  // the patch is complete
     if (t + 1 < t_end) request(t + 1);  // lands while this tile is computed and stored
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       // first layer's outputs are m = 1 .. MT-2, the second one's h is right for m = 1+d2 .. MT-2-d2, its outputs for
       // m = 2+d2 .. MT-3-d2 (the MT - 4 - 2 d2 positions a tile advances by).  Outside the sequence y1 is zero (the padding
       // of the second layer's conv1).
-      bool sat = false;
+      unsigned sat = 0;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         stage(half);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         }
         __syncthreads();  // the staged half has been read (second half: the second patch is complete)
       }
-      report_f16_saturation(sat, p.flags);
+      report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
       layer(std::true_type{}, arow1, base_h);
       b2v = *reinterpret_cast<const f32x4*>(b1s + 3 * C + 4 * cg);
     }
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       float* yi = p.y + (int64_t)img * T * C + 4 * cg;
       const bool even = (tid & 1) == 0;
       const float aslope = p.act_slope;
-      bool sat = false;
+      unsigned sat = 0;
 #pragma unroll
       for (int half = 0; half < NHALF; ++half) {
         stage(half);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         }
         __syncthreads();  // the staged rows have been read: the next half / the next patch may overwrite them
       }
-      if (p.ya) report_f16_saturation(sat, p.flags);
+      if (p.ya) report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
     }
   }
 }
