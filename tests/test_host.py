@@ -396,3 +396,18 @@ def test_profile_kernel_names():
     assert short(ns + "k_resblock<32, 2, false, true>(vfx::ResBlockParams const*)") == "k_resblock<32, 2>"
     assert short(ns + "k_resblock<128, 8, true, false>(vfx::ResBlockParams const*)") == "k_resblock<128, 8> f16"
     assert short(ns + "k_stft_mel<false>(float const*, int)") == "k_stft_mel<false>"
+
+
+def test_fragment_reads_of_2d_tiles_are_conflict_free_with_the_2d_key():
+    """scripts/lds_conflicts_conv.py models the ds_read_b128 lane groups of gfx950: the 2-D swizzle key k_conv / k_resblock use
+    on 2-D tiles must give one LDS cycle per group for every tile shape plan_conv can pick and every tap, and the row-linear key
+    (kept for 1-D patches only) must not be better anywhere."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import lds_conflicts_conv as m
+    for th, tw in ((8, 16), (16, 8), (24, 4), (32, 4), (8, 2), (64, 2), (4, 32), (2, 64)):
+        avg2, worst2 = m.tile_cost(th, tw, m.key_2d)
+        avg1, _ = m.tile_cost(th, tw, m.key_1d)
+        assert worst2 == 1 and avg2 == 1.0, (th, tw, avg2, worst2)
+        assert avg1 >= avg2
+    assert m.tile_cost(16, 8, m.key_1d)[0] == 3.0   # what levels 2-4 paid before the BN = 128 tile took the 2-D key
+    assert m.tile_cost(1, 128, m.key_2d) == (1.0, 1)  # a 1-D patch: the 2-D key is the row-linear one

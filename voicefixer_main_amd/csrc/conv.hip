@@ -125,9 +125,11 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   // Swizzle key of patch pixel (pi, pj): ((pj >> 1) + (TW / 2) * pi) & 7.  With an even patch width the bank half of
   // LDS row pi*PW + pj is pj & 1, and the 16 lanes of a ds_read_b128 group -- runs of consecutive columns in TW-wide
   // tile rows -- get 16 distinct (bank half, slot) pairs for every tap shift; for a 1-D patch this is (row >> 1) & 7.
-  // The BN = 128 tile (dominated by the vocoder's 1-D layers, and short of registers) keeps the 1-D form
-  // (LDS row >> 1) & 7: cheaper per tap, 2-way conflicts on the 2-D levels it also serves.
-  constexpr bool SWZ2D = BN <= 64;
+  // The 16-bit BN = 128 tile (the vocoder's 1-D layers only, three blocks per CU: short of registers) keeps the 1-D form
+  // (LDS row >> 1) & 7, cheaper per tap.  The split / fp32 BN = 128 tile serves ResUNet levels 2 and 3 on 16 x 8 tiles,
+  // where the 1-D key makes EVERY fragment read a 3-way conflict (scripts/lds_conflicts_conv.py; PMC: 64 % of the LDS
+  // cycles) -- a wave of this tile reads all 128 pixel fragments per K step, 85 B/clk/CU at full MFMA rate before conflicts.
+  constexpr bool SWZ2D = BN <= 64 || !HI;
   const int hTW = p.TW >> 1;
   int keyq[CNQ];  // key of this thread's patch pixels lr + 32q
 #pragma unroll
