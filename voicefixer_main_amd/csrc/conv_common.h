@@ -42,8 +42,16 @@ __device__ __forceinline__ unsigned pack_f16x2(float a, float b, unsigned& sat) 
 __device__ __forceinline__ bool f16_sat_bits_bad(unsigned sat) { return sat > 0x477fe000u; }
 
 // One atomic per wave that saw a clamp (rare path).
+// The atomic goes through a GLOBAL-address-space pointer on purpose.  atomicOr on a generic `int*` is a flat_atomic_or, and
+// the compiler's wait-count insertion treats a FLAT operation as one that may complete out of order on vmcnt AND lgkmcnt:
+// until it sees a vmcnt(0) of its own -- never, in kernels whose vmcnt waits are hand-counted inline asm -- it turns every
+// later "s_waitcnt lgkmcnt(N)" into lgkmcnt(0), i.e. a software-pipelined fragment read is waited for right after it is
+// issued (found on the gfx950 assembly of resblock_r128 / resblock_w64: 59 of 74 LDS waits behind the first report were 0).
+__device__ __forceinline__ void or_flag_global(int* flags, int bits) {
+  __hip_atomic_fetch_or((__attribute__((address_space(1))) int*)flags, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void report_f16_saturation(bool sat, int* flags) {
-  if (__any(sat) && flags && (threadIdx.x & 63) == 0) atomicOr(flags, VFX_FLAG_F16_SATURATED);
+  if (__any(sat) && flags && (threadIdx.x & 63) == 0) or_flag_global(flags, VFX_FLAG_F16_SATURATED);
 }
 
 // Phase stamps of the timing builds (-DVFX_TIMING; the shipped build compiles them away): lane 0 of every wave keeps

@@ -148,7 +148,7 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
         if (opix[q] >= 0 && !(SPLIT && f16 && !even)) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * astride + aoff) = o;
       }
       if constexpr (SPLIT) {
-        if (f16 && __any(f16_sat) && p.flags && (tid & 63) == 0) atomicOr(p.flags, VFX_FLAG_F16_SATURATED);
+        if (f16 && __any(f16_sat) && p.flags && (tid & 63) == 0) or_flag_global(p.flags, VFX_FLAG_F16_SATURATED);
       }
     }
   }

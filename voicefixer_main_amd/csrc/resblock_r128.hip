@@ -10,8 +10,10 @@
 // that it fetched for the patch (64 registers; a block is 4 waves = one per SIMD with 256 registers each) and adds them to the
 // staged conv2 result in LDS: the epilogue issues no load at all.  The rest follows resblock_w64.hip: the raw patch (4 chunks of
 // 32 channels x 160 rows x 128 B = 80 KB = half a CU's LDS, so two blocks share a CU and the memory phases of one run under the
-// arithmetic of the other) arrives in ONE LDS-DMA round trip and is turned into fp16 operand rows in place; a wave owns 32 couts x
-// all 128 positions (a weight fragment feeds four MFMAs and is fetched once per tile); the weight ring runs three taps ahead (a
+// arithmetic of the other) arrives in ONE LDS-DMA round trip and is turned into fp16 operand rows in place; a wave owns 64 couts x
+// 64 positions: a pixel fragment (1 KB from LDS) feeds TWO MFMAs and a weight fragment two -- with 32 couts x 128 positions per
+// wave every MFMA took its own pixel fragment, 128 B/clk/CU at full MFMA rate = all the LDS can deliver, and the convolution
+// phases ran 2.3x their MFMA time (phase stamps, profiles/r03_phase_timing_*.txt).  The weight ring runs three taps ahead (a
 // tap is only 8 MFMAs here); the pixel fragments are software-pipelined one K step ahead; no scheduling barriers and no memory
 // clobbers in the compute phases.
 //
@@ -33,9 +35,9 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   constexpr int PBYTES = PR * CROW;
   constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
   constexpr int NG = PR / RG;                // DMA instructions per wave and chunk (5)
-  static_assert(PR % RG == 0 && (RG / 2) % 8 == 0 && NCH == NW, "geometry");
-  constexpr int WM = MT / 32;                // 32-position blocks per wave
-  constexpr int WL = 2;                      // weight loads per tap and wave (the hi fragments f[0], f[2])
+  static_assert(PR % RG == 0 && (RG / 2) % 8 == 0 && NCH == 4 && NW == 4, "geometry");
+  constexpr int WM = 2, WN = 2;              // 32-position blocks / 32-cout blocks per wave: 64 positions x 64 couts
+  constexpr int WL = 2 * WN;                 // weight loads per tap and wave (the hi fragments f[0], f[2] of two cout blocks)
   constexpr int RING = 4, AHEAD = RING - 1;  // weight taps in flight: a tap is 8 MFMAs (256 cycles), an L2 round trip ~3 of them
   constexpr int HROW = C * 4;                // bytes per h row (operand form: 128-byte chunk rows, fp16 in the first half)
   constexpr int NT1 = 3 * NCH;               // taps of conv1 (chunk-major); conv2 has as many
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int l31 = lane & 31, lh = lane >> 5;
+  const int wn = wave_u & 1, wm = wave_u >> 1;  // cout half / position half of this wave
 
   // ---- the raw x patch: every chunk at once ---------------------------------------------------------------------------------
   {
@@ -106,52 +109,59 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   bool hval[WM];   // that h pixel lies inside the tile's h grid and inside the sequence
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
-    const int ml = a * 32 + l31;
+    const int ml = wm * 64 + a * 32 + l31;
     const int li = (int)(((unsigned)ml * inv_w1) >> 20), lj = ml - li * W1;
     arow1[a] = li < TH ? li * PW + lj : 0;
     const int pos = base_h + li * rowstride + lj;
     hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
   }
-  // weights: (32-channel chunk, tap) blocks of C / 32 cout blocks x 1024 floats; this wave's cout block is w
-  const unsigned nb_off = (unsigned)(wave_u * 1024 + lane * 4) * 4u;
+  // weights: (32-channel chunk, tap) blocks of C / 32 cout blocks x 1024 floats; this wave's cout blocks are 2 wn, 2 wn + 1
+  const unsigned nb_off = (unsigned)(2 * wn * 1024 + lane * 4) * 4u;
+  const unsigned nb_off2 = nb_off + 4096u;
   const int64_t ts = (int64_t)C * kKC;
   const float* const w1p = p.w1;
   const float* const w2p = p.w2;
   const int poff0 = p.poff[0], poff1 = p.poff[1], poff2 = p.poff[2];
 
-  f32x16 acc[WM];
+  f32x16 acc[WN][WM];
 #pragma unroll
-  for (int a = 0; a < WM; ++a)
+  for (int n = 0; n < WN; ++n)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][a][r] = 0.f;
 
   // ---- weight ring: global tap g in register pair g % RING, AHEAD taps ahead (no "memory" clobbers in the compute phases) -------
-  f32x4 Wa0 = {}, Wb0 = {}, Wa1 = {}, Wb1 = {}, Wa2 = {}, Wb2 = {}, Wa3 = {}, Wb3 = {};  // (k 0..15, k 16..31) of ring slot 0..3
-  auto load_w = [&](f32x4& A, f32x4& B, const float* wtap) __attribute__((always_inline)) {
+  // ring slot s: (k 0..15, k 16..31) of cout block 2 wn in Wa, Wb and of cout block 2 wn + 1 in Wc, Wd
+  f32x4 Wa0 = {}, Wb0 = {}, Wc0 = {}, Wd0 = {}, Wa1 = {}, Wb1 = {}, Wc1 = {}, Wd1 = {};
+  f32x4 Wa2 = {}, Wb2 = {}, Wc2 = {}, Wd2 = {}, Wa3 = {}, Wb3 = {}, Wc3 = {}, Wd3 = {};
+  auto load_w = [&](f32x4& A, f32x4& B, f32x4& Cc, f32x4& D, const float* wtap) __attribute__((always_inline)) {
     asm volatile(
         "s_nop 4\n\t"
-        "global_load_dwordx4 %0, %2, %3\n\t"
-        "global_load_dwordx4 %1, %2, %3 offset:2048"
-        : "=&v"(A), "=&v"(B)
-        : "v"(nb_off), "s"(wtap));
+        "global_load_dwordx4 %0, %4, %6\n\t"
+        "global_load_dwordx4 %1, %4, %6 offset:2048\n\t"
+        "global_load_dwordx4 %2, %5, %6\n\t"
+        "global_load_dwordx4 %3, %5, %6 offset:2048"
+        : "=&v"(A), "=&v"(B), "=&v"(Cc), "=&v"(D)
+        : "v"(nb_off), "v"(nb_off2), "s"(wtap));
   };
   auto fetch = [&](int g) __attribute__((always_inline)) {
     const float* w = g < NT1 ? w1p + g * ts : w2p + (g - NT1) * ts;
     switch (g % RING) {
-      case 0: load_w(Wa0, Wb0, w); break;
-      case 1: load_w(Wa1, Wb1, w); break;
-      case 2: load_w(Wa2, Wb2, w); break;
-      default: load_w(Wa3, Wb3, w); break;
+      case 0: load_w(Wa0, Wb0, Wc0, Wd0, w); break;
+      case 1: load_w(Wa1, Wb1, Wc1, Wd1, w); break;
+      case 2: load_w(Wa2, Wb2, Wc2, Wd2, w); break;
+      default: load_w(Wa3, Wb3, Wc3, Wd3, w); break;
     }
   };
   // The registers of a ring slot are readable behind this statement (a counted s_waitcnt precedes it in program order: asm
   // volatile statements keep their order); every reader depends on its outputs.
   auto use_slot = [&](int s) __attribute__((always_inline)) {
     switch (s) {
-      case 0: asm volatile("" : "+v"(Wa0), "+v"(Wb0)); break;
-      case 1: asm volatile("" : "+v"(Wa1), "+v"(Wb1)); break;
-      case 2: asm volatile("" : "+v"(Wa2), "+v"(Wb2)); break;
-      default: asm volatile("" : "+v"(Wa3), "+v"(Wb3)); break;
+      case 0: asm volatile("" : "+v"(Wa0), "+v"(Wb0), "+v"(Wc0), "+v"(Wd0)); break;
+      case 1: asm volatile("" : "+v"(Wa1), "+v"(Wb1), "+v"(Wc1), "+v"(Wd1)); break;
+      case 2: asm volatile("" : "+v"(Wa2), "+v"(Wb2), "+v"(Wc2), "+v"(Wd2)); break;
+      default: asm volatile("" : "+v"(Wa3), "+v"(Wb3), "+v"(Wc3), "+v"(Wd3)); break;
     }
   };
 
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     asm volatile("" : "+v"(lrow));
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
-      const int r0 = a * 32 + lrow + k - 1;
+      const int r0 = wm * 64 + a * 32 + lrow + k - 1;
       const int row = r0 < 0 ? 0 : (r0 > MT - 1 ? MT - 1 : r0);  // clamped rows only feed outputs that are masked anyway
       rb[g & 1][a] = row * HROW + (c ^ (row & 1)) * CROW;
       kx[g & 1][a] = swz_key(row) ^ (16 * lh);
@@ -235,16 +245,18 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   };
   // K step st (0, 1) of tap g: D = W (A operand: rows = couts) x image rows (B operand: columns = pixels)
   auto mm = [&](const f16x8 (&px)[WM], int g, int st) __attribute__((always_inline)) {
-    f32x4 w;
+    f32x4 w0, w1;
     switch (g % RING) {
-      case 0: w = st ? Wb0 : Wa0; break;
-      case 1: w = st ? Wb1 : Wa1; break;
-      case 2: w = st ? Wb2 : Wa2; break;
-      default: w = st ? Wb3 : Wa3; break;
+      case 0: w0 = st ? Wb0 : Wa0; w1 = st ? Wd0 : Wc0; break;
+      case 1: w0 = st ? Wb1 : Wa1; w1 = st ? Wd1 : Wc1; break;
+      case 2: w0 = st ? Wb2 : Wa2; w1 = st ? Wd2 : Wc2; break;
+      default: w0 = st ? Wb3 : Wa3; w1 = st ? Wd3 : Wc3; break;
     }
-    const f16x8 wf = __builtin_bit_cast(f16x8, w);
+    const f16x8 wf0 = __builtin_bit_cast(f16x8, w0), wf1 = __builtin_bit_cast(f16x8, w1);
 #pragma unroll
-    for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, px[a], acc[a], 0, 0, 0);
+    for (int a = 0; a < WM; ++a) acc[0][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, px[a], acc[0][a], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < WM; ++a) acc[1][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, px[a], acc[1][a], 0, 0, 0);
   };
   // taps g0 .. g1-1 of one convolution; `more`: the launch has taps behind g1 (conv1: conv2's), fetched ahead from here
   auto conv = [&](auto prep, int g0, int g1, bool more) __attribute__((always_inline)) {
@@ -257,24 +269,24 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       // fetch tap g + AHEAD if it exists; then tap g's loads are older than the fetches issued after them
       const int younger = (g + AHEAD < gmax ? AHEAD : gmax - 1 - g);
       if (g + AHEAD < gmax) fetch(g + AHEAD);
-      if (younger == 3) asm volatile("s_waitcnt vmcnt(6)");
-      else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)");
+      if (younger == 3) asm volatile("s_waitcnt vmcnt(12)");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)");
       else asm volatile("s_waitcnt vmcnt(0)");
       use_slot(g % RING);
       if (g + 1 < g1) prep(g + 1);
       // step 0 (fragments in pxE): read step 1 of this tap; step 1 (pxO): read step 0 of the next tap
-      // (the four reads of the next step FIRST, then this step's four MFMAs: a step is only 128 cycles, about one LDS latency --
+      // (the two reads of the next step FIRST, then this step's four MFMAs: a step is only 128 cycles, about one LDS latency --
       // interleaved one by one, the youngest read would be 32 cycles old when the next step waits for it)
       rd(pxO, g, 1);
       mm(pxE, g, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, WM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, WM * WN, 0);
       const bool last = g + 1 == g1;
       if (!last) rd(pxE, g + 1, 0);
       mm(pxO, g, 1);
       if (!last) __builtin_amdgcn_sched_group_barrier(0x100, WM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, WM * WN, 0);
     }
   };
 
@@ -285,28 +297,32 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   VFX_TS(6);
 
   // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------------------------
-  // Lane (l31, lh) of position block a holds h pixel m = a*32 + l31 and, in registers 4j .. 4j+3, channels w*32 + 8j + 4lh .. +3:
-  // chunk w of the pixel's row, piece j, half lh.
+  // Lane (l31, lh) of position block a holds h pixel m = 64 wm + 32 a + l31 and, in registers 4j .. 4j+3 of cout block n, channels
+  // (2 wn + n) * 32 + 8j + 4lh .. +3: chunk 2 wn + n of the pixel's row, piece j, half lh.
   {
     unsigned f16_sat = 0;
-    f32x4 b1v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b1v[j] = *(const VFX_GLOBAL f32x4*)(p.b1 + wave_u * 32 + 8 * j + 4 * lh);
+    for (int n = 0; n < WN; ++n) {
+      const int ch = 2 * wn + n;
+      f32x4 b1v[4];
 #pragma unroll
-    for (int a = 0; a < WM; ++a) {
-      const int m = a * 32 + l31;
-      char* rowp = lds + m * HROW + (wave_u ^ (m & 1)) * CROW + 8 * lh;  // chunk parity swap: see prep2()
-      const int key = (m >> 1) & 7;
+      for (int j = 0; j < 4; ++j) b1v[j] = *(const VFX_GLOBAL f32x4*)(p.b1 + ch * 32 + 8 * j + 4 * lh);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 u;
+      for (int a = 0; a < WM; ++a) {
+        const int m = wm * 64 + a * 32 + l31;
+        char* rowp = lds + m * HROW + (ch ^ (m & 1)) * CROW + 8 * lh;  // chunk parity swap: see prep2()
+        const int key = (m >> 1) & 7;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = acc[a][4 * j + e] + b1v[j][e];
-          u[e] = hval[a] ? fmaxf(t, t * slope) : 0.f;
-          acc[a][4 * j + e] = 0.f;
+        for (int j = 0; j < 4; ++j) {
+          f32x4 u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = acc[n][a][4 * j + e] + b1v[j][e];
+            u[e] = hval[a] ? fmaxf(t, t * slope) : 0.f;
+            acc[n][a][4 * j + e] = 0.f;
+          }
+          *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1], f16_sat), pack_f16x2(u[2], u[3], f16_sat));
         }
-        *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1], f16_sat), pack_f16x2(u[2], u[3], f16_sat));
       }
     }
     report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
@@ -323,13 +339,15 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 
   // ---- phase 4: y = conv2 + b2 + x: the accumulators staged in LDS, whole rows read back, the kept x rows added, stored ----------
 #pragma unroll
-  for (int a = 0; a < WM; ++a)
+  for (int n = 0; n < WN; ++n)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = a * 32 + l31;
-      *reinterpret_cast<f32x4*>(smem + row * LDO + wave_u * 32 + 8 * j + 4 * lh) =
-          f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
-    }
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wm * 64 + a * 32 + l31;
+        *reinterpret_cast<f32x4*>(smem + row * LDO + (2 * wn + n) * 32 + 8 * j + 4 * lh) =
+            f32x4{acc[n][a][4 * j], acc[n][a][4 * j + 1], acc[n][a][4 * j + 2], acc[n][a][4 * j + 3]};
+      }
   __syncthreads();
   VFX_TS(11);  // staged
   {

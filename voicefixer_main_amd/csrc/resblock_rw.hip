@@ -105,13 +105,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   // conv1's bias lives in LDS (a VMEM load per tile would queue behind the prefetch), conv2's in 4 registers (pairs: all four
   // vectors in LDS)
   float* const b1s = reinterpret_cast<float*>(lds + BIAS_OFF);
-  if (tid < C) b1s[tid] = p.b1[tid];
+  if (tid < C) b1s[tid] = ((const VFX_GLOBAL float*)p.b1)[tid];
   f32x4 b2v = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * cg);
   if constexpr (PAIR) {
     if (tid < C) {
-      b1s[C + tid] = p.b2[tid];
-      b1s[2 * C + tid] = p.b1b[tid];
-      b1s[3 * C + tid] = p.b2b[tid];
+      b1s[C + tid] = ((const VFX_GLOBAL float*)p.b2)[tid];
+      b1s[2 * C + tid] = ((const VFX_GLOBAL float*)p.b1b)[tid];
+      b1s[3 * C + tid] = ((const VFX_GLOBAL float*)p.b2b)[tid];
     }
   }
 
