@@ -359,7 +359,9 @@ def live_traffic(args):
     try:
         dbs = {}
         for name, counter in (("tcc1", "FETCH_SIZE"), ("tcc2", "WRITE_SIZE")):
-            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(out, name), "-o", name, "--"] + child,
+            # GRBM_GUI_ACTIVE rides along with the read pass: cycles the GPU was busy during a dispatch, summed over the 8 XCDs
+            ctrs = [counter, "GRBM_GUI_ACTIVE"] if name == "tcc1" else [counter]
+            r = subprocess.run([exe, "--kernel-trace", "--pmc"] + ctrs + ["-d", os.path.join(out, name), "-o", name, "--"] + child,
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             found = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(out, name)) for f in fs if f.endswith("_results.db")]
             if r.returncode != 0 or not found:
@@ -372,6 +374,16 @@ def live_traffic(args):
                              "group by dispatch_id order by dispatch_id", (counter,)).fetchall()
             return [(short(k), v) for _, k, v in rows]
         rd, wr = load(dbs["FETCH_SIZE"], "FETCH_SIZE"), load(dbs["WRITE_SIZE"], "WRITE_SIZE")
+        # effective shader clock per dispatch = busy cycles (per XCD) / wall time of the dispatch (MI355X_MICROARCH.md, DVFS)
+        clk = {}
+        try:
+            c = sqlite3.connect(dbs["FETCH_SIZE"])
+            for did, k, v, st, en in c.execute("select dispatch_id, kernel_name, sum(value), min(start), max(end) from "
+                                               "counters_collection where counter_name='GRBM_GUI_ACTIVE' group by dispatch_id"):
+                if en > st:
+                    clk.setdefault(short(k), []).append(v / 8.0 / (en - st))
+        except Exception:
+            clk = {}
         if len(rd) != len(wr) or not rd:
             return {"error": "PMC passes disagree on the launch sequence (%d vs %d)" % (len(rd), len(wr))}
         first = [i for i, (k, _) in enumerate(rd) if k.startswith("k_stft_mel")]
@@ -384,13 +396,77 @@ def live_traffic(args):
             t[0] += 1
             t[1] += 2.0 * r * 1024.0
             t[2] += w * 1024.0
+        def ghz(k):
+            g = sorted(clk.get(k, []))
+            g = g[len(g) // 2] if g else None
+            return round(g, 3) if g and 0.3 < g < 2.7 else None
         return {"kernels": {k: {"launches_per_step": v[0], "read_bytes_per_launch": round(v[1] / v[0]),
-                                "write_bytes_per_launch": round(v[2] / v[0]), "bytes_per_launch": round((v[1] + v[2]) / v[0])}
+                                "write_bytes_per_launch": round(v[2] / v[0]), "bytes_per_launch": round((v[1] + v[2]) / v[0]),
+                                "effective_sclk_ghz_profiled": ghz(k)}
                             for k, v in per.items()}}
     except Exception as e:  # never fatal for the throughput measurement
         return {"error": repr(e)[:300]}
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+class PowerSampler:
+    """Package power and shader clock of the GPU while the timed region runs, read from the amdgpu hwmon files (a thread that
+    polls sysfs every few ms: no rocm-smi process, nothing on the GPU).  The step runs at the package power cap with the
+    shader clock well below its 2.4 GHz maximum: the numbers belong next to every fraction of a peak
+    that assumes 2.4 GHz.  Absent files (no GPU, other driver) give None."""
+
+    def __init__(self, index=0):
+        import glob
+        self.files, self.samples, self._stop, self._thr = {}, [], False, None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
+        if not cards:
+            return
+        base = cards[min(index, len(cards) - 1)]
+        for key, names in (("power_uw", ("power1_average", "power1_input")), ("sclk_hz", ("freq1_input",)),
+                           ("cap_uw", ("power1_cap",))):
+            for n in names:
+                if os.path.exists(os.path.join(base, n)):
+                    self.files[key] = os.path.join(base, n)
+                    break
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def __enter__(self):
+        if "sclk_hz" in self.files or "power_uw" in self.files:
+            import threading
+
+            def run():
+                while not self._stop:
+                    self.samples.append((self._read(self.files.get("power_uw", "")), self._read(self.files.get("sclk_hz", ""))))
+                    time.sleep(0.004)
+            self._thr = threading.Thread(target=run, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thr:
+            self._thr.join(timeout=1.0)
+
+    def result(self):
+        pw = [p for p, _ in self.samples if p]
+        ck = [c for _, c in self.samples if c]
+        if not pw and not ck:
+            return None
+        cap = self._read(self.files["cap_uw"]) if "cap_uw" in self.files else None
+        return {"samples": len(self.samples), "avg_power_w": round(sum(pw) / len(pw) / 1e6, 1) if pw else None,
+                "max_power_w": round(max(pw) / 1e6, 1) if pw else None, "power_cap_w": round(cap / 1e6, 1) if cap else None,
+                "avg_sclk_mhz": round(sum(ck) / len(ck) / 1e6, 1) if ck else None,
+                "min_sclk_mhz": round(min(ck) / 1e6, 1) if ck else None, "nominal_sclk_mhz": 2400,
+                "source": "amdgpu hwmon (power1_average / freq1_input), polled every 4 ms over the timed region"}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -592,7 +668,9 @@ def main():
     rccl_ranks = vdist.live_ranks(device)
 
     # ---- timed region ---------------------------------------------------------------------------------
-    dt = w.timed(args.steps, args.warmup, barrier)
+    sampler = PowerSampler(int(os.environ.get("LOCAL_RANK", "0")))
+    with sampler:
+        dt = w.timed(args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -615,6 +693,7 @@ def main():
             "rccl_ranks": rccl_ranks, "negative_input_flag": int(flags["negative_input"]), "f16_saturated": flags["f16_saturated"],
         }
         res.update(w.extra)
+        res["power"] = sampler.result()
         if flags["f16_saturated"]:
             failed = ("the 16-bit vocoder clamped an activation (VFX_FLAG_F16_SATURATED): this measurement is invalid; "
                       "run with --precision 1")
@@ -654,6 +733,9 @@ def main():
                                                            ms_step=None if wl == "sharded1024" else dt / args.steps * 1e3)
             if whole:
                 res["step"] = whole
+                ck = (res.get("power") or {}).get("avg_sclk_mhz")
+                if ck:   # the same step against the MFMA rate of the clock the chip actually held under its power cap
+                    whole["frac_of_mfma_peak_at_measured_sclk"] = round(whole["tflops"] / (whole["peak"] * ck / 2400.0), 4)
             res["roofline_hbm"] = measure_hbm_stages(eng, min(B, 64), L)
         if args.cpu_baseline_clips > 0:
             ssr64 = (not gsr) and not args.no_parity     # the ssr parity reference is the float64 oracle

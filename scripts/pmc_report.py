@@ -54,8 +54,8 @@ def main():
         if d["us"] < min_us:
             continue
         groups.setdefault((d["name"], d["grid"]), []).append(d)
-    hdr = ("kernel", "blocks", "n", "us", "mfma%", "valu%", "act%", "wait%", "winst%", "ldsconf%", "rdGB", "wrGB", "TB/s", "l2hit%")
-    print("%-30s %8s %3s %8s %6s %6s %6s %6s %6s %8s %7s %7s %6s %6s" % hdr)
+    hdr = ("kernel", "blocks", "n", "us", "mfma%", "valu%", "act%", "wait%", "winst%", "ldsconf%", "rdGB", "wrGB", "TB/s", "l2hit%", "GHz")
+    print("%-30s %8s %3s %8s %6s %6s %6s %6s %6s %8s %7s %7s %6s %6s %5s" % hdr)
     for (name, grid), ds in groups.items():
         def avg(k):
             vals = [d[k] for d in ds if k in d]
@@ -71,12 +71,15 @@ def main():
         rd = 2.0 * avg("FETCH_SIZE") * 1024 / 1e9  # FETCH_SIZE is in KB
         wr = avg("WRITE_SIZE") * 1024 / 1e9
         hit, miss = avg("TCC_HIT_sum"), avg("TCC_MISS_sum")
-        print("%-30s %8d %3d %8.1f %6.1f %6.1f %6.1f %6.1f %6.1f %8.2f %7.3f %7.3f %6.2f %6.1f" % (
+        # effective shader clock of the counter pass that carried GRBM_GUI_ACTIVE: busy cycles per XCD / that pass's duration
+        us_gui = avg("us_tcc1") if any("us_tcc1" in d for d in ds) else us
+        ghz = gui / 8.0 / (us_gui * 1e3) if gui == gui else float("nan")
+        print("%-30s %8d %3d %8.1f %6.1f %6.1f %6.1f %6.1f %6.1f %8.2f %7.3f %7.3f %6.2f %6.1f %5.2f" % (
             name, grid // 256, len(ds), us, mfma_pct,
             100.0 * avg("SQ_ACTIVE_INST_VALU") / wc, 100.0 * avg("SQ_ACTIVE_INST_ANY") / wc,
             100.0 * avg("SQ_WAIT_ANY") / wc, 100.0 * avg("SQ_WAIT_INST_ANY") / wc,
             100.0 * avg("SQ_LDS_BANK_CONFLICT") / max(avg("SQ_LDS_IDX_ACTIVE"), 1.0),
-            rd, wr, (rd + wr) / (us * 1e-6) / 1e3, 100.0 * hit / max(hit + miss, 1.0)))
+            rd, wr, (rd + wr) / (us * 1e-6) / 1e3, 100.0 * hit / max(hit + miss, 1.0), ghz))
 
 
 if __name__ == "__main__":

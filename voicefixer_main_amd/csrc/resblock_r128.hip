@@ -8,9 +8,9 @@
 // -- the epilogue's re-read of the residual finds its lines evicted (2.35-2.7 GB read for a 1.21 GB tensor) -- at ~4.1 TB/s:
 // the stack is bandwidth-bound on bytes it does not need.  Here every thread keeps the raw values of the tile's 128 centre rows
 // that it fetched for the patch (64 registers; a block is 4 waves = one per SIMD with 256 registers each) and adds them to the
-// staged conv2 result in LDS: the epilogue issues no load at all.  The rest follows resblock_w64.hip: the raw patch (4 chunks of
-// 32 channels x 160 rows x 128 B = 80 KB = half a CU's LDS, so two blocks share a CU and the memory phases of one run under the
-// arithmetic of the other) arrives in ONE LDS-DMA round trip and is turned into fp16 operand rows in place; a wave owns 64 couts x
+// staged conv2 result in LDS: the epilogue issues no load at all.  The patch goes global -> registers -> fp16 operand rows in LDS
+// (4 chunk buffers of 160 rows x 128 B = 80 KB = half a CU's LDS; h and the staged tile overlay them), so two blocks share a CU
+// and the memory phases of one run under the arithmetic of the other; a wave owns 64 couts x
 // 64 positions: a pixel fragment (1 KB from LDS) feeds TWO MFMAs and a weight fragment two -- with 32 couts x 128 positions per
 // wave every MFMA took its own pixel fragment, 128 B/clk/CU at full MFMA rate = all the LDS can deliver, and the convolution
 // phases ran 2.3x their MFMA time (phase stamps, profiles/r03_phase_timing_*.txt).  The weight ring runs three taps ahead (a
@@ -33,9 +33,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   constexpr int NCH = C / 32;                // 32-channel chunks = waves along the couts
   constexpr int PR = R128_PR;
   constexpr int PBYTES = PR * CROW;
-  constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
-  constexpr int NG = PR / RG;                // DMA instructions per wave and chunk (5)
-  static_assert(PR % RG == 0 && (RG / 2) % 8 == 0 && NCH == 4 && NW == 4, "geometry");
+    static_assert(PR % 8 == 0 && NCH == 4 && NW == 4, "geometry");
   constexpr int WM = 2, WN = 2;              // 32-position blocks / 32-cout blocks per wave: 64 positions x 64 couts
   constexpr int WL = 2 * WN;                 // weight loads per tap and wave (the hi fragments f[0], f[2] of two cout blocks)
   constexpr int RING = 4, AHEAD = RING - 1;  // weight taps in flight: a tap is 8 MFMAs (256 cycles), an L2 round trip ~3 of them
@@ -72,39 +70,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   // instructions, a tile has 25 of them per thread
   const unsigned inv_pw = p.inv_pw, inv_w1 = p.inv_w1;
 
-  const int lr = tid >> 3, cg = tid & 7;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int l31 = lane & 31, lh = lane >> 5;
   const int wn = wave_u & 1, wm = wave_u >> 1;  // cout half / position half of this wave
 
-  // ---- the raw x patch: every chunk at once ---------------------------------------------------------------------------------
-  {
-    unsigned voff[NG];
-    unsigned okmask = 0;
-#pragma unroll
-    for (int q = 0; q < NG; ++q) {
-      const int prow = lr + RG * q;
-      const int pi = (int)(((unsigned)prow * inv_pw) >> 20), pj = prow - pi * PW;
-      const int pos = base_x + pi * rowstride + pj;
-      const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
-      voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 4);
-      okmask |= ok ? (1u << q) : 0u;
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(p.x + c * kKC), 0, (int)(unsigned)((int64_t)p.B * T * C * 4 - (int64_t)c * kKC * 4), 0x00020000);
-#pragma unroll
-      for (int q = 0; q < NG; ++q) {
-        const unsigned o = (okmask & (1u << q)) ? voff[q] + 16u * cg : 0xfffffff0u;  // out of the sequence: zero fill
-        VFX_LDS void* l = (VFX_LDS void*)(lds + c * PBYTES + (RG * q + 8 * wave_u) * CROW);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
-      }
-    }
-  }
-
-  VFX_TS(1);  // patch requested
   int arow1[WM];   // A row of this lane's h pixel in the patch (tap offset to be added)
   bool hval[WM];   // that h pixel lies inside the tile's h grid and inside the sequence
 #pragma unroll
@@ -166,50 +136,57 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   };
 
 #pragma unroll
-  for (int g = 0; g < AHEAD; ++g) fetch(g);
-  // the patch has landed (this wave's share); the AHEAD weight fetches may stay in flight
-  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
+  for (int g = 0; g < AHEAD; ++g) fetch(g);  // issued BEFORE the patch loads: they stay in flight through the transform
 
-  VFX_TS(2);  // patch landed
-  __syncthreads();  // ... and everybody else's: a thread transforms rows that other waves requested
-  // ---- raw fp32 -> fp16 operand rows, in place; the 128 centre rows stay in registers as the residual -----------------------------
+  // ---- the x patch: global -> registers -> fp16 operand rows in LDS; the 128 centre rows stay in registers as the residual --------
   // Patch row pr of chunk c: 32 floats.  Thread (rt, ct, cgt) = (tid / 32, chunk, 4-float piece) -- the thread that will STORE
-  // channels 32 ct + 4 cgt .. + 3 of the output rows m = rt + 8 j in the epilogue -- transforms, of chunk ct, the x samples of
-  // exactly those rows (patch rows m + off, off = d for 1-D tiles, PW = one patch row up for folded ones: the centre window of the
+  // channels 32 ct + 4 cgt .. + 3 of the output rows m = rt + 8 j in the epilogue -- loads, of chunk ct, the x samples of exactly
+  // those rows (patch rows m + off, off = d for 1-D tiles, PW = one patch row up for folded ones: the centre window of the
   // patch) and keeps their raw values: the residual is added in the output pass from registers, no thread ever hands it to
-  // another one.  The up to 32 halo rows around the window are shared out four per thread.  Operand form (k_conv's 16-bit rows):
-  // the 8 bytes of the four channels at slot ((cgt >> 1) ^ key(row)), half cgt & 1, of the same 128-byte row; the threads of a
-  // row's chunk are 8 consecutive lanes, which read all their raw values before any of them writes.
+  // another one, and x is read from memory ONCE.  The up to 32 halo rows around the window are shared out four per thread.  A
+  // wave's load instruction covers two whole 512-byte rows of x.  (Round 3 first staged the raw patch in LDS by LDS-DMA and
+  // transformed it in place: 20 DMA instructions per wave at 100-185 issue cycles each, a barrier, and a read + write pass over
+  // 80 KB of LDS -- 15 k of a block's 40 k cycles before the first MFMA, phase stamps in profiles/r03_phase_timing_*.txt.)
+  // Operand form (k_conv's 16-bit rows): the 8 bytes of the four channels at slot ((cgt >> 1) ^ key(row)), half cgt & 1, of the
+  // chunk's 128-byte row.  Rows outside the sequence / the patch are loaded beyond the descriptor's bound: zeros, and
+  // LeakyReLU(0) = 0.
   const int off = p.fold ? PW : d;  // <= 32 (launch_resblock_r128)
   const int rt = tid >> 5, ct = (tid >> 3) & 3, cgt = tid & 7;
   constexpr int NROW = PR / 8;      // rows per thread: 16 centre + 4 halo
   f32x4 keep[KEEP];
   {
     unsigned f16_sat = 0;
-    char* const cb = lds + ct * PBYTES + 16 * cgt;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(unsigned)((int64_t)p.B * T * C * 4), 0x00020000);
+    const unsigned lane_off = (unsigned)(ct * 128 + cgt * 16);
     int prow[NROW];
+    u32x4 raw[NROW];
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
       const int hh = rt + 8 * (j - KEEP);
       prow[j] = j < KEEP ? rt + 8 * j + off : (hh < off ? hh : hh + MT);
+      const int pi = (int)(((unsigned)prow[j] * inv_pw) >> 20), pj = prow[j] - pi * PW;
+      const int pos = base_x + pi * rowstride + pj;
+      const bool ok = (prow[j] < P) & ((unsigned)pos < (unsigned)T);
+      const unsigned o = ok ? (unsigned)(img * T + pos) * (unsigned)(C * 4) + lane_off : 0xfffffff0u;
+      raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
     }
-    f32x4 raw[NROW];
-#pragma unroll
-    for (int j = 0; j < NROW; ++j) raw[j] = *reinterpret_cast<const f32x4*>(cb + prow[j] * CROW);
-#pragma unroll
-    for (int j = 0; j < KEEP; ++j) keep[j] = raw[j];
+    __builtin_amdgcn_sched_barrier(0);  // all twenty loads are in flight before the first row is converted
+    VFX_TS(1);  // patch requested
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
+      const f32x4 r = __builtin_bit_cast(f32x4, raw[j]);
+      if (j < KEEP) keep[j] = r;
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[j][e], raw[j][e] * slope);  // LeakyReLU(0) = 0: the DMA's zero fill stays zero
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(r[e], r[e] * slope);
       const int key = (prow[j] >> 1) & 7;
       *reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((cgt >> 1) ^ key) << 4) + 8 * (cgt & 1)) =
           make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
     }
     report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
   }
-  VFX_TS(3);  // transformed
+  VFX_TS(2);  // loaded and transformed
+  VFX_TS(3);
   __syncthreads();  // the operand rows of every wave are visible
   VFX_TS(4);
 
