@@ -50,13 +50,15 @@ enum {
  * plan is built; vfx_create reports a non-zero mask on stderr.  Every bit is exercised by the GPU test suite. */
 enum {
   VFX_TUNE_NO_FUSED_STACKS = 1,    /* vocoder ResStack layers (C = 64, 128) as two tap-convolution launches per layer */
-  VFX_TUNE_NO_FUSED_WIDE = 2,      /* ... the C = 256 layers of the 16-bit mode as two launches per layer */
+  VFX_TUNE_NO_FUSED_WIDE = 2,      /* ... the C = 256 layers of the 16-bit mode as two launches per layer (two-form trunk) */
   VFX_TUNE_NO_FUSED_UNET = 4,      /* identity-shortcut ConvBlockRes of the ResUNets (C = 32, 64) as two launches */
   VFX_TUNE_NO_PERSISTENT_C64 = 8,  /* 16-bit mode, C = 64 layers on k_resblock instead of the persistent kernel */
   VFX_TUNE_NO_PAIRS = 16,          /* 16-bit mode, C = 64: one launch per layer (no layer pairs) */
   VFX_TUNE_NO_SPLITK = 32,         /* no split-K in the deep ResUNet levels */
-  VFX_TUNE_WIDE_8WAVE = 64,        /* C = 256 layers on the 8-wave / one-block-per-CU kernel (resblock_act.hip) */
-  VFX_TUNE_C128_8WAVE = 128        /* 16-bit mode, C = 128 layers on k_resblock<128, 8> (re-reads the residual) */
+  VFX_TUNE_WIDE_8WAVE = 64,        /* C = 256 layers on the 8-wave / one-block-per-CU kernel (resblock_act.hip, two-form trunk) */
+  VFX_TUNE_C128_8WAVE = 128,       /* 16-bit mode, C = 128 layers on k_resblock<128, 8> (re-reads the residual) */
+  VFX_TUNE_WIDE_TWO_FORM = 256     /* 16-bit mode, C = 256 layers on the two-form trunk (fp32 + activated fp16 copy, resblock_w64.hip)
+                                      instead of the single-form layer of resblock_s256.hip */
 };
 
 typedef struct vfx_config {
@@ -239,6 +241,8 @@ int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int C, const fl
  * C channels over sequences of T positions in precision mode `precision`.  out[12] = fold, TH, W1, TWo, tiles_h, tiles_w, PW, P,
  * tile_m, rw, rl, asrc (ResBlockParams).  The CPU tests use it to check that the tiles cover every position exactly once. */
 int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int precision, int* out);
+/* ... for a handle configured with vfx_config.tuning = `tuning` (the function above is tuning = 0). */
+int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2, int precision, int tuning, int* out);
 
 /* Two consecutive ResStack layers (dilations dil, dil2) as ONE launch: y = layer_b(layer_a(x)), the intermediate tensor never
  * leaves the CU (resblock_rw.hip).  precision 2, C = 64, dil <= 32, dil2 <= 62 only -- what the vocoder plan pairs (dilations

@@ -5,6 +5,7 @@ k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
 k_resblock_act<C, NW, MT>              ->  "k_resblock<C, NW> f16"
 k_resblock_w64<C>                      ->  "k_resblock<C, 4> f16"
 k_resblock_r128                        ->  "k_resblock<128, 4> f16"
+k_resblock_s256                        ->  "k_resblock<256, 4> f16"
 k_resblock_rw<NW, PAIR>                ->  "k_resblock<64, NW> f16" / "k_resblock_pair<64, NW> f16"
 """
 import re
@@ -24,6 +25,8 @@ def short(n, width=40):
         return "k_resblock<%s, 4> f16" % args[0]
     if name == "k_resblock_r128":                        # C = 128, 16-bit mode: 4-wave blocks, x read once
         return "k_resblock<128, 4> f16"
+    if name == "k_resblock_s256":                        # C = 256, 16-bit mode, single-form trunk: 4-wave blocks of 64 positions
+        return "k_resblock<256, 4> f16"
     if name == "k_resblock_rw" and args:                 # C = 64, 16-bit mode: persistent, weights in registers
         if len(args) >= 2 and args[1] == "true":         # two layers per launch
             return "k_resblock_pair<64, %s> f16" % args[0]

@@ -68,8 +68,8 @@ def _resblock_ref(x, w1, b1, w2, b2, d, slope):
 def test_resblock_layer(engine, C, T, fused):
     """One ResStack layer (oracle/vocoder.py): fused k_resblock and the two-launch form with the activated
     intermediate tensor, over the vocoder's dilations (plain tiles up to 27, folded geometry beyond, also d > T).
-    C = 256 fused = the wide layer of the 16-bit mode on the two-form trunk (resblock_act.hip; the entry point also
-    checks its activated fp16 output against fp16(LeakyReLU(y)))."""
+    C = 256 fused = the wide layer of the 16-bit mode, by default on the single-form trunk (resblock_s256.hip; the entry point
+    also checks its activated fp16 output against fp16(LeakyReLU(y))); the two-form kernels: test_wide_layer_forms."""
     if fused and engine.tol['name'] == 'fp32':
         pytest.skip("the fused kernel has no fp32 form; fp32 plans use the two-launch form")
     if fused and C == 256 and engine.tol['name'] != 'fp16-vocoder':
@@ -83,6 +83,28 @@ def test_resblock_layer(engine, C, T, fused):
         y = engine.op_resblock(x.permute(0, 2, 1).contiguous(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), d, 0.01, fused)
         err = (y.cpu().permute(0, 2, 1).double() - ref).abs().max().item()
         assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), (d, err)
+
+
+@pytest.mark.parametrize("tuning,T", [(0, 1100), (0, 7350), (256, 1100), (256, 7350), (64, 1100)],
+                         ids=["single-form", "single-form-long", "two-form-w64", "two-form-w64-long", "two-form-8wave"])
+def test_wide_layer_forms(tuning, T):
+    """The three kernels of the C = 256 layer of the 16-bit mode (vfx_config.tuning: 0 = resblock_s256.hip, single-form trunk,
+    64-position tiles; VFX_TUNE_WIDE_TWO_FORM = resblock_w64.hip; VFX_TUNE_WIDE_8WAVE = resblock_act.hip) against the float64
+    layer, all eight dilations (1-D tiles up to 9, folded rows above, d > T), three clips of unequal tile phase; the op checks
+    the activated fp16 output a last layer writes against fp16(LeakyReLU(y)) itself."""
+    from voicefixer_main_amd.engine import Engine
+    from conftest import TOL
+    eng = Engine("cuda:0", config={"precision": 2, "tuning": tuning})
+    B, C = 3, 256
+    x = _rand((B, C, T), 61)
+    w1, w2 = _rand((C, C, 3), 62, 0.05), _rand((C, C, 3), 63, 0.05)
+    b1, b2 = _rand((C,), 64, 0.1), _rand((C,), 65, 0.1)
+    for d in (1, 3, 9, 27, 81, 243, 729, 2187):
+        ref = _resblock_ref(x, w1, b1, w2, b2, d, 0.01)
+        y = eng.op_resblock(x.permute(0, 2, 1).contiguous(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), d, 0.01, True)
+        err = (y.cpu().permute(0, 2, 1).double() - ref).abs().max().item()
+        assert err < TOL[2]['conv'] * max(1.0, ref.abs().max().item()), (tuning, d, err)
+    assert eng.take_flags() == 0
 
 
 def test_resblock_layer_long_sequence(engine):

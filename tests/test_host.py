@@ -221,7 +221,8 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
     # kernels that are allowed a few bytes of scratch: opt-in experiments and the opt-in 64-position form of the C = 256 layer
     # (and k_conv<64, ELU, split, ring 3>: 8 bytes since round 1, split-bf16 mode of the vocoder's ELU convolutions only)
     may_spill = ("k_resblock_actILi256ELi8ELi64E", "k_convILi64ELb1ELb1ELi0ELi3ELb0ELb0E")
-    for name in ("conv.hip", "resblock.hip", "resblock_act.hip", "resblock_w64.hip", "resblock_r128.hip", "resblock_rw.hip", "stft.hip"):
+    for name in ("conv.hip", "resblock.hip", "resblock_act.hip", "resblock_w64.hip", "resblock_r128.hip", "resblock_s256.hip", "resblock_rw.hip",
+                 "stft.hip"):
         out = str(tmp_path / (name + ".s"))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                         "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, name)], check=True,
@@ -236,6 +237,9 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
             kernel, scratch = m.group(1), int(m.group(2))
             if not any(k in kernel for k in may_spill):
                 assert scratch == 0, (name, kernel, scratch)
+        # no FLAT memory instruction anywhere: the compiler's wait-count insertion answers one with lgkmcnt(0) / vmcnt(0) on every later
+        # wait, which un-pipelines the fragment reads of kernels whose vmcnt waits are hand-counted asm (conv_common.h: or_flag_global)
+        assert not re.search(r"\n\s*flat_(load|store|atomic)", asm), name
 
 
 def test_committed_bench_line_follows_the_contract():
@@ -262,8 +266,8 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(d["value"] - audio / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
 
 
-@pytest.mark.parametrize("C,precision", [(64, 2), (64, 1), (128, 2), (256, 2)])
-def test_resblock_tiles_cover_every_position_once(C, precision):
+@pytest.mark.parametrize("C,precision,tuning", [(64, 2, 0), (64, 1, 0), (128, 2, 0), (256, 2, 0), (256, 2, 256), (256, 2, 64)])
+def test_resblock_tiles_cover_every_position_once(C, precision, tuning):
     """Tile geometry of the fused ResStack kernels (plan_resblock, host-only entry point): over the vocoder's dilations, the
     layer pairs of the 16-bit C = 64 stack and short / long / unaligned sequences, the outputs the kernels' masks let through
     -- restated here from resblock.hip / resblock_rw.hip / resblock_act.hip -- hit every position exactly once, and the taps
@@ -277,7 +281,7 @@ def test_resblock_tiles_cover_every_position_once(C, precision):
         cases += [(1, 3), (9, 27), (3, 9)]
     for T in (3, 90, 1000, 49049, 70001):
         for d, d2 in cases:
-            assert lib.vfx_plan_resblock_geometry(C, T, d, d2, precision, out) == 0, (T, d, d2)
+            assert lib.vfx_plan_resblock_geometry_tuned(C, T, d, d2, precision, tuning, out) == 0, (T, d, d2)
             fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, MT, rw, rl, asrc = list(out)
             MT = MT or 128
             assert P <= MT + 64 and TH * W1 <= MT and TH >= 1
@@ -393,6 +397,7 @@ def test_profile_kernel_names():
     assert short(ns + "k_resblock_act<256, 8, 128>(vfx::ResBlockParams const*)") == "k_resblock<256, 8> f16"
     assert short(ns + "k_resblock_w64<256>(vfx::ResBlockParams const*)") == "k_resblock<256, 4> f16"
     assert short(ns + "k_resblock_r128(vfx::ResBlockParams const*)") == "k_resblock<128, 4> f16"
+    assert short(ns + "k_resblock_s256(vfx::ResBlockParams const*)") == "k_resblock<256, 4> f16"
     assert short(ns + "k_resblock<32, 2, false, true>(vfx::ResBlockParams const*)") == "k_resblock<32, 2>"
     assert short(ns + "k_resblock<128, 8, true, false>(vfx::ResBlockParams const*)") == "k_resblock<128, 8> f16"
     assert short(ns + "k_stft_mel<false>(float const*, int)") == "k_stft_mel<false>"

@@ -120,8 +120,9 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
     float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, h_f16 ? 3 : pmode));
     float* db1 = sc.blob.upload(b1, C);
     float* db2 = sc.blob.upload(b2, C);
-    if (fused && h->cfg.precision == 2 && resblock_act_supported(C)) {
-      // wide fused layer of the 16-bit mode: conv1 reads xa = fp16(LeakyReLU(x)), built here on the host
+    const bool s256 = fused && h->cfg.precision == 2 && C == 256 && resblock_s256_enabled(h->cfg.tuning);
+    if (fused && h->cfg.precision == 2 && resblock_act_supported(C) && !s256) {
+      // wide fused layer of the 16-bit mode on the two-form trunk: conv1 reads xa = fp16(LeakyReLU(x)), built here on the host
       std::vector<float> hx((size_t)B * T * C);
       VFX_HIP(hipMemcpy(hx.data(), x, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
       std::vector<_Float16> ha(hx.size());
@@ -158,12 +159,13 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       launch_resblock(rp, d, s);
       check_activated_output(y, dya, hx.size(), slope, s);
     } else if (fused) {
-      VFX_CHECK(split && resblock_supported(C), "vfx_op_resblock: the fused kernel needs precision 1 or 2 and C = 64 or 128");
+      VFX_CHECK(split && (resblock_supported(C) || s256), "vfx_op_resblock: the fused kernel needs precision 1 or 2 and C = 64 or 128 (precision 2: also 256)");
       ResBlockParams rp{};
       rp.x = x;
       rp.y = y;
-      rp.w1 = dw1;
-      rp.w2 = dw2;
+      // the single-form wide layer takes the fp16 64-channel-chunk fragments (mode 3)
+      rp.w1 = s256 ? sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, 3)) : dw1;
+      rp.w2 = s256 ? sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, 3)) : dw2;
       rp.b1 = db1;
       rp.b2 = db2;
       rp.slope = slope;
@@ -226,7 +228,12 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
 // sequences of `T` positions in precision mode `precision` -- so that the CPU test suite can check that the tiles of every
 // kernel family (1-D, folded, pairs; 128- and 256-position tiles) write each output position exactly once.
 // out[12] = fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, tile_m, rw, 0, asrc.  Needs no GPU and no handle.
+extern "C" int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2, int precision, int tuning, int* out);
 extern "C" int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int precision, int* out) {
+  return vfx_plan_resblock_geometry_tuned(C, T, dil, dil2, precision, 0, out);
+}
+
+extern "C" int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2, int precision, int tuning, int* out) {
   try {
     VFX_CHECK(out && T > 0 && dil >= 1 && dil2 >= 0, "bad argument");
     ResBlockParams rp{};
@@ -236,7 +243,8 @@ extern "C" int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int p
     rp.dil = dil;
     rp.dil2 = dil2;
     rp.hionly = precision == 2;
-    if (precision == 2 && resblock_act_supported(C)) {
+    rp.tuning = tuning;
+    if (precision == 2 && resblock_act_supported(C) && !resblock_s256_enabled(tuning)) {
       rp.asrc = 1;
       rp.tile_m = resblock_act_tile();
     }

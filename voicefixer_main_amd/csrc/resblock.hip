@@ -536,7 +536,7 @@ bool resblock_supported(int C) { return C == 64 || C == 128; }
 // Waves per block of the kernel that runs this (planned) layer: the second template argument in the kernel tables
 int resblock_block_waves(const ResBlockParams& hp) {
   if (hp.rw) return hp.tile_m / 32;
-  if ((hp.asrc && hp.patch_rows) || hp.r128) return 4;
+  if ((hp.asrc && hp.patch_rows) || hp.r128 || hp.s256) return 4;
   if (hp.geo2d) return hp.C == 32 ? 2 : 4;
   return hp.C >= 128 ? 8 : 4;
 }
@@ -577,8 +577,10 @@ void plan_block2d(ResBlockParams& p) {
 
 // Fills the tile geometry of a fused ResStack layer (B, T, C, dil must be set).
 void plan_resblock(ResBlockParams& p) {
-  VFX_CHECK(p.asrc ? resblock_act_supported(p.C) : resblock_supported(p.C), "resblock: C=%d is not supported", p.C);
+  p.s256 = (!p.asrc && p.hionly && p.C == 256 && !p.geo2d && p.dil2 == 0 && resblock_s256_enabled(p.tuning)) ? 1 : 0;
+  VFX_CHECK(p.asrc ? resblock_act_supported(p.C) : (resblock_supported(p.C) || p.s256), "resblock: C=%d is not supported", p.C);
   const int d = p.dil;
+  if (p.s256) p.tile_m = resblock_s256_tile();
 #ifdef VFX_TIMING
   p.timing = getenv("VFX_TIMING_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("VFX_TIMING_PTR"), nullptr, 0)) : nullptr;
 #endif
@@ -591,6 +593,7 @@ void plan_resblock(ResBlockParams& p) {
   p.patch_rows = (p.asrc && MT == 128 && p.dil2 == 0 && resblock_w64_enabled(p.tuning)) ? resblock_w64_patch_rows() : 0;
   p.r128 = (!p.asrc && !p.rw && p.hionly && p.C == 128 && MT == 128 && p.dil2 == 0 && resblock_r128_enabled(p.tuning)) ? 1 : 0;
   if (p.r128) p.patch_rows = resblock_r128_patch_rows();
+  if (p.s256) p.patch_rows = resblock_s256_patch_rows();
   const int PR = p.patch_rows ? p.patch_rows : MT + 64;
   VFX_CHECK(MT == 64 || MT == 128 || (MT == 256 && p.rw), "resblock: tile of %d positions", MT);
   p.tile_m = MT;
@@ -658,6 +661,10 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
   }
   if (hp.r128) {
     launch_resblock_r128(hp, dparams, stream);
+    return;
+  }
+  if (hp.s256) {
+    launch_resblock_s256(hp, dparams, stream);
     return;
   }
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;

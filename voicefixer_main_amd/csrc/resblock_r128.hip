@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   constexpr int PBYTES = PR * CROW;
     static_assert(PR % 8 == 0 && NCH == 4 && NW == 4, "geometry");
   constexpr int WM = 2, WN = 2;              // 32-position blocks / 32-cout blocks per wave: 64 positions x 64 couts
-  constexpr int WL = 2 * WN;                 // weight loads per tap and wave (the hi fragments f[0], f[2] of two cout blocks)
+  constexpr int WL = 2 * WN;                 // weight loads per tap and wave (the hi fragments f[0], f[2] of two cout blocks): the vmcnt counts below
+  static_assert(WL == 4, "the hand-counted waits of conv() assume four loads per tap");
   constexpr int RING = 4, AHEAD = RING - 1;  // weight taps in flight: a tap is 8 MFMAs (256 cycles), an L2 round trip ~3 of them
   constexpr int HROW = C * 4;                // bytes per h row (operand form: 128-byte chunk rows, fp16 in the first half)
   constexpr int NT1 = 3 * NCH;               // taps of conv1 (chunk-major); conv2 has as many

@@ -202,6 +202,7 @@ struct ResBlockParams {
   const float* b1b;
   const float* b2b;
   int r128;         // set by plan_resblock: resblock_r128.hip runs this layer (16-bit mode, C = 128)
+  int s256;         // set by plan_resblock: resblock_s256.hip runs this layer (16-bit mode, C = 256, single-form trunk)
   int rw;           // set by plan_resblock: the persistent register-weights kernel runs this layer (resblock_rw.hip: 16-bit mode, C = 64)
   const float* xa;
   float* ya;
@@ -235,6 +236,11 @@ bool resblock_w64_enabled(int tuning);
 bool resblock_r128_enabled(int tuning);
 int resblock_r128_patch_rows();
 void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
+// resblock_s256.hip: C = 256, 16-bit mode, single-form trunk -- 4-wave blocks of 64-position tiles, two per CU, x read once
+bool resblock_s256_enabled(int tuning);
+int resblock_s256_patch_rows();
+int resblock_s256_tile();
+void launch_resblock_s256(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 int resblock_w64_patch_rows();
 void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 int resblock_rw_tile(int tuning);

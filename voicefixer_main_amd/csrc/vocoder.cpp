@@ -37,11 +37,22 @@ int pack_mode(const vfx_config& cfg, bool src_act) {
   return cfg.precision != 0 ? 1 : 0;
 }
 
-// HBM-bound stacks (C = 64, 128) run each layer as ONE fused launch on the raw trunk (resblock.hip); the wide stacks
-// run two launches per layer on a trunk kept in both forms.  VFX_TUNE_NO_FUSED_STACKS forces the latter.
+// The C = 256 stack of the 16-bit mode on the single-form trunk (resblock_s256.hip): raw fp32 in, raw fp32 out
+bool stack_single_form_wide(const vfx_config& cfg, int channels) {
+  return cfg.precision == 2 && channels == 256 && resblock_s256_enabled(cfg.tuning);
+}
+
+// HBM-bound stacks (C = 64, 128; in the 16-bit mode also C = 256) run each layer as ONE fused launch on the raw trunk
+// (resblock.hip, resblock_s256.hip); the other wide stacks run on a trunk kept in both forms (one or two launches per layer).
+// VFX_TUNE_NO_FUSED_STACKS forces the latter everywhere.
 bool stack_fused(const vfx_config& cfg, int channels) {
+  if (stack_single_form_wide(cfg, channels)) return true;
   return cfg.precision != 0 && resblock_supported(channels) && !(cfg.tuning & VFX_TUNE_NO_FUSED_STACKS);
 }
+
+// Packing of the fused layers' weights: pack_mode(raw source), except the single-form wide layer, which takes the fp16
+// 64-channel-chunk fragments of resblock_w64.hip (mode 3)
+int fused_layer_mode(const vfx_config& cfg, int channels) { return stack_single_form_wide(cfg, channels) ? 3 : pack_mode(cfg, false); }
 
 // Conv1d weight (Cout, Cin, K) -> packed with taps k = 0..K-1
 VocConvW load_conv1d(vfx_handle* h, const std::string& p, int cin, int cout, int K, bool src_act) {
@@ -117,7 +128,7 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
       snprintf(a, sizeof(a), "generator.%d.res_layers.%d.1", idx + 1, i);
       snprintf(b, sizeof(b), "generator.%d.res_layers.%d.3", idx + 1, i);
       // unfused layers read the activated trunk / the activated h; the fused kernel transforms raw patches itself
-      const bool act = !stack_fused(cfg, c);
+      const bool act = !stack_fused(cfg, c) || stack_single_form_wide(cfg, c);  // (mode 3 = the packing for activated sources)
       stack.push_back({load_conv1d(h, a, c, c, 3, act), load_conv1d(h, b, c, c, 3, act)});
     }
     W->res.push_back(stack);
@@ -313,7 +324,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.hionly = cfg.precision == 2;
         rp.tuning = cfg.tuning;
         VFX_CHECK(layer.first.mode == layer.second.mode &&
-                      layer.first.mode == pack_mode(cfg, false),
+                      layer.first.mode == fused_layer_mode(cfg, up.cout),
                   "vocoder plan: the weights of a fused %d-channel layer are packed for another kernel", up.cout);
         // 16-bit mode, C = 64: two layers of small dilation as one launch -- the tensor between them is never stored
         if (rp.hionly && li + 1 < nlayers && resblock_rw_pair_ok(up.cout, dil, dil * cfg.voc_dilation_base, cfg.tuning)) {
