@@ -423,7 +423,19 @@ class PowerSampler:
         cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
         if not cards:
             return
-        base = cards[min(index, len(cards) - 1)]
+        # the card of THIS process's device: sysfs lists every GPU of the node, the container sees one -- match the PCI address
+        base = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x." % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            base = next((c for c in cards if addr in os.path.realpath(os.path.join(c, "..", ".."))), None)
+        except Exception:
+            base = None
+        if base is None:   # no PCI address: the card that draws the most power right now (the warm-up steps have just run)
+            def watts(c):
+                v = self._read(os.path.join(c, "power1_average")) or self._read(os.path.join(c, "power1_input")) or 0.0
+                return v
+            base = max(cards, key=watts)
         for key, names in (("power_uw", ("power1_average", "power1_input")), ("sclk_hz", ("freq1_input",)),
                            ("cap_uw", ("power1_cap",))):
             for n in names:

@@ -68,8 +68,8 @@ def _resblock_ref(x, w1, b1, w2, b2, d, slope):
 def test_resblock_layer(engine, C, T, fused):
     """One ResStack layer (oracle/vocoder.py): fused k_resblock and the two-launch form with the activated
     intermediate tensor, over the vocoder's dilations (plain tiles up to 27, folded geometry beyond, also d > T).
-    C = 256 fused = the wide layer of the 16-bit mode, by default on the single-form trunk (resblock_s256.hip; the entry point
-    also checks its activated fp16 output against fp16(LeakyReLU(y))); the two-form kernels: test_wide_layer_forms."""
+    C = 256 fused = the wide layer of the 16-bit mode on the two-form trunk (resblock_w64.hip; the entry point also checks its
+    activated fp16 output against fp16(LeakyReLU(y))); its other forms: test_wide_layer_forms."""
     if fused and engine.tol['name'] == 'fp32':
         pytest.skip("the fused kernel has no fp32 form; fp32 plans use the two-launch form")
     if fused and C == 256 and engine.tol['name'] != 'fp16-vocoder':
@@ -85,11 +85,11 @@ def test_resblock_layer(engine, C, T, fused):
         assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), (d, err)
 
 
-@pytest.mark.parametrize("tuning,T", [(0, 1100), (0, 7350), (256, 1100), (256, 7350), (64, 1100)],
+@pytest.mark.parametrize("tuning,T", [(256, 1100), (256, 7350), (0, 1100), (0, 7350), (64, 1100)],
                          ids=["single-form", "single-form-long", "two-form-w64", "two-form-w64-long", "two-form-8wave"])
 def test_wide_layer_forms(tuning, T):
-    """The three kernels of the C = 256 layer of the 16-bit mode (vfx_config.tuning: 0 = resblock_s256.hip, single-form trunk,
-    64-position tiles; VFX_TUNE_WIDE_TWO_FORM = resblock_w64.hip; VFX_TUNE_WIDE_8WAVE = resblock_act.hip) against the float64
+    """The three kernels of the C = 256 layer of the 16-bit mode (vfx_config.tuning: 0 = resblock_w64.hip, two-form trunk;
+    VFX_TUNE_WIDE_SINGLE_FORM = resblock_s256.hip, 64-position tiles; VFX_TUNE_WIDE_8WAVE = resblock_act.hip) against the float64
     layer, all eight dilations (1-D tiles up to 9, folded rows above, d > T), three clips of unequal tile phase; the op checks
     the activated fp16 output a last layer writes against fp16(LeakyReLU(y)) itself."""
     from voicefixer_main_amd.engine import Engine

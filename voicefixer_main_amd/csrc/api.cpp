@@ -800,7 +800,7 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   VFX_CHECK((h->cfg.tuning & ~511) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
   if (h->cfg.tuning) {  // never silent: a non-default kernel selection is announced
     static const char* names[] = {"NO_FUSED_STACKS", "NO_FUSED_WIDE", "NO_FUSED_UNET", "NO_PERSISTENT_C64", "NO_PAIRS", "NO_SPLITK",
-                                  "WIDE_8WAVE", "C128_8WAVE", "WIDE_TWO_FORM"};
+                                  "WIDE_8WAVE", "C128_8WAVE", "WIDE_SINGLE_FORM"};
     std::string msg;
     for (int b = 0; b < 9; ++b)
       if (h->cfg.tuning & (1 << b)) msg += std::string(msg.empty() ? "" : " | ") + "VFX_TUNE_" + names[b];

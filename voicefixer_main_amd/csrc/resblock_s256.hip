@@ -5,7 +5,9 @@
 // x and y are the raw fp32 trunk; nothing else crosses HBM (the last layer of the stack also writes the activated fp16 form the
 // next upsampler reads).
 //
-// Why (round-3 phase stamps and PMC): the two-form layer (resblock_w64.hip: x and an activated fp16 copy xa
+// Opt-in with VFX_TUNE_WIDE_SINGLE_FORM -- see resblock_s256_enabled() below for what it measured.
+//
+// Why it was written (round-3 phase stamps and PMC): the two-form layer (resblock_w64.hip: x and an activated fp16 copy xa
 // in, y and ya out) moves 400 KB per 128-position tile -- 12 bytes per element plus the halo -- and a CU gets ~10 B/clk of the
 // fabric: 40 k of the 44.9 k cycles a CU has per tile.  That layer is traffic-bound on its own data layout.  The single-form
 // layer needs the tile's raw centre rows on chip for the residual: at 128 positions that is 128 registers per thread beside 128
@@ -371,10 +373,12 @@ __global__ __launch_bounds__(256, 2) void k_resblock_s256(const ResBlockParams* 
 int resblock_s256_patch_rows() { return S256_PR; }
 int resblock_s256_tile() { return S256_MT; }
 
-// The single-form layer runs the C = 256 stack of the 16-bit mode by default; VFX_TUNE_WIDE_TWO_FORM (and VFX_TUNE_WIDE_8WAVE,
-// VFX_TUNE_NO_FUSED_WIDE, which are forms of it) select the two-form trunk of resblock_w64.hip / resblock_act.hip.
+// Opt-in (VFX_TUNE_WIDE_SINGLE_FORM): measured against the two-form layer of resblock_w64.hip on the vocoder at 16 x 10 s, this
+// layer moves 1.80 GB instead of 2.62 GB per launch and takes 0.76 ms instead of 0.70 (profiles/r03_c9_single_form_ab.jsonl):
+// 64-position tiles pay the per-tile phases (parameter loads, address math, 24 loads per thread, h, epilogue: 31 k cycles) twice
+// per 128 positions and fetch every weight fragment twice as often.  The default stays the two-form layer.
 bool resblock_s256_enabled(int tuning) {
-  return !(tuning & (VFX_TUNE_WIDE_TWO_FORM | VFX_TUNE_WIDE_8WAVE | VFX_TUNE_NO_FUSED_WIDE | VFX_TUNE_NO_FUSED_STACKS));
+  return (tuning & VFX_TUNE_WIDE_SINGLE_FORM) && !(tuning & (VFX_TUNE_WIDE_8WAVE | VFX_TUNE_NO_FUSED_WIDE | VFX_TUNE_NO_FUSED_STACKS));
 }
 
 void launch_resblock_s256(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
