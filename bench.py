@@ -412,52 +412,48 @@ def live_traffic(args):
 
 class PowerSampler:
     """Package power and shader clock of the GPU while the timed region runs, read from the amdgpu hwmon files (a thread that
-    polls sysfs every few ms: no rocm-smi process, nothing on the GPU).  The step runs at the package power cap with the
-    shader clock well below its 2.4 GHz maximum: the numbers belong next to every fraction of a peak
-    that assumes 2.4 GHz.  Absent files (no GPU, other driver) give None."""
+    polls sysfs every few ms: no rocm-smi process, nothing on the GPU).  The numbers belong next to every fraction of a peak
+    that assumes 2.4 GHz.  sysfs lists every GPU of the node while the container sees one: the card is
+    matched by PCI address, or -- without one -- taken as the card that drew the most power over the region.  Absent files (no
+    GPU, other driver) give None."""
 
     def __init__(self, index=0):
         import glob
-        self.files, self.samples, self._stop, self._thr = {}, [], False, None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
-        if not cards:
-            return
-        # the card of THIS process's device: sysfs lists every GPU of the node, the container sees one -- match the PCI address
-        base = None
+        self.cards, self.samples, self._stop, self._thr, self.match = [], {}, False, None, None
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*")):
+            f = {}
+            for key, names in (("power_uw", ("power1_average", "power1_input")), ("sclk_hz", ("freq1_input",)), ("cap_uw", ("power1_cap",))):
+                for n in names:
+                    if os.path.exists(os.path.join(c, n)):
+                        f[key] = os.path.join(c, n)
+                        break
+            if "sclk_hz" in f or "power_uw" in f:
+                self.cards.append((c, f))
+                self.samples[c] = []
         try:
             pr = torch.cuda.get_device_properties(index)
             addr = "%04x:%02x:%02x." % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
-            base = next((c for c in cards if addr in os.path.realpath(os.path.join(c, "..", ".."))), None)
+            self.match = next((c for c, _ in self.cards if addr in os.path.realpath(os.path.join(c, "..", ".."))), None)
         except Exception:
-            base = None
-        if base is None:   # no PCI address: the card that draws the most power right now (the warm-up steps have just run)
-            def watts(c):
-                v = self._read(os.path.join(c, "power1_average")) or self._read(os.path.join(c, "power1_input")) or 0.0
-                return v
-            base = max(cards, key=watts)
-        for key, names in (("power_uw", ("power1_average", "power1_input")), ("sclk_hz", ("freq1_input",)),
-                           ("cap_uw", ("power1_cap",))):
-            for n in names:
-                if os.path.exists(os.path.join(base, n)):
-                    self.files[key] = os.path.join(base, n)
-                    break
+            self.match = None
 
     @staticmethod
     def _read(path):
         try:
             with open(path) as f:
                 return float(f.read().strip())
-        except (OSError, ValueError):
+        except (OSError, ValueError, TypeError):
             return None
 
     def __enter__(self):
-        if "sclk_hz" in self.files or "power_uw" in self.files:
+        if self.cards:
             import threading
+            watch = [(c, f) for c, f in self.cards if self.match in (None, c)]
 
             def run():
                 while not self._stop:
-                    self.samples.append((self._read(self.files.get("power_uw", "")), self._read(self.files.get("sclk_hz", ""))))
+                    for c, f in watch:
+                        self.samples[c].append((self._read(f.get("power_uw")), self._read(f.get("sclk_hz"))))
                     time.sleep(0.004)
             self._thr = threading.Thread(target=run, daemon=True)
             self._thr.start()
@@ -469,15 +465,26 @@ class PowerSampler:
             self._thr.join(timeout=1.0)
 
     def result(self):
-        pw = [p for p, _ in self.samples if p]
-        ck = [c for _, c in self.samples if c]
-        if not pw and not ck:
+        best = None
+        for c, f in self.cards:
+            smp = self.samples.get(c) or []
+            pw = [p for p, _ in smp if p]
+            ck = [k for _, k in smp if k]
+            if not pw and not ck:
+                continue
+            avg = sum(pw) / len(pw) if pw else 0.0
+            if best is None or avg > best[0]:
+                best = (avg, c, f, pw, ck, len(smp))
+        if best is None:
             return None
-        cap = self._read(self.files["cap_uw"]) if "cap_uw" in self.files else None
-        return {"samples": len(self.samples), "avg_power_w": round(sum(pw) / len(pw) / 1e6, 1) if pw else None,
+        _, c, f, pw, ck, n = best
+        cap = self._read(f.get("cap_uw"))
+        return {"samples": n, "avg_power_w": round(sum(pw) / len(pw) / 1e6, 1) if pw else None,
                 "max_power_w": round(max(pw) / 1e6, 1) if pw else None, "power_cap_w": round(cap / 1e6, 1) if cap else None,
                 "avg_sclk_mhz": round(sum(ck) / len(ck) / 1e6, 1) if ck else None,
                 "min_sclk_mhz": round(min(ck) / 1e6, 1) if ck else None, "nominal_sclk_mhz": 2400,
+                "card": os.path.basename(os.path.dirname(os.path.dirname(os.path.dirname(c)))),
+                "card_matched_by": "pci address" if self.match else "highest average power over the region",
                 "source": "amdgpu hwmon (power1_average / freq1_input), polled every 4 ms over the timed region"}
 
 
@@ -746,7 +753,7 @@ def main():
             if whole:
                 res["step"] = whole
                 ck = (res.get("power") or {}).get("avg_sclk_mhz")
-                if ck:   # the same step against the MFMA rate of the clock the chip actually held under its power cap
+                if ck and ck > 500:   # the same step against the MFMA rate of the clock the chip actually held under its power cap
                     whole["frac_of_mfma_peak_at_measured_sclk"] = round(whole["tflops"] / (whole["peak"] * ck / 2400.0), 4)
             res["roofline_hbm"] = measure_hbm_stages(eng, min(B, 64), L)
         if args.cpu_baseline_clips > 0:
