@@ -243,24 +243,42 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The committed bench line of the default workload (profiles/r02_bench_gsr16x10.json) carries every key of the
-    bench.py contract, including the `roofline`, `cpu_baseline` and in-run `parity` objects, with self-consistent numbers."""
+    """The committed bench line of the default workload (profiles/r03_bench_gsr16x10.json) carries every key of the
+    bench.py contract, including the `roofline`, `cpu_baseline`, in-run `parity`, `step`, `power` and `aux_workloads` objects,
+    with self-consistent numbers; the roofline follows SURVEY.md section 8(d) (a ResStack layer = 8 bytes per element)."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_gsr16x10.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_gsr16x10.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "step", "aux_workloads"):
         assert k in d, k
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert d["config"]["workload"] == "gsr16x10" and "model" not in d["config"]
     assert d["parity"]["logmel_l1"] < d["parity"]["bar"]["logmel_l1"] and d["parity"]["clips"] >= 1
+    assert d["f16_saturated"] is False and d["negative_input_flag"] == 0
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "accounting", "design_bytes_per_launch"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # section 8(d): the dominant kernel is a ResStack layer of 16 clips x 147 882 positions x 128 channels: 8 bytes per element
+    assert "k_resblock<128, 4> f16" in r["kernel"] and r["algorithmic_bytes_per_launch"] == 16 * 147882 * 128 * 8
+    assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2          # x is read once
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.01 * r["achieved"]
+    for name, k in r["all_conv_kernels"].items():
+        assert 0 < k["frac_mfma"] < 1 and 0 < k["frac_hbm"] < 1, name
+    st = d["step"]
+    assert abs(st["tflops"] - st["gflop"] / st["ms"]) < 0.01 * st["tflops"] and abs(st["frac_of_mfma_peak"] - st["tflops"] / st["peak"]) < 1e-3
+    assert abs(st["ms"] - d["ms_per_step"]) < 1e-6
+    pw = d["power"]
+    assert pw["card_matched_by"] == "pci address" and 500 < pw["avg_power_w"] <= pw["power_cap_w"] and 1000 < pw["avg_sclk_mhz"] <= 2400
+    for name in ("ssr_sr64", "stream1s"):
+        a = d["aux_workloads"][name]
+        for k in ("value", "ms_per_step", "parity", "roofline", "cpu_baseline"):
+            assert k in a, (name, k)
+        assert "FLOAT64" in a["parity"]["vs"] and a["parity"]["wav_sisdr_db"] > 50
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "timed_calls"):
         assert k in c, k
-    assert c["kind"] in ("reference", "port")
+    assert c["kind"] in ("reference", "port") and c["statistic"] == "median" and len(c["timed_calls"]) >= 3
     # value = audio seconds of all ranks / wall seconds
     audio = d["n_gpus"] * d["config"]["clips_per_gpu"] * d["config"]["clip_seconds"]
     assert abs(d["value"] - audio / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
