@@ -68,7 +68,7 @@ namespace vfx {
 // the 32-channel form, and every fetched byte is an operand).  HI without H64: raw fp32 sources, 32-channel stages,
 // transformed in place to fp16 in the first half of the row, two K = 16 steps per tap.
 template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false>
-__global__ __launch_bounds__(256, ((BN <= 64 || HI) && RING < 4) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
+__global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
   static_assert(!H64 || (HI && SPLIT), "H64 is a variant of the 16-bit mode");
   constexpr bool HI32 = HI && !H64;  // the hi fragments (f[0], f[2]) only
   constexpr int WAVES_N = BN / 32;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256, ((BN <= 64 || HI) && RING < 4) ? 3 : 2) void k
   //   t == NT-1     everything in flight (next taps' weights, the patch) lands before the transform / barrier.
   constexpr int AHEAD = RING - 1;
   constexpr int WL = HI32 ? 2 : 4;  // weight loads per tap and wave
-  BFrag R0 = {}, R1 = {}, R2 = {}, R3 = {};
+  BFrag R0 = {}, R1 = {}, R2 = {};
   const int nstages = st_hi - st_lo;  // stages of this block
   const int last = nstages - 1;
   // Cursor state lives in scalar registers; table fields are re-read only when a cursor enters a new stage, and the
@@ -417,10 +417,8 @@ __global__ __launch_bounds__(256, ((BN <= 64 || HI) && RING < 4) ? 3 : 2) void k
     }
     tap = stages[st < last ? st : last].poff[t];  // next step's tap (all fragment reads of this step have been consumed)
   };
-  static_assert(RING >= 2 && RING <= 4, "ring depth");
   fetch(R0);
-  if constexpr (RING >= 3) fetch(R1);
-  if constexpr (RING >= 4) fetch(R2);
+  if constexpr (RING == 3) fetch(R1);
   issue_patch(stages[0], 0);
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
   // Ring groups that no fetch has filled yet are defined by copies made AFTER the wait: a copy of a group whose
@@ -428,32 +426,15 @@ __global__ __launch_bounds__(256, ((BN <= 64 || HI) && RING < 4) ? 3 : 2) void k
   // compiler, the stale one may end up feeding the first tap.
   if constexpr (HI32) use_b_hi(R0);
   else use_b(R0);
-  if constexpr (RING >= 3) {
+  if constexpr (RING == 3) {
     if constexpr (HI32) use_b_hi(R1);
     else use_b(R1);
   } else {
     R1 = R0;
   }
-  if constexpr (RING >= 4) {
-    if constexpr (HI32) use_b_hi(R2);
-    else use_b(R2);
-  } else {
-    R2 = R1;
-  }
-  R3 = R2;
+  R2 = R1;
   if (praw) transform_patch(stages[0], 0);
-  if constexpr (RING == 4) {
-    while (true) {
-      step(R0, R3);
-      if (st > last) break;
-      step(R1, R0);
-      if (st > last) break;
-      step(R2, R1);
-      if (st > last) break;
-      step(R3, R2);
-      if (st > last) break;
-    }
-  } else if constexpr (RING == 3) {
+  if constexpr (RING == 3) {
     while (true) {
       step(R0, R2);
       if (st > last) break;
@@ -522,27 +503,8 @@ static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvP
 }
 #endif
 
-// Launches of a few blocks per CU (the deep ResUNet levels, every level of the 1-s streaming step): nothing hides a block's
-// own latency chain, and with one or two taps of look-ahead every tap waits for most of an L2 / HBM round trip -- a tap of the
-// BN = 32 tile is 6 MFMAs, 0.1 us.  These launches take the ring of FOUR groups (three taps ahead; same blocks per CU).
-constexpr int kDeepRingMaxBlocks = 2048;
-
 template <bool ELU, bool SPLIT, bool HI = false, bool H64 = false>
 static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams* dparams) {
-  if constexpr (!HI) {
-    if (grid <= kDeepRingMaxBlocks) {
-      // (not the BN = 64 tile: with a fourth group it needs 186 registers, two blocks per CU instead of three, and the level
-      // it serves launches 768 blocks = three per CU)
-      if (BN == 128) {
-        launch_one<128, ELU, SPLIT, 0, 4>(grid, stream, dparams);
-        return;
-      }
-      if (BN == 32) {
-        launch_one<32, ELU, SPLIT, 0, 4>(grid, stream, dparams);
-        return;
-      }
-    }
-  }
   switch (BN) {
     // H64: a tap is four K = 16 steps (as long as two taps of the 32-channel form), so one tap of look-ahead covers the
     // same time with a third less ring registers (with three groups the BN = 128 tile spills at three waves per SIMD)
