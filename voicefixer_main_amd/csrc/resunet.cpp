@@ -320,6 +320,55 @@ struct TrunkBuilder {
   // BN -> ReLU -> ConvTranspose2d(k3, s2, p0) -> prune (modules.py:205-214)
   Act4 upsample(const DecoderW& D, const Act4& x, bool prune_w) {
     Act4 y = make(2 * x.H, prune_w ? 2 * x.W : 2 * x.W + 1, D.cout);
+    auto parity_taps = [](TapSeg& S, int a, int b) {
+      S.ntaps = 0;
+      for (int kh = a; kh < 3; kh += 2)
+        for (int kw = b; kw < 3; kw += 2) {
+          S.dh[S.ntaps] = -(kh / 2);  // oh = 2*ih + kh  ->  ih = i - kh/2 for oh = 2i + a
+          S.dw[S.ntaps] = -(kw / 2);
+          ++S.ntaps;
+        }
+    };
+    if (prune_w && !(pb.h->cfg.tuning & VFX_TUNE_NO_FUSED_UNET)) {
+      // An even output width makes (B, 2H, 2W, C) a (B, 2H, W, 2C) tensor whose channel halves are the two column parities:
+      // the column classes of one row class are the PHASES of one launch (own taps, own weight tensor, one patch) -- two
+      // launches per upsampler instead of four.  In the deep levels a launch is a chain of patch round trips, one per 32-channel
+      // stage, whatever it computes (25-45 us each, profiles/r03_c10_ring4_ab.jsonl): half the launches, half that time.
+      for (int a = 0; a < 2; ++a) {
+        TapConvParams p{};
+        p.B = B;
+        p.Hi = x.H;
+        p.Wi = x.W;
+        p.Ho = y.H;
+        p.Wo = x.W;
+        p.Cout = 2 * D.cout;
+        p.sh = 2;
+        p.sw = 1;
+        p.oh0 = a;
+        p.ow0 = 0;
+        p.Hg = (y.H - a + 1) / 2;
+        p.Wg = x.W;
+        p.out = const_cast<float*>(rel_ptr(y.off));
+        p.act_slope = 1.f;
+        p.nseg = 1;
+        std::vector<TapSeg> phases(2);
+        for (int b = 0; b < 2; ++b) {
+          TapSeg& S = phases[b];
+          S = TapSeg{};
+          S.src = rel_ptr(x.off);
+          S.C = x.C;
+          S.scale = D.bn_scale;
+          S.shift = D.bn_shift;
+          S.act = ACT_LEAKY;
+          S.slope = 0.f;  // ReLU
+          S.wt = D.wT[a * 2 + b];
+          parity_taps(S, a, b);
+        }
+        p.seg[0] = phases[0];  // column class 0 reads kw = 0, 2: its taps are the union of both classes' windows
+        pb.add_conv_phased(p, phases);
+      }
+      return y;
+    }
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b) {
         TapConvParams p{};
@@ -345,13 +394,7 @@ struct TrunkBuilder {
         S.act = ACT_LEAKY;
         S.slope = 0.f;  // ReLU
         S.wt = D.wT[a * 2 + b];
-        S.ntaps = 0;
-        for (int kh = a; kh < 3; kh += 2)
-          for (int kw = b; kw < 3; kw += 2) {
-            S.dh[S.ntaps] = -(kh / 2);  // oh = 2*ih + kh  ->  ih = i - kh/2 for oh = 2i + a
-            S.dw[S.ntaps] = -(kw / 2);
-            ++S.ntaps;
-          }
+        parity_taps(S, a, b);
         pb.add_conv(p);
       }
     return y;
