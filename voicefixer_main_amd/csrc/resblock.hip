@@ -182,23 +182,6 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
     }
   };
   const int nq = (P + RG - 1) / RG;
-  // 2-D mode: the patch goes global -> registers -> operand rows (no LDS-DMA staging, no read-back: what resblock_r128.hip
-  // gained 6 % with); a thread loads exactly the pieces it transforms -- patch rows lr + RG q, 16-byte piece cg -- for every chunk
-  // up front (48 registers at C = 32 and at C = 64).  Out-of-image pixels are loaded beyond the descriptor's bound: zeros.
-  f32x4 xr[G2 ? NCH : 1][G2 ? NG : 1];
-  auto load_patch_regs = [&]() __attribute__((always_inline)) {
-    if constexpr (G2) {
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(p.x), 0, (int)(unsigned)((int64_t)p.B * Hh * Ww * C * 4), 0x00020000);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int q = 0; q < NG; ++q) {
-          const unsigned o = (okmask & (1u << q)) ? voff[q] + (unsigned)(c * kKC * 4) + 16u * cg : 0xfffffff0u;
-          xr[c][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0));
-        }
-    }
-  };
   f32x4 keep[KEEPRES ? NCH : 1][KEEPRES ? NG : 1];  // raw x of this thread's patch pixels, all chunks
   auto transform_patch = [&](int dst, int c) __attribute__((always_inline)) {
     char* row0 = lds + dst + lr * CROW;
@@ -212,8 +195,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
 #pragma unroll
     for (int q = 0; q < NG; ++q)
       if (q * RG < 128 || q < nq) {
-        if constexpr (G2) raw[q] = xr[c][q];
-        else raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
+        raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
         if constexpr (KEEPRES) keep[c][q] = raw[q];
       }
 #pragma unroll
@@ -337,8 +319,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
   // ~5 GB per layer through the fabric at ~4.9 TB/s, it is bandwidth-, not latency-bound.)
 #pragma unroll
   for (int g = 0; g < AHEAD; ++g) fetch(g);
-  if constexpr (G2) load_patch_regs();
-  else issue_patch(0, 0);
+  issue_patch(0, 0);
   // NBUF = 3 (four chunks: C = 128): chunks 0, 1, 2 arrive in ONE round trip, chunk 3 goes into chunk 0's buffer once conv1 is
   // done with it -- two exposed memory latencies per tile instead of four (a chunk is 0.2 us of MFMAs, a round trip 2 us)
   if constexpr (NBUF == 3) {
@@ -351,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
   for (int c = 0; c < NCH; ++c) {
     // the patch requested while this chunk is computed: the next one, or (three buffers) chunk 3 during chunk 1
     const int dma_chunk = NBUF == 3 ? (c == 1 ? 3 : NCH) : c + 1;
-    const bool has_dma = !G2 && dma_chunk < NCH;  // 2-D mode: every chunk is in registers already
+    const bool has_dma = dma_chunk < NCH;
     __syncthreads();  // patch c is visible; the buffer of the chunk before it is free
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
