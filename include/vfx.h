@@ -53,7 +53,7 @@ enum {
   VFX_TUNE_NO_FUSED_WIDE = 2,      /* ... the C = 256 layers of the 16-bit mode as two launches per layer (two-form trunk) */
   VFX_TUNE_NO_FUSED_UNET = 4,      /* identity-shortcut ConvBlockRes of the ResUNets (C = 32, 64) as two launches */
   VFX_TUNE_NO_PERSISTENT_C64 = 8,  /* 16-bit mode, C = 64 layers on k_resblock instead of the persistent kernel */
-  VFX_TUNE_NO_PAIRS = 16,          /* 16-bit mode, C = 64: one launch per layer (no layer pairs) */
+  VFX_TUNE_NO_PAIRS = 16,          /* 16-bit mode, C = 64 / 128: one launch per layer (no layer pairs) */
   VFX_TUNE_NO_SPLITK = 32,         /* no split-K in the deep ResUNet levels */
   VFX_TUNE_WIDE_8WAVE = 64,        /* C = 256 layers on the 8-wave / one-block-per-CU kernel (resblock_act.hip, two-form trunk) */
   VFX_TUNE_C128_8WAVE = 128,       /* 16-bit mode, C = 128 layers on k_resblock<128, 8> (re-reads the residual) */
@@ -245,8 +245,8 @@ int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int precision, i
 int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2, int precision, int tuning, int* out);
 
 /* Two consecutive ResStack layers (dilations dil, dil2) as ONE launch: y = layer_b(layer_a(x)), the intermediate tensor never
- * leaves the CU (resblock_rw.hip).  precision 2, C = 64, dil <= 32, dil2 <= 62 only -- what the vocoder plan pairs (dilations
- * (1, 3) and (9, 27) of the 44.1 kHz stack).  Weights / biases as in vfx_op_resblock, on the HOST. */
+ * leaves the CU.  precision 2 only; C = 64 (resblock_rw.hip): dil <= 32, dil2 <= 62; C = 128 (resblock_r128.hip): dil <= 16,
+ * dil2 <= 4 -- what the vocoder plan pairs: dilations (1, 3) and, at C = 64, (9, 27) of the 44.1 kHz stack.  Weights / biases as in vfx_op_resblock, on the HOST. */
 int vfx_op_resblock_pair(vfx_handle* h, const float* x, int B, int T, int C, const float* wa1, const float* ba1,
                          const float* wa2, const float* ba2, int dil, const float* wb1, const float* bb1,
                          const float* wb2, const float* bb2, int dil2, float slope, float* y, void* stream);

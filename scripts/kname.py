@@ -4,7 +4,7 @@ k_conv<BN, ELU, SPLIT, ABL, RING, HI>  ->  "k_conv<BN, ELU, SPLIT>" (+ " f16" fo
 k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
 k_resblock_act<C, NW, MT>              ->  "k_resblock<C, NW> f16"
 k_resblock_w64<C>                      ->  "k_resblock<C, 4> f16"
-k_resblock_r128                        ->  "k_resblock<128, 4> f16"
+k_resblock_r128<PAIR>                  ->  "k_resblock<128, 4> f16" / "k_resblock_pair<128, 4> f16"
 k_resblock_s256                        ->  "k_resblock<256, 4> f16"
 k_resblock_rw<NW, PAIR>                ->  "k_resblock<64, NW> f16" / "k_resblock_pair<64, NW> f16"
 """
@@ -23,8 +23,8 @@ def short(n, width=40):
         return "k_resblock<%s, %s> f16" % (args[0], args[1])
     if name == "k_resblock_w64" and args:                # the same layer as 4-wave blocks, two per CU
         return "k_resblock<%s, 4> f16" % args[0]
-    if name == "k_resblock_r128":                        # C = 128, 16-bit mode: 4-wave blocks, x read once
-        return "k_resblock<128, 4> f16"
+    if name == "k_resblock_r128":                        # C = 128, 16-bit mode: 4-wave blocks, x read once; <true>: a layer pair
+        return "k_resblock_pair<128, 4> f16" if args and args[0] == "true" else "k_resblock<128, 4> f16"
     if name == "k_resblock_s256":                        # C = 256, 16-bit mode, single-form trunk: 4-wave blocks of 64 positions
         return "k_resblock<256, 4> f16"
     if name == "k_resblock_rw" and args:                 # C = 64, 16-bit mode: persistent, weights in registers

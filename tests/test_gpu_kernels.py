@@ -124,18 +124,18 @@ def test_resblock_layer_long_sequence(engine):
         assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), (d, err)
 
 
-@pytest.mark.parametrize("T", [70001, 300, 3])
-def test_resblock_layer_pair(engine, T):
-    """Two consecutive ResStack layers as ONE launch (resblock_rw.hip, 16-bit mode, C = 64): the pairs the vocoder plan forms
-    -- dilations (1, 3) and (9, 27) -- and one more, over several tiles per block, a single partial tile and a sequence shorter
-    than every halo.  The tensor between the layers exists only inside the kernel."""
+@pytest.mark.parametrize("C,T", [(64, 70001), (64, 300), (64, 3), (128, 70001), (128, 300), (128, 3)])
+def test_resblock_layer_pair(engine, C, T):
+    """Two consecutive ResStack layers as ONE launch (16-bit mode; C = 64: resblock_rw.hip, C = 128: resblock_r128.hip): the pairs
+    the vocoder plan forms -- dilations (1, 3) and, at C = 64, (9, 27) -- and one more, over several tiles per block, a single
+    partial tile and a sequence shorter than every halo.  The tensor between the layers exists only inside the kernel."""
     if engine.tol['name'] != 'fp16-vocoder':
         pytest.skip("layer pairs exist in the 16-bit mode only")
-    B, C = 3, 64
+    B = 3
     x = _rand((B, C, T), 51)
     la = (_rand((C, C, 3), 52, 0.08), _rand((C,), 53, 0.1), _rand((C, C, 3), 54, 0.08), _rand((C,), 55, 0.1))
     lb = (_rand((C, C, 3), 56, 0.08), _rand((C,), 57, 0.1), _rand((C, C, 3), 58, 0.08), _rand((C,), 59, 0.1))
-    for da, db in ((1, 3), (9, 27), (3, 9)):
+    for da, db in (((1, 3), (9, 27), (3, 9)) if C == 64 else ((1, 3), (2, 4), (16, 1))):
         y1 = _resblock_ref(x, la[0], la[1], la[2], la[3], da, 0.01)
         ref = _resblock_ref(y1, lb[0], lb[1], lb[2], lb[3], db, 0.01)
         y = engine.op_resblock_pair(x.permute(0, 2, 1).contiguous(), [a.numpy() for a in la], da, [a.numpy() for a in lb], db, 0.01)

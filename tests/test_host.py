@@ -297,6 +297,8 @@ def test_resblock_tiles_cover_every_position_once(C, precision, tuning):
     cases = [(d, 0) for d in (1, 3, 9, 27, 81, 243, 729, 2187)]
     if C == 64 and precision == 2:
         cases += [(1, 3), (9, 27), (3, 9)]
+    if C == 128 and precision == 2 and tuning == 0:
+        cases += [(1, 3), (2, 4), (16, 1)]
     for T in (3, 90, 1000, 49049, 70001):
         for d, d2 in cases:
             assert lib.vfx_plan_resblock_geometry_tuned(C, T, d, d2, precision, tuning, out) == 0, (T, d, d2)
@@ -414,7 +416,8 @@ def test_profile_kernel_names():
     assert short(ns + "k_resblock_rw<4, false>(vfx::ResBlockParams const*, int, int)") == "k_resblock<64, 4> f16"
     assert short(ns + "k_resblock_act<256, 8, 128>(vfx::ResBlockParams const*)") == "k_resblock<256, 8> f16"
     assert short(ns + "k_resblock_w64<256>(vfx::ResBlockParams const*)") == "k_resblock<256, 4> f16"
-    assert short(ns + "k_resblock_r128(vfx::ResBlockParams const*)") == "k_resblock<128, 4> f16"
+    assert short(ns + "k_resblock_r128<false>(vfx::ResBlockParams const*)") == "k_resblock<128, 4> f16"
+    assert short(ns + "k_resblock_r128<true>(vfx::ResBlockParams const*)") == "k_resblock_pair<128, 4> f16"
     assert short(ns + "k_resblock_s256(vfx::ResBlockParams const*)") == "k_resblock<256, 4> f16"
     assert short(ns + "k_resblock<32, 2, false, true>(vfx::ResBlockParams const*)") == "k_resblock<32, 2>"
     assert short(ns + "k_resblock<128, 8, true, false>(vfx::ResBlockParams const*)") == "k_resblock<128, 8> f16"

@@ -266,7 +266,8 @@ extern "C" int vfx_op_resblock_pair(vfx_handle* h, const float* x, int B, int T,
   try {
     VFX_CHECK(h && x && y && wa1 && ba1 && wa2 && ba2 && wb1 && bb1 && wb2 && bb2 && B > 0 && T > 0, "bad argument");
     DeviceGuard device_guard_(h->device);
-    VFX_CHECK(h->cfg.precision == 2 && resblock_rw_pair_ok(C, dil, dil2, h->cfg.tuning), "vfx_op_resblock_pair: needs the 16-bit mode, C = 64 and small dilations");
+    VFX_CHECK(h->cfg.precision == 2 && (resblock_rw_pair_ok(C, dil, dil2, h->cfg.tuning) || resblock_r128_pair_ok(C, dil, dil2, h->cfg.tuning)),
+              "vfx_op_resblock_pair: needs the 16-bit mode and a pair the plan would build (C = 64: dil <= 32, dil2 <= 62; C = 128: (1, 3))");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scratch sc;
     std::vector<std::pair<int, int>> taps = {{0, 0}, {0, 1}, {0, 2}};
@@ -289,6 +290,7 @@ extern "C" int vfx_op_resblock_pair(vfx_handle* h, const float* x, int B, int T,
     rp.flags = h->d_flags;
     rp.dil = dil;
     rp.dil2 = dil2;
+    rp.tuning = h->cfg.tuning;
     float* dya = static_cast<float*>(sc.blob.alloc((size_t)B * T * C * sizeof(_Float16)));
     rp.ya = dya;
     rp.act_slope = slope;

@@ -591,7 +591,8 @@ void plan_resblock(ResBlockParams& p) {
   // patch rows per buffer: MT + 64 (= kPatchMaxRows for MT = 128); the 4-wave form of the wide layer keeps four chunk
   // buffers in half a CU's LDS: 160 rows (resblock_w64.hip)
   p.patch_rows = (p.asrc && MT == 128 && p.dil2 == 0 && resblock_w64_enabled(p.tuning)) ? resblock_w64_patch_rows() : 0;
-  p.r128 = (!p.asrc && !p.rw && p.hionly && p.C == 128 && MT == 128 && p.dil2 == 0 && resblock_r128_enabled(p.tuning)) ? 1 : 0;
+  p.r128 = (!p.asrc && !p.rw && p.hionly && p.C == 128 && MT == 128 && resblock_r128_enabled(p.tuning) &&
+            (p.dil2 == 0 || resblock_r128_pair_ok(p.C, d, p.dil2, p.tuning))) ? 1 : 0;
   if (p.r128) p.patch_rows = resblock_r128_patch_rows();
   if (p.s256) p.patch_rows = resblock_s256_patch_rows();
   const int PR = p.patch_rows ? p.patch_rows : MT + 64;
@@ -599,7 +600,8 @@ void plan_resblock(ResBlockParams& p) {
   p.tile_m = MT;
   if (p.dil2 > 0) {
     // layer pair: both layers over the MT-index space of the tile, MT - 4 - 2 dil2 outputs per tile (resblock_rw.hip)
-    VFX_CHECK(p.rw && resblock_rw_pair_ok(p.C, d, p.dil2, p.tuning), "resblock: layers of dilation %d, %d cannot run as a pair", d, p.dil2);
+    VFX_CHECK((p.rw && resblock_rw_pair_ok(p.C, d, p.dil2, p.tuning)) || (p.r128 && MT + 2 * d <= PR && MT + 2 * p.dil2 <= PR),
+              "resblock: layers of dilation %d, %d cannot run as a pair", d, p.dil2);
     p.fold = 0;
     p.TH = 1;
     p.W1 = MT;

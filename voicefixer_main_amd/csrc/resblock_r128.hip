@@ -28,6 +28,11 @@ namespace {
 constexpr int R128_PR = 160;  // patch rows per chunk buffer
 }
 
+// PAIR: TWO consecutive layers (dilations d, d2: the plan pairs (1, 3)) in one pass -- the first layer's output y1 never leaves
+// the CU: raw, it replaces x in the 64 registers that hold the residual; activated, it is written as the operand patch of the
+// second layer over the first one's.  Both layers work over the 128-index space of the tile: y1 is valid on indices 1 .. 126, the
+// second layer's h on 1 + d2 .. 126 - d2, the outputs on 2 + d2 .. 125 - d2 (plan_resblock: 128 - 4 - 2 d2 positions per tile).
+template <bool PAIR>
 __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* __restrict__ pp) {
   constexpr int C = 128, NW = 4, NTHR = NW * 64, MT = 128;
   constexpr int NCH = C / 32;                // 32-channel chunks = waves along the couts
@@ -37,9 +42,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   constexpr int WM = 2, WN = 2;              // 32-position blocks / 32-cout blocks per wave: 64 positions x 64 couts
   constexpr int WL = 2 * WN;                 // weight loads per tap and wave (the hi fragments f[0], f[2] of two cout blocks): the vmcnt counts below
   static_assert(WL == 4, "the hand-counted waits of conv() assume four loads per tap");
-  constexpr int RING = 4, AHEAD = RING - 1;  // weight taps in flight: a tap is 8 MFMAs (256 cycles), an L2 round trip ~3 of them
+  // weight taps in flight: a tap is 8 MFMAs (256 cycles), an L2 round trip ~3 of them (a pair keeps one slot less: registers)
+  constexpr int RING = PAIR ? 3 : 4, AHEAD = RING - 1;
   constexpr int HROW = C * 4;                // bytes per h row (operand form: 128-byte chunk rows, fp16 in the first half)
   constexpr int NT1 = 3 * NCH;               // taps of conv1 (chunk-major); conv2 has as many
+  constexpr int NTOT = (PAIR ? 4 : 2) * NT1; // taps of the launch
   constexpr int LDO = C + 4;                 // staged output row (floats)
   constexpr int KEEP = MT / 8;               // centre rows per thread (16: rows rt + 8 j of one chunk)
 
@@ -64,7 +71,9 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
   const int rowstride = p.fold ? d : 0;
   const int j0 = tj * p.TWo;
-  const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
+  const int d2 = PAIR ? p.dil2 : 0;
+  // position of h pixel (0, 0); a pair's tile starts 1 + d2 further left (the second layer's halo)
+  const int base_h = PAIR ? j0 - 2 - d2 : (p.fold ? ti * TH * d + j0 - 1 : j0 - 1);
   const int base_x = base_h - d;                                // position of patch pixel (0, 0)
   const float slope = p.slope;
   // m / W1 and prow / PW as multiply-shift (rows < 512, divisors <= 320: exact; cf. resblock_rw.hip): an integer division is ~25 VALU
@@ -92,6 +101,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   const int64_t ts = (int64_t)C * kKC;
   const float* const w1p = p.w1;
   const float* const w2p = p.w2;
+  const float* const w1bp = PAIR ? p.w1b : nullptr;
+  const float* const w2bp = PAIR ? p.w2b : nullptr;
   const int poff0 = p.poff[0], poff1 = p.poff[1], poff2 = p.poff[2];
 
   f32x16 acc[WN][WM];
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         : "v"(nb_off), "v"(nb_off2), "s"(wtap));
   };
   auto fetch = [&](int g) __attribute__((always_inline)) {
-    const float* w = g < NT1 ? w1p + g * ts : w2p + (g - NT1) * ts;
+    const float* w = g < NT1 ? w1p + g * ts : (g < 2 * NT1 ? w2p + (g - NT1) * ts : (g < 3 * NT1 ? w1bp + (g - 2 * NT1) * ts : w2bp + (g - 3 * NT1) * ts));
     switch (g % RING) {
       case 0: load_w(Wa0, Wb0, Wc0, Wd0, w); break;
       case 1: load_w(Wa1, Wb1, Wc1, Wd1, w); break;
@@ -194,18 +205,21 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   // ---- pixel fragments: software-pipelined one K step (4 MFMAs) ahead ------------------------------------------------------------
   int rb[2][WM], kx[2][WM];
   auto prep1 = [&](int g) __attribute__((always_inline)) {  // conv1: the patch chunk of tap g, rows arow1 + tap offset
-    const int c = g / 3, k = g % 3;
+    const bool second = g >= 2 * NT1;  // a pair's second layer: y1a row of index m sits at patch row m + d2, tap k reads m + k d2
+    const int gl = second ? g - 2 * NT1 : g;
+    const int c = gl / 3, k = gl % 3;
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
-      int r = arow1[a];
+      int r = second ? wm * 64 + a * 32 + l31 : arow1[a];
       asm volatile("" : "+v"(r));  // per-tap addresses are recomputed, not kept
-      const int row = r + (k == 0 ? poff0 : (k == 1 ? poff1 : poff2));
+      const int row = r + (second ? k * d2 : (k == 0 ? poff0 : (k == 1 ? poff1 : poff2)));
       rb[g & 1][a] = c * PBYTES + row * CROW;
       kx[g & 1][a] = swz_key(row) ^ (16 * lh);
     }
   };
   auto prep2 = [&](int g) __attribute__((always_inline)) {  // conv2: h rows m + k - 1; chunk c of row r sits at chunk position c ^ (r & 1)
-    const int c = (g - NT1) / 3, k = (g - NT1) % 3;
+    const int gl = g >= 3 * NT1 ? g - 3 * NT1 : g - NT1;
+    const int c = gl / 3, k = gl % 3;
     int lrow = l31;
     asm volatile("" : "+v"(lrow));
 #pragma unroll
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     __builtin_amdgcn_sched_group_barrier(0x100, WM, 0);  // the prologue's reads are a group of their own: the pattern below starts behind them
 #pragma unroll
     for (int g = g0; g < g1; ++g) {
-      const int gmax = more ? 2 * NT1 : g1;  // taps that exist
+      const int gmax = more ? NTOT : g1;  // taps that exist
       // fetch tap g + AHEAD if it exists; then tap g's loads are older than the fetches issued after them
       const int younger = (g + AHEAD < gmax ? AHEAD : gmax - 1 - g);
       if (g + AHEAD < gmax) fetch(g + AHEAD);
@@ -268,23 +282,17 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     }
   };
 
-  // ---- phase 1: conv1 (its last taps fetch the first taps of conv2) --------------------------------------------------------------
-  conv(prep1, 0, NT1, true);
-  VFX_TS(5);  // conv1 done
-  __syncthreads();  // every wave is done reading the patch buffers that h overlays
-  VFX_TS(6);
-
-  // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------------------------
+  // h = LeakyReLU(conv1 + bias) in operand form, zero where `valid` says the h pixel lies outside the tile's grid / the sequence.
   // Lane (l31, lh) of position block a holds h pixel m = 64 wm + 32 a + l31 and, in registers 4j .. 4j+3 of cout block n, channels
   // (2 wn + n) * 32 + 8j + 4lh .. +3: chunk 2 wn + n of the pixel's row, piece j, half lh.
-  {
+  auto write_h = [&](const float* bias, const bool (&valid)[WM]) __attribute__((always_inline)) {
     unsigned f16_sat = 0;
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
       const int ch = 2 * wn + n;
       f32x4 b1v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b1v[j] = *(const VFX_GLOBAL f32x4*)(p.b1 + ch * 32 + 8 * j + 4 * lh);
+      for (int j = 0; j < 4; ++j) b1v[j] = *(const VFX_GLOBAL f32x4*)(bias + ch * 32 + 8 * j + 4 * lh);
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
         const int m = wm * 64 + a * 32 + l31;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float t = acc[n][a][4 * j + e] + b1v[j][e];
-            u[e] = hval[a] ? fmaxf(t, t * slope) : 0.f;
+            u[e] = valid[a] ? fmaxf(t, t * slope) : 0.f;
             acc[n][a][4 * j + e] = 0.f;
           }
           *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1], f16_sat), pack_f16x2(u[2], u[3], f16_sat));
@@ -304,35 +312,98 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       }
     }
     report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
-  }
+  };
+  // the accumulators of a conv2 staged in LDS as whole rows
+  auto stage_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wm * 64 + a * 32 + l31;
+          *reinterpret_cast<f32x4*>(smem + row * LDO + (2 * wn + n) * 32 + 8 * j + 4 * lh) =
+              f32x4{acc[n][a][4 * j], acc[n][a][4 * j + 1], acc[n][a][4 * j + 2], acc[n][a][4 * j + 3]};
+        }
+  };
+  constexpr int V = C / 4, RPP = NTHR / V, NPASS = MT / RPP;  // 32 float4 per row, 8 rows per step, 16 steps
+  const int c4 = tid % V, r0 = tid / V;  // = (ct * 8 + cgt, rt) of the patch loads: keep[q] is x at row r0 + 8 q, channels 4 c4 ..
+  static_assert(V == 32 && RPP == 8 && NPASS == KEEP, "the output pass must walk the rows the loads kept");
+
+  // ---- first (or only) layer -----------------------------------------------------------------------------------------------------
+  conv(prep1, 0, NT1, true);  // its last taps fetch the first taps of conv2
+  VFX_TS(5);  // conv1 done
+  __syncthreads();  // every wave is done reading the patch buffers that h overlays
+  VFX_TS(6);
+  write_h(p.b1, hval);
   VFX_TS(7);  // h written
   __syncthreads();  // h is complete
   VFX_TS(8);
-
-  // ---- phase 3: conv2 from the resident h ----------------------------------------------------------------------------------------
-  conv(prep2, NT1, 2 * NT1, false);
+  conv(prep2, NT1, 2 * NT1, PAIR);
   VFX_TS(9);  // conv2 done
   __syncthreads();  // every wave is done with h
   VFX_TS(10);
-
-  // ---- phase 4: y = conv2 + b2 + x: the accumulators staged in LDS, whole rows read back, the kept x rows added, stored ----------
-#pragma unroll
-  for (int n = 0; n < WN; ++n)
-#pragma unroll
-    for (int a = 0; a < WM; ++a)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wm * 64 + a * 32 + l31;
-        *reinterpret_cast<f32x4*>(smem + row * LDO + (2 * wn + n) * 32 + 8 * j + 4 * lh) =
-            f32x4{acc[n][a][4 * j], acc[n][a][4 * j + 1], acc[n][a][4 * j + 2], acc[n][a][4 * j + 3]};
-      }
+  stage_acc();
   __syncthreads();
   VFX_TS(11);  // staged
+
+  if constexpr (PAIR) {
+    // ---- between the layers: y1 = conv2 + b2 + x replaces x in the residual registers; LeakyReLU(y1) becomes the operand patch ----
+    // (index m at patch row m + d2; zero outside the sequence -- the second layer's zero padding -- and on the two indices of the
+    // tile where y1 is not valid).  Every staged row is read before any operand row is written: the two images overlap.
+    {
+      const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) keep[q] = *reinterpret_cast<const f32x4*>(smem + (r0 + q * RPP) * LDO + 4 * c4) + bv + keep[q];
+    }
+    __syncthreads();
+    {
+      unsigned f16_sat = 0;
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+        const int m = r0 + q * RPP;
+        const bool ok = (m >= 1) & (m <= MT - 2) & ((unsigned)(base_h + m) < (unsigned)T);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(keep[q][e], keep[q][e] * slope) : 0.f;
+        const int row = m + d2;
+        const int key = (row >> 1) & 7;
+        *reinterpret_cast<uint2*>(lds + ct * PBYTES + row * CROW + (((cgt >> 1) ^ key) << 4) + 8 * (cgt & 1)) =
+            make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
+      }
+      report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
+    }
+    __syncthreads();  // the second layer's operand rows are visible
+
+    // ---- second layer ---------------------------------------------------------------------------------------------------------------
+    bool hval2[WM];
+    int l31o = l31;
+    asm volatile("" : "+v"(l31o));
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const int m = wm * 64 + a * 32 + l31o;
+      hval2[a] = (m >= 1 + d2) & (m <= MT - 2 - d2) & ((unsigned)(base_h + m) < (unsigned)T);
+    }
+    // (cleared here, not when they were staged: 64 live zeros beside the residual and the ring do not fit the register file)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][a][r] = 0.f;
+    conv(prep1, 2 * NT1, 3 * NT1, true);
+    __syncthreads();
+    write_h(p.b1b, hval2);
+    __syncthreads();
+    conv(prep2, 3 * NT1, 4 * NT1, false);
+    __syncthreads();
+    stage_acc();
+    __syncthreads();
+  }
+
+  // ---- y = conv2 + b2 + residual: whole staged rows read back, the kept rows (x; a pair: y1) added, stored --------------------------
   {
-    constexpr int V = C / 4, RPP = NTHR / V, NPASS = MT / RPP;  // 32 float4 per row, 8 rows per step, 16 steps
-    const int c4 = tid % V, r0 = tid / V;  // = (ct * 8 + cgt, rt) of the transform: keep[q] is x at row r0 + 8 q, channels 4 c4 ..
-    static_assert(V == 32 && RPP == 8 && NPASS == KEEP, "the output pass must walk the rows the transform kept");
-    const f32x4 bv = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
+    const f32x4 bv = *(const VFX_GLOBAL f32x4*)((PAIR ? p.b2b : p.b2) + 4 * c4);
     const float aslope = p.act_slope;
     const bool even = (tid & 1) == 0;
     unsigned ya_sat = 0;
@@ -342,13 +413,16 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     const unsigned ybytes = (unsigned)((int64_t)p.B * T * C * 4);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(p.ya, 0, p.ya ? (int)(ybytes / 2) : 0, 0x00020000);
+    int r0o = r0;
+    if constexpr (PAIR) asm volatile("" : "+v"(r0o));  // recomputed here: row values shared with the pass between the layers would be kept (spilled) through the second layer
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
-      const int m = r0 + q * RPP;  // h pixel of the staged row
+      const int m = r0o + q * RPP;  // h pixel of the staged row
       const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
       const int pos = base_h + li * rowstride + lj;
-      const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
-      const f32x4 val = *reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * c4) + bv + keep[q];  // + x: this thread's own rows
+      const bool ok = PAIR ? ((m >= 2 + d2) & (m <= MT - 3 - d2) & ((unsigned)pos < (unsigned)T))
+                           : ((li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d)));
+      const f32x4 val = *reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * c4) + bv + keep[q];  // + the residual: this thread's own rows
       const unsigned off = (unsigned)(img * T + pos) * (unsigned)(C * 4) + 16u * c4;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ry, (int)(ok ? off : kOob), 0, 0);
       if (p.ya) {
@@ -375,9 +449,15 @@ int resblock_r128_patch_rows() { return R128_PR; }
 // The four-wave, read-x-once form runs the C = 128 layers of the 16-bit mode by default; VFX_TUNE_C128_8WAVE selects k_resblock<128, 8>.
 bool resblock_r128_enabled(int tuning) { return !(tuning & VFX_TUNE_C128_8WAVE); }
 
+// Layer pairs at C = 128: (d, d2) = (1, 3) -- 118 of a tile's 128 indices are outputs; (9, 27) would be 70.
+bool resblock_r128_pair_ok(int C, int dil, int dil2, int tuning) {
+  return !(tuning & VFX_TUNE_NO_PAIRS) && resblock_r128_enabled(tuning) && C == 128 && dil >= 1 && dil <= 16 && dil2 >= 1 && dil2 <= 4;
+}
+
 void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
-  VFX_CHECK(!hp.asrc && hp.hionly && hp.C == 128 && !hp.geo2d && hp.dil2 == 0 && hp.tile_m == 128 && hp.patch_rows == R128_PR,
+  VFX_CHECK(!hp.asrc && hp.hionly && hp.C == 128 && !hp.geo2d && hp.tile_m == 128 && hp.patch_rows == R128_PR,
             "resblock_r128: needs the 16-bit mode, C = 128, 128-position tiles planned with %d patch rows", R128_PR);
+  VFX_CHECK(hp.dil2 == 0 || (!hp.fold && hp.w1b && hp.w2b && hp.b1b && hp.b2b && 128 + 2 * hp.dil2 <= R128_PR), "resblock_r128: bad layer pair");
   VFX_CHECK((hp.fold ? hp.PW : hp.dil) <= 32, "resblock_r128: the residual window starts beyond patch row 32");
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock_r128: bad grid");
@@ -386,9 +466,11 @@ void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparam
   static_assert((128 / 32) * R128_PR * CROW >= 128 * (128 + 4) * 4 && (128 / 32) * R128_PR * CROW >= 128 * 128 * 4, "overlays must fit");
   static uint64_t attr_devices = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL(k_resblock_r128, dim3((int)grid), dim3(256), lds, stream, dparams);
+  if (hp.dil2 > 0) hipLaunchKernelGGL(k_resblock_r128<true>, dim3((int)grid), dim3(256), lds, stream, dparams);
+  else hipLaunchKernelGGL(k_resblock_r128<false>, dim3((int)grid), dim3(256), lds, stream, dparams);
   VFX_HIP(hipGetLastError());
 }
 

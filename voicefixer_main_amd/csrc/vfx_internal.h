@@ -234,6 +234,7 @@ void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams
 bool resblock_w64_enabled(int tuning);
 // resblock_r128.hip: C = 128, 16-bit mode -- 4-wave blocks, two per CU, x read once (the residual stays in registers)
 bool resblock_r128_enabled(int tuning);
+bool resblock_r128_pair_ok(int C, int dil, int dil2, int tuning);  // two layers (dil, dil2) as one launch: (1, 3)
 int resblock_r128_patch_rows();
 void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 // resblock_s256.hip: C = 256, 16-bit mode, single-form trunk -- 4-wave blocks of 64-position tiles, two per CU, x read once

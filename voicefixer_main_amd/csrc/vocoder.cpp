@@ -326,8 +326,10 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         VFX_CHECK(layer.first.mode == layer.second.mode &&
                       layer.first.mode == fused_layer_mode(cfg, up.cout),
                   "vocoder plan: the weights of a fused %d-channel layer are packed for another kernel", up.cout);
-        // 16-bit mode, C = 64: two layers of small dilation as one launch -- the tensor between them is never stored
-        if (rp.hionly && li + 1 < nlayers && resblock_rw_pair_ok(up.cout, dil, dil * cfg.voc_dilation_base, cfg.tuning)) {
+        // 16-bit mode, C = 64 ((1, 3), (9, 27)) and C = 128 ((1, 3)): two layers of small dilation as one launch -- the tensor
+        // between them is never stored
+        if (rp.hionly && li + 1 < nlayers && (resblock_rw_pair_ok(up.cout, dil, dil * cfg.voc_dilation_base, cfg.tuning) ||
+                                              resblock_r128_pair_ok(up.cout, dil, dil * cfg.voc_dilation_base, cfg.tuning))) {
           auto& next = W->res[st][li + 1];
           dil *= cfg.voc_dilation_base;
           ++li;
