@@ -64,10 +64,11 @@ def _resblock_ref(x, w1, b1, w2, b2, d, slope):
 
 
 @pytest.mark.parametrize("C,T,fused", [(64, 1000, True), (128, 777, True), (64, 90, True), (96, 500, False), (256, 333, False),
-                                       (256, 1100, True)])
+                                       (256, 1100, True), (128, 90, True), (256, 90, True), (128, 3, True)])
 def test_resblock_layer(engine, C, T, fused):
     """One ResStack layer (oracle/vocoder.py): fused k_resblock and the two-launch form with the activated
-    intermediate tensor, over the vocoder's dilations (plain tiles up to 27, folded geometry beyond, also d > T).
+    intermediate tensor, over the vocoder's dilations (plain tiles up to 27, folded geometry beyond, also d > T; T = 90 / 3 with
+    two clips: ONE tile per clip -- the tile -> clip split of the 4-wave kernels once divided by a reciprocal that overflowed there).
     C = 256 fused = the wide layer of the 16-bit mode on the two-form trunk (resblock_w64.hip; the entry point also checks its
     activated fp16 output against fp16(LeakyReLU(y))); its other forms: test_wide_layer_forms."""
     if fused and engine.tol['name'] == 'fp32':
@@ -85,8 +86,9 @@ def test_resblock_layer(engine, C, T, fused):
         assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), (d, err)
 
 
-@pytest.mark.parametrize("tuning,T", [(256, 1100), (256, 7350), (0, 1100), (0, 7350), (64, 1100)],
-                         ids=["single-form", "single-form-long", "two-form-w64", "two-form-w64-long", "two-form-8wave"])
+@pytest.mark.parametrize("tuning,T", [(256, 1100), (256, 7350), (0, 1100), (0, 7350), (64, 1100), (256, 50), (0, 50)],
+                         ids=["single-form", "single-form-long", "two-form-w64", "two-form-w64-long", "two-form-8wave",
+                              "single-form-one-tile", "two-form-w64-one-tile"])
 def test_wide_layer_forms(tuning, T):
     """The three kernels of the C = 256 layer of the 16-bit mode (vfx_config.tuning: 0 = resblock_w64.hip, two-form trunk;
     VFX_TUNE_WIDE_SINGLE_FORM = resblock_s256.hip, 64-position tiles; VFX_TUNE_WIDE_8WAVE = resblock_act.hip) against the float64

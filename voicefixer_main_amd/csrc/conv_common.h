@@ -70,6 +70,11 @@ __device__ __forceinline__ void report_f16_saturation(bool sat, int* flags) {
 #define VFX_TS_FLUSH(ptr, tile, wave, nwaves)
 #endif
 
+// n / d for the host's r = ceil(2^32 / d) (exact while n * d < 2^32, plan_resblock): r needs 33 bits when d = 1
+__device__ __forceinline__ int div_recip(int n, unsigned long long r) {
+  return (int)(((unsigned long long)(unsigned)n * (unsigned)r) >> 32) + ((r >> 32) ? n : 0);
+}
+
 constexpr int CBM = 128;                     // pixels per tile
 constexpr int CROW = 128;                    // bytes per patch row (32 channels)
 constexpr int CNQ = kPatchMaxRows / 32;      // patch row groups (one DMA instruction / register group each)

@@ -645,8 +645,8 @@ void plan_resblock(ResBlockParams& p) {
   p.inv_pw = ((1u << 20) + p.PW - 1) / p.PW;
   p.inv_w1 = ((1u << 20) + p.W1 - 1) / p.W1;
   const int64_t tpi = (int64_t)p.tiles_w * p.tiles_h;
-  p.inv_tiles_w = (unsigned)((((uint64_t)1 << 32) + p.tiles_w - 1) / p.tiles_w);
-  p.inv_tiles_per_img = (unsigned)((((uint64_t)1 << 32) + tpi - 1) / tpi);
+  p.inv_tiles_w = (((uint64_t)1 << 32) + p.tiles_w - 1) / p.tiles_w;  // = 2^32 for one tile: does not fit 32 bits
+  p.inv_tiles_per_img = (((uint64_t)1 << 32) + tpi - 1) / tpi;
   // exact while n * d < 2^32: n = tile index < B * tpi, d = tpi
   VFX_CHECK(!p.patch_rows || (double)p.B * (double)tpi * (double)tpi < 4294967296.0, "resblock: too many tiles for the reciprocal tile split");
   VFX_CHECK((int64_t)p.B * p.T * p.C * 4 < ((int64_t)1 << 32) - 4096, "resblock: tensor exceeds 4 GiB");

@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   VFX_TS_DECL;
   VFX_TS(0);
   // tile -> (image, tile row, tile column) with the host's reciprocals (plan_resblock): three integer divisions otherwise
-  const int img = (int)(((unsigned long long)(unsigned)tile * p.inv_tiles_per_img) >> 32);
+  const int img = div_recip(tile, p.inv_tiles_per_img);
   const int trem = tile - img * (p.tiles_w * p.tiles_h);
-  const int ti = (int)(((unsigned long long)(unsigned)trem * p.inv_tiles_w) >> 32);
+  const int ti = div_recip(trem, p.inv_tiles_w);
   const int tj = trem - ti * p.tiles_w;
   const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
   const int rowstride = p.fold ? d : 0;

@@ -218,7 +218,8 @@ struct ResBlockParams {
   // set by plan_resblock: multiply-shift reciprocals, n / d = (n * inv) >> 20 (exact for n < 512, d <= 320), and the tile ->
   // (image, tile row, tile column) split as (tile * inv_tpi) >> 32 etc. (exact for tile < 2^32 / d)
   unsigned inv_pw, inv_w1;
-  unsigned inv_tiles_w, inv_tiles_per_img;
+  // ceil(2^32 / n) for n = tiles_w, tiles_w * tiles_h: 33 bits when n = 1 (one tile per image: short sequences) -- div_recip()
+  unsigned long long inv_tiles_w, inv_tiles_per_img;
   int patch_rows;    // set by plan_resblock: rows of a patch buffer when they are not tile_m + 64 (resblock_w64.hip: 160)
   int tuning;        // vfx_config.tuning of the handle: which kernel family runs the layer (plan_resblock)
   // Timing builds only (-DVFX_TIMING, scripts/phase_timing.py): [tile][wave][16] s_memtime stamps of the 4-wave kernels' phases
