@@ -256,13 +256,19 @@ def test_committed_bench_line_follows_the_contract():
     assert d["parity"]["logmel_l1"] < d["parity"]["bar"]["logmel_l1"] and d["parity"]["clips"] >= 1
     assert d["f16_saturated"] is False and d["negative_input_flag"] == 0
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "accounting", "design_bytes_per_launch"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "accounting", "hbm_roofline", "mfma_roofline"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # section 8(d): the dominant kernel is a ResStack layer of 16 clips x 147 882 positions x 128 channels: 8 bytes per element
-    assert "k_resblock<128, 4> f16" in r["kernel"] and r["algorithmic_bytes_per_launch"] == 16 * 147882 * 128 * 8
-    assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2          # x is read once
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.01 * r["achieved"]
+    # section 8(d): the dominant kernel is a ResStack layer of 16 clips x 49 294 positions x 256 channels: 8 bytes per element
+    # -> 384 flop/B, above the ridge: MFMA-bound; the kernel's two-form trunk moves 12 (design_bytes), the counters say 13
+    hb = r["hbm_roofline"]
+    assert "k_resblock<256, 4> f16" in r["kernel"] and r["bound"] == "mfma" and hb["algorithmic_bytes_per_launch"] == 16 * 49294 * 256 * 8
+    assert hb["design_bytes_per_launch"] == 16 * 49294 * 256 * 12 and 1.0 < r["traffic"] / hb["design_bytes_per_launch"] < 1.15
+    assert abs(hb["achieved"] - hb["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.01 * hb["achieved"]
+    assert abs(r["achieved"] - r["algorithmic_gflop_per_step"] / r["kernel_ms_per_step"]) < 0.01 * r["achieved"]
+    k128 = r["all_conv_kernels"]["k_resblock<128, 4> f16"]
+    assert 0.9 < k128["hbm_bytes_per_launch"] / (16 * 147882 * 128 * 8) < 1.2    # C = 128: x is read once
+    assert r["all_conv_kernels"]["k_resblock_pair<128, 4> f16"]["hbm_bytes_per_launch"] < 1.1 * 16 * 147882 * 128 * 8   # two layers
     for name, k in r["all_conv_kernels"].items():
         assert 0 < k["frac_mfma"] < 1 and 0 < k["frac_hbm"] < 1, name
     st = d["step"]
