@@ -443,3 +443,36 @@ def test_fragment_reads_of_2d_tiles_are_conflict_free_with_the_2d_key():
         assert avg1 >= avg2
     assert m.tile_cost(16, 8, m.key_1d)[0] == 3.0   # what levels 2-4 paid before the BN = 128 tile took the 2-D key
     assert m.tile_cost(1, 128, m.key_2d) == (1.0, 1)  # a 1-D patch: the 2-D key is the row-linear one
+
+
+def test_tile_split_reciprocal_is_exact_including_one_tile_per_clip():
+    """conv_common.h's div_recip(n, r) with the host's r = ceil(2^32 / d) (plan_resblock) -- restated here -- equals n // d for
+    every tile count the plan admits (n * d < 2^32), including d = 1 (one tile per clip), where r = 2^32 does not fit 32 bits:
+    the first form of this arithmetic kept r in 32 bits and sent every tile of a batch of short sequences to clip 0."""
+    def div_recip(n, r):
+        return ((n * (r & 0xFFFFFFFF)) >> 32) + (n if (r >> 32) else 0)
+    rng = np.random.default_rng(5)
+    ds = [1, 2, 3, 7, 126, 127, 792, 4743, 65535, 65536] + [int(x) for x in rng.integers(1, 60000, 200)]
+    for d in ds:
+        r = ((1 << 32) + d - 1) // d
+        assert r >> 33 == 0
+        nmax = min((1 << 32) // d - 1, (1 << 31) - 1)
+        ns = [0, 1, d - 1, d, d + 1, nmax] + [int(x) for x in rng.integers(0, nmax + 1, 50)]
+        for n in ns:
+            if 0 <= n <= nmax:
+                assert div_recip(n, r) == n // d, (n, d)
+    # the 32-bit truncation of r the kernels once used: wrong exactly when d == 1
+    assert ((5 * (((1 << 32) // 1) & 0xFFFFFFFF)) >> 32) == 0 != 5 // 1
+
+
+def test_power_sampler_without_a_gpu_reports_nothing():
+    """bench.py's PowerSampler reads amdgpu hwmon files; where there are none (this container) the bench line carries null."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    ps = m.PowerSampler(0)
+    with ps:
+        pass
+    res = ps.result()
+    assert res is None or ("avg_power_w" in res and "avg_sclk_mhz" in res)
