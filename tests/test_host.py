@@ -476,3 +476,23 @@ def test_power_sampler_without_a_gpu_reports_nothing():
         pass
     res = ps.result()
     assert res is None or ("avg_power_w" in res and "avg_sclk_mhz" in res)
+
+
+def test_tuning_bits_agree_between_header_python_and_vfx_create():
+    """include/vfx.h's VFX_TUNE_* enum, _lib.py's TUNE_* constants, the names vfx_create announces (api.cpp) and its mask check
+    describe the same bits; the GPU suite's TUNING list (tests/test_gpu_models.py) exercises every one of them."""
+    import re
+    from voicefixer_main_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vfx.h")).read()
+    bits = {m.group(1): int(m.group(2)) for m in re.finditer(r"VFX_TUNE_(\w+)\s*=\s*(\d+)", hdr)}
+    assert bits and sorted(bits.values()) == [1 << i for i in range(len(bits))]
+    for name, v in bits.items():
+        assert getattr(_lib, "TUNE_" + name) == v, name
+    api = open(os.path.join(ROOT, "voicefixer_main_amd", "csrc", "api.cpp")).read()
+    names = re.search(r"static const char\* names\[\] = \{([^}]*)\}", api).group(1)
+    names = re.findall(r'"(\w+)"', names)
+    assert names == [n for n, _ in sorted(bits.items(), key=lambda kv: kv[1])]
+    assert "tuning & ~%d" % (sum(bits.values())) in api
+    gpu = open(os.path.join(ROOT, "tests", "test_gpu_models.py")).read()
+    for name, v in bits.items():
+        assert '("%s", %d,' % (name, v) in gpu, name
