@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--no-aux", action="store_true", help="skip the nested ssr_sr64 / stream1s measurements of the default run")
     ap.add_argument("--aux-steps", type=int, default=3)
     ap.add_argument("--cpu-repeats", type=int, default=3, help="timed calls of the CPU oracle (the median is reported)")
+    ap.add_argument("--tuning", type=int, default=0, help="vfx_config.tuning mask (include/vfx.h VFX_TUNE_*); 0 = the shipped kernel selection")
     ap.add_argument("--precision", type=int, default=2, help="0 = exact fp32 MFMA, 1 = split-bf16 (hi+lo, 3 bf16 MFMAs), 2 = ResUNet split-bf16 + vocoder fp16 (1 MFMA per product)")
     args = ap.parse_args()
     d_clips, d_sec, d_cpu = {"gsr16x10": (16, 10.0, 2), "sharded1024": (128, 10.0, 0), "ssr_sr64": (64, 3.0, 1),
@@ -495,7 +496,7 @@ class Workload:
     """One BASELINE.json config on one rank: `step()` enqueues one pass of the hot path over its batch of clips, which are
     resident in HBM before the clock starts."""
 
-    def __init__(self, wl, args, device, rank, world, precision, clips_n=None, seconds=None, weights=None):
+    def __init__(self, wl, args, device, rank, world, precision, clips_n=None, seconds=None, weights=None, tuning=0):
         from voicefixer_main_amd import dist as vdist
         from voicefixer_main_amd import synth
         from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER
@@ -507,7 +508,9 @@ class Workload:
         self.extra = {}
         self.phases = None
         self.eager = None
-        self.weights = weights or {}
+        self.weights = weights if weights is not None else {}
+        self.tuning = tuning
+        self.step_ms = []
 
         def state_dict(seed, kind):
             # N ranks: rank 0 builds (or, in production, reads the checkpoint) once, everybody else receives ONE flat
@@ -520,8 +523,8 @@ class Workload:
                 self.weights[key] = vdist.broadcast_state_dict(sd, device)
             return self.weights[key]
 
-        def make_engine(precision):
-            e = Engine(device, config={"precision": precision})
+        def make_engine(precision, tuning=tuning):
+            e = Engine(device, config={"precision": precision, "tuning": tuning})
             if self.gsr:
                 e.load_state_dict(MODEL_UNET_MEL, state_dict(0, "unet"))
                 e.load_state_dict(MODEL_VOCODER, state_dict(1, "voc"))
@@ -602,13 +605,20 @@ class Workload:
         if self.phases:
             for k in self.phases:
                 self.phases[k] = 0.0
+        # one event per step boundary on the launch stream (torch's current stream is the one handed to libvfx): the spread of
+        # the K steps inside the SAME timed region -- the clock around the region stays the host's, as the contract says
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        ev[0].record()
+        for i in range(steps):
             self.step()
+            ev[i + 1].record()
         torch.cuda.synchronize(self.device)
         barrier()
-        return time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        self.step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        return dt
 
     def flags(self):
         """The handle's sticky flags after the timed region: a 16-bit vocoder whose activations left the fp16 range, or a
@@ -618,10 +628,34 @@ class Workload:
         return {"negative_input": bool(f & _lib.FLAG_NEGATIVE_INPUT), "f16_saturated": bool(f & _lib.FLAG_F16_SATURATED)}
 
 
-def dtype_string(gsr, precision):
+F32_TRUNK = 64   # include/vfx.h VFX_TUNE_F32_TRUNK
+
+
+def dtype_string(gsr, precision, tuning=0):
+    trunk = "fp32 residual trunk between the ResStack launches" if tuning & F32_TRUNK else \
+        "fp16 residual trunk between the ResStack launches (sums in fp32 registers)"
     return {0: "f32", 1: "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)",
-            2: "f16 (vocoder: fp16 operands, 1 MFMA per product; ResUNet: split-bf16 hi+lo; fp32 accumulate)"
+            2: "f16 (vocoder: fp16 operands, 1 MFMA per product, %s; ResUNet: split-bf16 hi+lo; fp32 accumulate)" % trunk
             if gsr else "bf16x3 (split-bf16 operands hi+lo, fp32 accumulate)"}[precision]
+
+
+def step_stats(step_ms, sclk_mhz):
+    """Spread of the K steps of the timed region (HIP events at the step boundaries) and the median step scaled to a common
+    reference clock: boxes of this pool hold 1.9 .. 2.0 GHz under this load, a 3 % spread that a single mean cannot tell from a
+    3 % regression.  `step_at_ref_clock` is NOT `value` -- it is what the median step would take at 1950 MHz if time scaled with
+    the shader clock alone (true for the MFMA-dense kernels, optimistic for the HBM-bound ones)."""
+    if not step_ms:
+        return {}
+    s = sorted(step_ms)
+    n = len(s)
+    med = s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
+    out = {"ms_per_step_min": round(s[0], 3), "ms_per_step_median": round(med, 3),
+           "ms_per_step_p90": round(s[min(n - 1, int(np.ceil(0.9 * n)) - 1)], 3), "ms_per_step_max": round(s[-1], 3),
+           "step_timing": "HIP events at the step boundaries of the timed region, on the launch stream"}
+    if sclk_mhz and sclk_mhz > 500:
+        out["step_at_ref_clock"] = {"ms": round(med * sclk_mhz / 1950.0, 3), "ref_sclk_mhz": 1950, "measured_avg_sclk_mhz": sclk_mhz,
+                                    "definition": "median step x measured shader clock / 1950 MHz (comparison aid, never `value`)"}
+    return out
 
 
 def aux_workload(name, args, device, weights):
@@ -675,7 +709,8 @@ def main():
 
     wl = args.workload
     weights = {}
-    w = Workload(wl, args, device, rank, world, args.precision, clips_n=args.clips, seconds=args.seconds, weights=weights)
+    w = Workload(wl, args, device, rank, world, args.precision, clips_n=args.clips, seconds=args.seconds, weights=weights,
+                 tuning=args.tuning)
     eng, gsr, B, L = w.eng, w.gsr, w.B, w.L
 
     def barrier():
@@ -704,15 +739,16 @@ def main():
             "value": round(w.audio_per_step * args.steps / dt, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype_string(gsr, args.precision),
+            "dtype": dtype_string(gsr, args.precision, args.tuning),
             "data": "synthetic",
-            "config": {"workload": wl, "precision_mode": args.precision, "clips_per_gpu": B, "clip_seconds": w.seconds,
+            "config": {"workload": wl, "precision_mode": args.precision, "tuning": args.tuning, "clips_per_gpu": B, "clip_seconds": w.seconds,
                        "parallelism": "dp%d" % world, "weights": "seeded random (no checkpoint available offline)"
                        + ("; built on rank 0, one flat broadcast to the other ranks" if world > 1 else "")},
             "rccl_ranks": rccl_ranks, "negative_input_flag": int(flags["negative_input"]), "f16_saturated": flags["f16_saturated"],
         }
         res.update(w.extra)
         res["power"] = sampler.result()
+        res.update(step_stats(w.step_ms, (res["power"] or {}).get("avg_sclk_mhz")))
         if flags["f16_saturated"]:
             failed = ("the 16-bit vocoder clamped an activation (VFX_FLAG_F16_SATURATED): this measurement is invalid; "
                       "run with --precision 1")
@@ -773,30 +809,44 @@ def main():
                     res["parity"] = parity_wav(w.holder[0][:n], ref["wav"][:, 0])
                     res["parity"]["vs"] = "oracle.pipeline.restore_ssr in FLOAT64 (CPU port of unet_v2.py:86-148)"
         if gsr and wl == "gsr16x10" and args.precision == 2 and not args.no_alt:
-            # Same workload with every GEMM-shaped layer on split-bf16 operands (precision 1: 3 MFMAs per product in the
-            # vocoder as well): the stricter arithmetic, reported beside `value`, with its own parity.
-            try:
-                alt = w.make_engine(1)
-                wav, out = w.wav, w.out
-                for _ in range(max(args.warmup, 1)):
-                    alt.restore_gsr(wav, out=out)
-                torch.cuda.synchronize(device)
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    alt.restore_gsr(wav, out=out)
-                torch.cuda.synchronize(device)
-                dta = time.perf_counter() - t1
-                res["split_bf16_mode"] = {
-                    "value": round(B * w.seconds * args.steps / dta, 2), "unit": "audio-s/s",
-                    "ms_per_step": round(dta / args.steps * 1e3, 3), "outputs_finite": bool(torch.isfinite(out).all().item()),
-                    "dtype": "bf16x3 everywhere (split-bf16 operands hi+lo, 3 MFMAs per product, fp32 accumulate)"}
-                if "parity" in res:
-                    n = args.cpu_baseline_clips
-                    o1, l1 = alt.restore_gsr(wav[:n], want_logmel=True)
-                    res["split_bf16_mode"]["parity"] = parity_gsr(o1, l1, ref)
-                del alt
-            except Exception as e:
-                res["split_bf16_mode"] = {"error": repr(e)}
+            # Same workload, same process, same box, minutes apart:
+            #   split_bf16_mode -- every GEMM-shaped layer on split-bf16 operands (precision 1: 3 MFMAs per product in the
+            #       vocoder as well): the stricter arithmetic, reported beside `value`, with its own parity;
+            #   f32_trunk_mode  -- precision 2 with VFX_TUNE_F32_TRUNK: the round-3 data path of the vocoder (fp32 residual trunk
+            #       between the ResStack launches), i.e. the A/B of round 4's fp16 trunk inside the driver's own line.
+            def alt_mode(precision, tuning, dtype):
+                try:
+                    alt = w.make_engine(precision, tuning)
+                    wav, out = w.wav, w.out
+                    for _ in range(max(args.warmup, 1)):
+                        alt.restore_gsr(wav, out=out)
+                    torch.cuda.synchronize(device)
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+                    t1 = time.perf_counter()
+                    ev[0].record()
+                    for i in range(args.steps):
+                        alt.restore_gsr(wav, out=out)
+                        ev[i + 1].record()
+                    torch.cuda.synchronize(device)
+                    dta = time.perf_counter() - t1
+                    r = {"value": round(B * w.seconds * args.steps / dta, 2), "unit": "audio-s/s",
+                         "ms_per_step": round(dta / args.steps * 1e3, 3), "outputs_finite": bool(torch.isfinite(out).all().item()),
+                         "dtype": dtype}
+                    r.update({k: v for k, v in step_stats([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)], None).items()
+                              if k.startswith("ms_per_step")})
+                    if "parity" in res:
+                        n = args.cpu_baseline_clips
+                        o1, l1 = alt.restore_gsr(wav[:n], want_logmel=True)
+                        r["parity"] = parity_gsr(o1, l1, ref)
+                    fl = alt.take_flags()
+                    r["f16_saturated"] = bool(fl & 2)
+                    del alt
+                    return r
+                except Exception as e:
+                    return {"error": repr(e)}
+            res["split_bf16_mode"] = alt_mode(1, 0, "bf16x3 everywhere (split-bf16 operands hi+lo, 3 MFMAs per product, fp32 accumulate)")
+            if not args.tuning & F32_TRUNK:
+                res["f32_trunk_mode"] = alt_mode(2, args.tuning | F32_TRUNK, dtype_string(True, 2, F32_TRUNK))
         if wl == "gsr16x10" and not args.no_aux:
             # BASELINE.json configs[2] and configs[4], driver-visible: a few steps each in this process
             del w, eng

@@ -55,10 +55,9 @@ enum {
   VFX_TUNE_NO_PERSISTENT_C64 = 8,  /* 16-bit mode, C = 64 layers on k_resblock instead of the persistent kernel */
   VFX_TUNE_NO_PAIRS = 16,          /* 16-bit mode, C = 64 / 128: one launch per layer (no layer pairs) */
   VFX_TUNE_NO_SPLITK = 32,         /* no split-K in the deep ResUNet levels */
-  VFX_TUNE_WIDE_8WAVE = 64,        /* C = 256 layers on the 8-wave / one-block-per-CU kernel (resblock_act.hip, two-form trunk) */
-  VFX_TUNE_C128_8WAVE = 128,       /* 16-bit mode, C = 128 layers on k_resblock<128, 8> (re-reads the residual) */
-  VFX_TUNE_WIDE_SINGLE_FORM = 256  /* 16-bit mode, C = 256 layers on a single-form trunk (raw fp32 only, 64-position tiles,
-                                      resblock_s256.hip): 31 % less HBM traffic than the two-form layer, 8 % more time */
+  VFX_TUNE_F32_TRUNK = 64          /* 16-bit mode: the residual trunk of the fused ResStacks (C = 64 / 128 / 256) travels as fp32
+                                      between the layers (the round-3 form: 8 - 12 bytes per element and layer) instead of
+                                      fp16 (4 bytes per element and layer; the sums themselves are fp32 in registers either way) */
 };
 
 typedef struct vfx_config {

@@ -2,11 +2,10 @@
 
 k_conv<BN, ELU, SPLIT, ABL, RING, HI>  ->  "k_conv<BN, ELU, SPLIT>" (+ " f16" for the 16-bit launches of precision 2)
 k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
-k_resblock_act<C, NW, MT>              ->  "k_resblock<C, NW> f16"
-k_resblock_w64<C>                      ->  "k_resblock<C, 4> f16"
-k_resblock_r128<PAIR>                  ->  "k_resblock<128, 4> f16" / "k_resblock_pair<128, 4> f16"
-k_resblock_s256                        ->  "k_resblock<256, 4> f16"
-k_resblock_rw<NW, PAIR>                ->  "k_resblock<64, NW> f16" / "k_resblock_pair<64, NW> f16"
+k_resblock_w64<C, X16>                 ->  "k_resblock<C, 4> f16"
+k_resblock_r128<PAIR, X16>             ->  "k_resblock<128, 4> f16" / "k_resblock_pair<128, 4> f16"
+k_resblock_rw<NW, PAIR, X16>           ->  "k_resblock<64, NW> f16" / "k_resblock_pair<64, NW> f16"
+(X16 = the fp16 trunk of round 4: same rows of the tables, the bench line's `dtype` names the trunk format)
 """
 import re
 
@@ -19,14 +18,10 @@ def short(n, width=40):
     if name == "k_conv" and len(args) >= 3:
         hi = len(args) >= 6 and args[5] == "true"
         return "k_conv<%s, %s, %s>%s" % (args[0], args[1], args[2], " f16" if hi else "")
-    if name == "k_resblock_act" and len(args) >= 2:      # the fused wide layer of the 16-bit mode
-        return "k_resblock<%s, %s> f16" % (args[0], args[1])
     if name == "k_resblock_w64" and args:                # the same layer as 4-wave blocks, two per CU
         return "k_resblock<%s, 4> f16" % args[0]
     if name == "k_resblock_r128":                        # C = 128, 16-bit mode: 4-wave blocks, x read once; <true>: a layer pair
         return "k_resblock_pair<128, 4> f16" if args and args[0] == "true" else "k_resblock<128, 4> f16"
-    if name == "k_resblock_s256":                        # C = 256, 16-bit mode, single-form trunk: 4-wave blocks of 64 positions
-        return "k_resblock<256, 4> f16"
     if name == "k_resblock_rw" and args:                 # C = 64, 16-bit mode: persistent, weights in registers
         if len(args) >= 2 and args[1] == "true":         # two layers per launch
             return "k_resblock_pair<64, %s> f16" % args[0]

@@ -86,14 +86,13 @@ def test_resblock_layer(engine, C, T, fused):
         assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), (d, err)
 
 
-@pytest.mark.parametrize("tuning,T", [(256, 1100), (256, 7350), (0, 1100), (0, 7350), (64, 1100), (256, 50), (0, 50)],
-                         ids=["single-form", "single-form-long", "two-form-w64", "two-form-w64-long", "two-form-8wave",
-                              "single-form-one-tile", "two-form-w64-one-tile"])
+@pytest.mark.parametrize("tuning,T", [(0, 1100), (0, 7350), (0, 50), (64, 1100), (64, 7350), (64, 50)],
+                         ids=["f16-trunk", "f16-trunk-long", "f16-trunk-one-tile", "two-form", "two-form-long", "two-form-one-tile"])
 def test_wide_layer_forms(tuning, T):
-    """The three kernels of the C = 256 layer of the 16-bit mode (vfx_config.tuning: 0 = resblock_w64.hip, two-form trunk;
-    VFX_TUNE_WIDE_SINGLE_FORM = resblock_s256.hip, 64-position tiles; VFX_TUNE_WIDE_8WAVE = resblock_act.hip) against the float64
-    layer, all eight dilations (1-D tiles up to 9, folded rows above, d > T), three clips of unequal tile phase; the op checks
-    the activated fp16 output a last layer writes against fp16(LeakyReLU(y)) itself."""
+    """The two trunk forms of the C = 256 layer of the 16-bit mode (resblock_w64.hip; vfx_config.tuning: 0 = the activated fp16
+    tensor is the whole trunk and the residual is LeakyReLU^-1 of it, VFX_TUNE_F32_TRUNK = raw fp32 x / y beside xa / ya) against
+    the float64 layer, all eight dilations (1-D tiles up to 9, folded rows above, d > T), three clips of unequal tile phase; the
+    op checks the activated fp16 output against fp16(LeakyReLU(y)) itself (two-form) or returns LeakyReLU^-1(ya) (fp16 trunk)."""
     from voicefixer_main_amd.engine import Engine
     from conftest import TOL
     eng = Engine("cuda:0", config={"precision": 2, "tuning": tuning})
@@ -143,6 +142,32 @@ def test_resblock_layer_pair(engine, C, T):
         y = engine.op_resblock_pair(x.permute(0, 2, 1).contiguous(), [a.numpy() for a in la], da, [a.numpy() for a in lb], db, 0.01)
         err = (y.cpu().permute(0, 2, 1).double() - ref).abs().max().item()
         assert err < 2 * engine.tol['conv'] * max(1.0, ref.abs().max().item()), (da, db, err)
+
+
+@pytest.mark.parametrize("C", [64, 128])
+def test_f32_trunk_layers(C):
+    """VFX_TUNE_F32_TRUNK: the round-3 form of the 16-bit ResStack kernels (raw fp32 x in, raw fp32 y out) stays selectable;
+    single layers (1-D and folded tiles) and the (1, 3) pair against the float64 layers.  The `engine` fixture's 16-bit mode
+    runs the same tests on the fp16 trunk (the default)."""
+    from voicefixer_main_amd.engine import Engine
+    from conftest import TOL
+    eng = Engine("cuda:0", config={"precision": 2, "tuning": 64})
+    B, T = 3, 7001
+    x = _rand((B, C, T), 71)
+    la = (_rand((C, C, 3), 72, 0.08), _rand((C,), 73, 0.1), _rand((C, C, 3), 74, 0.08), _rand((C,), 75, 0.1))
+    lb = (_rand((C, C, 3), 76, 0.08), _rand((C,), 77, 0.1), _rand((C, C, 3), 78, 0.08), _rand((C,), 79, 0.1))
+    xc = x.permute(0, 2, 1).contiguous()
+    for d in (1, 9, 81, 2187):
+        ref = _resblock_ref(x, la[0], la[1], la[2], la[3], d, 0.01)
+        y = eng.op_resblock(xc, la[0].numpy(), la[1].numpy(), la[2].numpy(), la[3].numpy(), d, 0.01, True)
+        err = (y.cpu().permute(0, 2, 1).double() - ref).abs().max().item()
+        assert err < TOL[2]['conv'] * max(1.0, ref.abs().max().item()), (C, d, err)
+    y1 = _resblock_ref(x, la[0], la[1], la[2], la[3], 1, 0.01)
+    ref = _resblock_ref(y1, lb[0], lb[1], lb[2], lb[3], 3, 0.01)
+    y = eng.op_resblock_pair(xc, [a.numpy() for a in la], 1, [a.numpy() for a in lb], 3, 0.01)
+    err = (y.cpu().permute(0, 2, 1).double() - ref).abs().max().item()
+    assert err < 2 * TOL[2]['conv'] * max(1.0, ref.abs().max().item()), (C, err)
+    assert eng.take_flags() == 0
 
 
 @pytest.mark.parametrize("prune_w,H,W", [(False, 5, 1), (False, 10, 3), (True, 4, 16)])

@@ -220,9 +220,8 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
     import re
     # kernels that are allowed a few bytes of scratch: opt-in experiments and the opt-in 64-position form of the C = 256 layer
     # (and k_conv<64, ELU, split, ring 3>: 8 bytes since round 1, split-bf16 mode of the vocoder's ELU convolutions only)
-    may_spill = ("k_resblock_actILi256ELi8ELi64E", "k_convILi64ELb1ELb1ELi0ELi3ELb0ELb0E")
-    for name in ("conv.hip", "resblock.hip", "resblock_act.hip", "resblock_w64.hip", "resblock_r128.hip", "resblock_s256.hip", "resblock_rw.hip",
-                 "stft.hip"):
+    may_spill = ("k_convILi64ELb1ELb1ELi0ELi3ELb0ELb0E",)
+    for name in ("conv.hip", "resblock.hip", "resblock_w64.hip", "resblock_r128.hip", "resblock_rw.hip", "stft.hip", "small_ops.hip"):
         out = str(tmp_path / (name + ".s"))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                         "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, name)], check=True,
@@ -290,18 +289,18 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(d["value"] - audio / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
 
 
-@pytest.mark.parametrize("C,precision,tuning", [(64, 2, 0), (64, 1, 0), (128, 2, 0), (256, 2, 0), (256, 2, 256), (256, 2, 64)])
+@pytest.mark.parametrize("C,precision,tuning", [(64, 2, 0), (64, 1, 0), (128, 2, 0), (256, 2, 0), (256, 2, 64), (64, 2, 8)])
 def test_resblock_tiles_cover_every_position_once(C, precision, tuning):
     """Tile geometry of the fused ResStack kernels (plan_resblock, host-only entry point): over the vocoder's dilations, the
     layer pairs of the 16-bit C = 64 stack and short / long / unaligned sequences, the outputs the kernels' masks let through
-    -- restated here from resblock.hip / resblock_rw.hip / resblock_act.hip -- hit every position exactly once, and the taps
+    -- restated here from resblock.hip / resblock_rw.hip / resblock_w64.hip -- hit every position exactly once, and the taps
     of conv1 stay inside the patch."""
     import ctypes
     from voicefixer_main_amd import _lib
     lib = _lib.load()
     out = (ctypes.c_int * 12)()
     cases = [(d, 0) for d in (1, 3, 9, 27, 81, 243, 729, 2187)]
-    if C == 64 and precision == 2:
+    if C == 64 and precision == 2 and tuning == 0:
         cases += [(1, 3), (9, 27), (3, 9)]
     if C == 128 and precision == 2 and tuning == 0:
         cases += [(1, 3), (2, 4), (16, 1)]
@@ -417,16 +416,16 @@ def test_profile_kernel_names():
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     from kname import short
     ns = "void vfx::"
-    assert short(ns + "k_resblock_rw<8, false>(vfx::ResBlockParams const*, int, int)") == "k_resblock<64, 8> f16"
-    assert short(ns + "k_resblock_rw<8, true>(vfx::ResBlockParams const*, int, int)") == "k_resblock_pair<64, 8> f16"
-    assert short(ns + "k_resblock_rw<4, false>(vfx::ResBlockParams const*, int, int)") == "k_resblock<64, 4> f16"
-    assert short(ns + "k_resblock_act<256, 8, 128>(vfx::ResBlockParams const*)") == "k_resblock<256, 8> f16"
-    assert short(ns + "k_resblock_w64<256>(vfx::ResBlockParams const*)") == "k_resblock<256, 4> f16"
-    assert short(ns + "k_resblock_r128<false>(vfx::ResBlockParams const*)") == "k_resblock<128, 4> f16"
-    assert short(ns + "k_resblock_r128<true>(vfx::ResBlockParams const*)") == "k_resblock_pair<128, 4> f16"
-    assert short(ns + "k_resblock_s256(vfx::ResBlockParams const*)") == "k_resblock<256, 4> f16"
+    assert short(ns + "k_resblock_rw<8, false, true>(vfx::ResBlockParams const*, int, int)") == "k_resblock<64, 8> f16"
+    assert short(ns + "k_resblock_rw<8, true, true>(vfx::ResBlockParams const*, int, int)") == "k_resblock_pair<64, 8> f16"
+    assert short(ns + "k_resblock_rw<8, false, false>(vfx::ResBlockParams const*, int, int)") == "k_resblock<64, 8> f16"
+    assert short(ns + "k_resblock_w64<256, true>(vfx::ResBlockParams const*)") == "k_resblock<256, 4> f16"
+    assert short(ns + "k_resblock_w64<256, false>(vfx::ResBlockParams const*)") == "k_resblock<256, 4> f16"
+    assert short(ns + "k_resblock_r128<false, true>(vfx::ResBlockParams const*)") == "k_resblock<128, 4> f16"
+    assert short(ns + "k_resblock_r128<true, true>(vfx::ResBlockParams const*)") == "k_resblock_pair<128, 4> f16"
+    assert short(ns + "k_resblock_r128<true, false>(vfx::ResBlockParams const*)") == "k_resblock_pair<128, 4> f16"
     assert short(ns + "k_resblock<32, 2, false, true>(vfx::ResBlockParams const*)") == "k_resblock<32, 2>"
-    assert short(ns + "k_resblock<128, 8, true, false>(vfx::ResBlockParams const*)") == "k_resblock<128, 8> f16"
+    assert short(ns + "k_resblock<64, 4, true, false>(vfx::ResBlockParams const*)") == "k_resblock<64, 4> f16"
     assert short(ns + "k_stft_mel<false>(float const*, int)") == "k_stft_mel<false>"
 
 

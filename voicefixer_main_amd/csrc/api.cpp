@@ -472,12 +472,15 @@ static double conv_algo_bytes(const TapConvParams& q) {
 // a ResStack layer's algorithmic bytes are x in + y out = 8 bytes per element and LAYER (a pair
 // launch runs two layers).  What the kernel's own design moves on top of that (the fp16 forms xa / ya of the two-form trunk
 // of the wide stacks; half of it for a pair, whose intermediate tensor never leaves the CU) is `resblock_design_bytes`.
+// On the fp16 trunk of the 16-bit mode (round 4, ResBlockParams::x16) the tensors themselves are 2 bytes per element: x in + y
+// out = 4 bytes per element and layer.
 static double resblock_algo_bytes(const ResBlockParams& q) {
   const double n = (double)q.B * (q.geo2d ? (double)q.H * q.W : (double)q.T) * q.C;
-  return n * 8.0 * (q.dil2 > 0 ? 2.0 : 1.0);
+  return n * (q.x16 ? 4.0 : 8.0) * (q.dil2 > 0 ? 2.0 : 1.0);
 }
 static double resblock_design_bytes(const ResBlockParams& q) {
   const double n = (double)q.B * (q.geo2d ? (double)q.H * q.W : (double)q.T) * q.C;
+  if (q.x16) return n * 2.0 * ((q.x || q.xa ? 1.0 : 0.0) + (q.y ? 1.0 : 0.0) + (q.ya ? 1.0 : 0.0));  // one fp16 tensor in, y and / or ya out
   return n * 8.0 + (q.asrc ? n * 2.0 : 0.0) + (q.ya ? n * 2.0 : 0.0);  // x in, y out (+ the fp16 forms: xa in, ya out)
 }
 
@@ -585,7 +588,7 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
     } else {
       launch_resblock(hp, pl->dev_rb + idx, c.stream);
     }
-    if (debug_level("VFX_DEBUG_NAN"))
+    if (debug_level("VFX_DEBUG_NAN") && hp.y && !hp.x16)
       debug_scan(pl, "resblock y", idx, hp.y, (int64_t)hp.B * hp.T * hp.C, hp.B * hp.T, hp.C, 6 * hp.C, c.stream);
   });
 }
@@ -654,8 +657,8 @@ void bind_plan(vfx_handle* h, Plan& plan) {
   if (!plan.host_rb.empty()) {
     std::vector<ResBlockParams> rb = plan.host_rb;
     for (auto& q : rb) {
-      q.x = rebase(q.x);
-      q.y = const_cast<float*>(rebase(q.y));
+      if (q.x) q.x = rebase(q.x);
+      if (q.y) q.y = const_cast<float*>(rebase(q.y));
       if (q.xa) q.xa = rebase(q.xa);
       if (q.ya) q.ya = const_cast<float*>(rebase(q.ya));
       q.flags = h->d_flags;
@@ -797,12 +800,12 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   h->device = device;
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
   VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
-  VFX_CHECK((h->cfg.tuning & ~511) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
+  VFX_CHECK((h->cfg.tuning & ~127) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
   if (h->cfg.tuning) {  // never silent: a non-default kernel selection is announced
     static const char* names[] = {"NO_FUSED_STACKS", "NO_FUSED_WIDE", "NO_FUSED_UNET", "NO_PERSISTENT_C64", "NO_PAIRS", "NO_SPLITK",
-                                  "WIDE_8WAVE", "C128_8WAVE", "WIDE_SINGLE_FORM"};
+                                  "F32_TRUNK"};
     std::string msg;
-    for (int b = 0; b < 9; ++b)
+    for (int b = 0; b < 7; ++b)
       if (h->cfg.tuning & (1 << b)) msg += std::string(msg.empty() ? "" : " | ") + "VFX_TUNE_" + names[b];
     fprintf(stderr, "[libvfx] handle on device %d uses non-default kernel selection: tuning = 0x%x (%s)\n", device, h->cfg.tuning,
             msg.c_str());

@@ -1,5 +1,7 @@
 // ops_debug.cpp -- kernel-level C entry points used by the parity tests (vfx_op_*).
 // They pack PyTorch-layout weights on the fly, run one tap-convolution and synchronise.
+#include <cmath>
+
 #include "vfx_internal.h"
 
 using namespace vfx;
@@ -98,6 +100,63 @@ static void check_activated_output(const float* y, const float* dya, size_t n, f
   }
 }
 
+// ---- fp16 trunk of the 16-bit mode (ResBlockParams::x16): the debug entry points keep their fp32 interface and convert ----------
+static bool handle_trunk_f16(const vfx_handle* h) { return h->cfg.precision == 2 && !(h->cfg.tuning & VFX_TUNE_F32_TRUNK); }
+
+// device fp32 tensor -> a device fp16 tensor holding fp16(f(x)), f = LeakyReLU(slope) (slope = 1: the raw trunk)
+static float* to_device_f16(DeviceBlob& blob, const float* dx, size_t n, float slope) {
+  std::vector<float> hx(n);
+  VFX_HIP(hipMemcpy(hx.data(), dx, n * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<_Float16> hh(n);
+  for (size_t i = 0; i < n; ++i) {
+    const float v = hx[i] > 0.f ? hx[i] : hx[i] * slope;
+    hh[i] = (_Float16)std::min(std::max(v, -65504.f), 65504.f);
+  }
+  void* d = blob.alloc(n * sizeof(_Float16));
+  VFX_HIP(hipMemcpy(d, hh.data(), n * sizeof(_Float16), hipMemcpyHostToDevice));
+  return static_cast<float*>(d);
+}
+static std::vector<_Float16> download_f16(const float* d, size_t n) {
+  std::vector<_Float16> hh(n);
+  VFX_HIP(hipMemcpy(hh.data(), d, n * sizeof(_Float16), hipMemcpyDeviceToHost));
+  return hh;
+}
+// device fp16 tensor holding LeakyReLU(y, slope) (slope = 1: y itself) -> the caller's device fp32 tensor y
+static void from_device_f16(const float* d16, float* dy, size_t n, float slope) {
+  const std::vector<_Float16> hh = download_f16(d16, n);
+  std::vector<float> hy(n);
+  for (size_t i = 0; i < n; ++i) hy[i] = (float)hh[i] >= 0.f ? (float)hh[i] : (float)hh[i] / slope;
+  VFX_HIP(hipMemcpy(dy, hy.data(), n * sizeof(float), hipMemcpyHostToDevice));
+}
+// Runs a planned layer (or pair) of the raw fp16 trunk twice -- y16 + ya, then ya alone (the last layer in front of an upsampler
+// stores no raw output) -- checks that ya is the same bit pattern both times and that it is LeakyReLU(y16) up to the one rounding
+// that separates fp16(LeakyReLU(s)) from LeakyReLU(fp16(s)), and returns y16 widened in the caller's fp32 tensor.
+static void run_raw_f16_trunk(ResBlockParams rp, float* y_out, size_t n, float slope, DeviceBlob& blob, hipStream_t s) {
+  float* y16 = static_cast<float*>(blob.alloc(n * sizeof(_Float16)));
+  float* ya_a = static_cast<float*>(blob.alloc(n * sizeof(_Float16)));
+  float* ya_b = static_cast<float*>(blob.alloc(n * sizeof(_Float16)));
+  rp.x16 = 1;
+  rp.act_slope = slope;
+  for (int pass = 0; pass < 2; ++pass) {
+    rp.y = pass == 0 ? y16 : nullptr;
+    rp.ya = pass == 0 ? ya_a : ya_b;
+    plan_resblock(rp);
+    ResBlockParams* d = static_cast<ResBlockParams*>(blob.alloc(sizeof(ResBlockParams)));
+    VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
+    launch_resblock(rp, d, s);
+  }
+  VFX_HIP(hipStreamSynchronize(s));
+  const std::vector<_Float16> hy = download_f16(y16, n), ha = download_f16(ya_a, n), hb = download_f16(ya_b, n);
+  for (size_t i = 0; i < n; ++i) {
+    VFX_CHECK(__builtin_bit_cast(unsigned short, ha[i]) == __builtin_bit_cast(unsigned short, hb[i]),
+              "fp16 trunk: ya differs between the launch with and without the raw output at element %zu", i);
+    const float v = (float)hy[i] > 0.f ? (float)hy[i] : (float)hy[i] * slope;
+    VFX_CHECK(std::fabs((float)ha[i] - v) <= std::fabs(v) * (1.f / 512.f) + 1e-7f, "fp16 trunk: ya is not LeakyReLU(y) at element %zu (%g vs %g)", i,
+              (double)(float)ha[i], (double)v);
+  }
+  from_device_f16(y16, y_out, n, 1.f);
+}
+
 // One ResStack layer y = x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 on (B, T, C) tensors; weights in PyTorch
 // Conv1d layout (C, C, 3) on the HOST.  fused != 0: k_resblock (C = 64 / 128, split-bf16 mode only);
 // fused == 0: two k_conv launches with the ACTIVATED intermediate tensor (any C multiple of 32), which is what
@@ -120,26 +179,20 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
     float* dw2 = sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, h_f16 ? 3 : pmode));
     float* db1 = sc.blob.upload(b1, C);
     float* db2 = sc.blob.upload(b2, C);
-    const bool s256 = fused && h->cfg.precision == 2 && C == 256 && resblock_s256_enabled(h->cfg.tuning);
-    if (fused && h->cfg.precision == 2 && resblock_act_supported(C) && !s256) {
-      // wide fused layer of the 16-bit mode on the two-form trunk: conv1 reads xa = fp16(LeakyReLU(x)), built here on the host
-      std::vector<float> hx((size_t)B * T * C);
-      VFX_HIP(hipMemcpy(hx.data(), x, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
-      std::vector<_Float16> ha(hx.size());
-      for (size_t i = 0; i < hx.size(); ++i) {
-        const float v = hx[i] > 0.f ? hx[i] : hx[i] * slope;
-        ha[i] = (_Float16)std::min(std::max(v, -65504.f), 65504.f);
-      }
-      void* dxa = sc.blob.alloc(ha.size() * sizeof(_Float16));
-      VFX_HIP(hipMemcpy(dxa, ha.data(), ha.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-      float* dya = static_cast<float*>(sc.blob.alloc(ha.size() * sizeof(_Float16)));
+    const size_t nel = (size_t)B * T * C;
+    const bool t16 = handle_trunk_f16(h);
+    if (fused && h->cfg.precision == 2 && resblock_w64_supported(C)) {
+      // wide fused layer of the 16-bit mode: conv1 reads xa = fp16(LeakyReLU(x)), built here on the host.  Two-form trunk
+      // (VFX_TUNE_F32_TRUNK): x / y raw fp32 beside xa / ya; fp16 trunk: xa -> ya alone, y = LeakyReLU^-1(ya) for the caller.
+      float* dxa = to_device_f16(sc.blob, x, nel, slope);
+      float* dya = static_cast<float*>(sc.blob.alloc(nel * sizeof(_Float16)));
       ResBlockParams rp{};
       rp.asrc = 1;
+      rp.x16 = t16 ? 1 : 0;
       rp.tuning = h->cfg.tuning;
-      rp.tile_m = resblock_act_tile();
-      rp.x = x;
-      rp.xa = static_cast<const float*>(dxa);
-      rp.y = y;
+      rp.x = t16 ? nullptr : x;
+      rp.xa = dxa;
+      rp.y = t16 ? nullptr : y;
       rp.ya = dya;
       rp.act_slope = slope;
       rp.w1 = sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, 3));
@@ -157,15 +210,19 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
       VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
       launch_resblock(rp, d, s);
-      check_activated_output(y, dya, hx.size(), slope, s);
+      if (t16) {
+        VFX_HIP(hipStreamSynchronize(s));
+        from_device_f16(dya, y, nel, slope);
+      } else {
+        check_activated_output(y, dya, nel, slope, s);
+      }
     } else if (fused) {
-      VFX_CHECK(split && (resblock_supported(C) || s256), "vfx_op_resblock: the fused kernel needs precision 1 or 2 and C = 64 or 128 (precision 2: also 256)");
+      VFX_CHECK(split && resblock_supported(C), "vfx_op_resblock: the fused kernel needs precision 1 or 2 and C = 64 or 128 (precision 2: also 256)");
       ResBlockParams rp{};
       rp.x = x;
       rp.y = y;
-      // the single-form wide layer takes the fp16 64-channel-chunk fragments (mode 3)
-      rp.w1 = s256 ? sc.blob.upload(pack_conv(w1, C, C, 1, 3, 0, C, taps, 3)) : dw1;
-      rp.w2 = s256 ? sc.blob.upload(pack_conv(w2, C, C, 1, 3, 0, C, taps, 3)) : dw2;
+      rp.w1 = dw1;
+      rp.w2 = dw2;
       rp.b1 = db1;
       rp.b2 = db2;
       rp.slope = slope;
@@ -176,17 +233,23 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
       rp.tuning = h->cfg.tuning;
       rp.flags = h->d_flags;
       rp.dil = dil;
-      float* dya = nullptr;
-      if (rp.hionly) {  // 16-bit mode: also the activated fp16 form a last layer writes for the upsampler behind it
-        dya = static_cast<float*>(sc.blob.alloc((size_t)B * T * C * sizeof(_Float16)));
-        rp.ya = dya;
-        rp.act_slope = slope;
+      // fp16 trunk: wherever the plan would run this layer on it (vocoder.cpp stack_trunk_f16: resblock_r128, resblock_rw)
+      if (rp.hionly && t16 && (C == 128 || (C == 64 && resblock_rw_tile(h->cfg.tuning) != 0))) {
+        rp.x = to_device_f16(sc.blob, x, nel, 1.f);
+        run_raw_f16_trunk(rp, y, nel, slope, sc.blob, s);
+      } else {
+        float* dya = nullptr;
+        if (rp.hionly) {  // 16-bit mode: also the activated fp16 form a last layer writes for the upsampler behind it
+          dya = static_cast<float*>(sc.blob.alloc(nel * sizeof(_Float16)));
+          rp.ya = dya;
+          rp.act_slope = slope;
+        }
+        plan_resblock(rp);
+        ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
+        VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
+        launch_resblock(rp, d, s);
+        if (dya) check_activated_output(y, dya, nel, slope, s);
       }
-      plan_resblock(rp);
-      ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
-      VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
-      launch_resblock(rp, d, s);
-      if (dya) check_activated_output(y, dya, (size_t)B * T * C, slope, s);
     } else {
       float* hbuf = static_cast<float*>(sc.blob.alloc((size_t)B * T * C * sizeof(float)));
       TapConvParams p1{};
@@ -244,10 +307,7 @@ extern "C" int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2,
     rp.dil2 = dil2;
     rp.hionly = precision == 2;
     rp.tuning = tuning;
-    if (precision == 2 && resblock_act_supported(C) && !resblock_s256_enabled(tuning)) {
-      rp.asrc = 1;
-      rp.tile_m = resblock_act_tile();
-    }
+    if (precision == 2 && resblock_w64_supported(C)) rp.asrc = 1;
     plan_resblock(rp);
     const int v[12] = {rp.fold, rp.TH, rp.W1, rp.TWo, rp.tiles_h, rp.tiles_w, rp.PW, rp.P, rp.tile_m, rp.rw, 0, rp.asrc};
     for (int i = 0; i < 12; ++i) out[i] = v[i];
@@ -291,14 +351,20 @@ extern "C" int vfx_op_resblock_pair(vfx_handle* h, const float* x, int B, int T,
     rp.dil = dil;
     rp.dil2 = dil2;
     rp.tuning = h->cfg.tuning;
-    float* dya = static_cast<float*>(sc.blob.alloc((size_t)B * T * C * sizeof(_Float16)));
-    rp.ya = dya;
-    rp.act_slope = slope;
-    plan_resblock(rp);
-    ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
-    VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
-    launch_resblock(rp, d, s);
-    check_activated_output(y, dya, (size_t)B * T * C, slope, s);
+    const size_t nel = (size_t)B * T * C;
+    if (handle_trunk_f16(h)) {
+      rp.x = to_device_f16(sc.blob, x, nel, 1.f);
+      run_raw_f16_trunk(rp, y, nel, slope, sc.blob, s);
+    } else {
+      float* dya = static_cast<float*>(sc.blob.alloc(nel * sizeof(_Float16)));
+      rp.ya = dya;
+      rp.act_slope = slope;
+      plan_resblock(rp);
+      ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
+      VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
+      launch_resblock(rp, d, s);
+      check_activated_output(y, dya, nel, slope, s);
+    }
   } catch (const vfx::Error&) {
     return 1;
   }

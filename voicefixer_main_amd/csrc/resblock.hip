@@ -536,7 +536,7 @@ bool resblock_supported(int C) { return C == 64 || C == 128; }
 // Waves per block of the kernel that runs this (planned) layer: the second template argument in the kernel tables
 int resblock_block_waves(const ResBlockParams& hp) {
   if (hp.rw) return hp.tile_m / 32;
-  if ((hp.asrc && hp.patch_rows) || hp.r128 || hp.s256) return 4;
+  if (hp.asrc || hp.r128) return 4;
   if (hp.geo2d) return hp.C == 32 ? 2 : 4;
   return hp.C >= 128 ? 8 : 4;
 }
@@ -577,26 +577,26 @@ void plan_block2d(ResBlockParams& p) {
 
 // Fills the tile geometry of a fused ResStack layer (B, T, C, dil must be set).
 void plan_resblock(ResBlockParams& p) {
-  p.s256 = (!p.asrc && p.hionly && p.C == 256 && !p.geo2d && p.dil2 == 0 && resblock_s256_enabled(p.tuning)) ? 1 : 0;
-  VFX_CHECK(p.asrc ? resblock_act_supported(p.C) : (resblock_supported(p.C) || p.s256), "resblock: C=%d is not supported", p.C);
+  VFX_CHECK(p.asrc ? resblock_w64_supported(p.C) : resblock_supported(p.C), "resblock: C=%d is not supported", p.C);
   const int d = p.dil;
-  if (p.s256) p.tile_m = resblock_s256_tile();
 #ifdef VFX_TIMING
   p.timing = getenv("VFX_TIMING_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("VFX_TIMING_PTR"), nullptr, 0)) : nullptr;
 #endif
   // 16-bit mode, C = 64: the persistent register-weights kernel (resblock_rw.hip) with its own tile size
   p.rw = (!p.asrc && p.hionly && p.C == 64 && resblock_rw_tile(p.tuning) != 0) ? 1 : 0;
   if (p.rw) p.tile_m = resblock_rw_tile(p.tuning);
-  const int MT = p.tile_m ? p.tile_m : CBM;  // h positions per tile (resblock_act: 64 or 128; resblock_rw: 128 or 256)
+  const int MT = p.tile_m ? p.tile_m : CBM;  // h positions per tile (resblock_rw: 128 or 256)
   // patch rows per buffer: MT + 64 (= kPatchMaxRows for MT = 128); the 4-wave form of the wide layer keeps four chunk
   // buffers in half a CU's LDS: 160 rows (resblock_w64.hip)
-  p.patch_rows = (p.asrc && MT == 128 && p.dil2 == 0 && resblock_w64_enabled(p.tuning)) ? resblock_w64_patch_rows() : 0;
-  p.r128 = (!p.asrc && !p.rw && p.hionly && p.C == 128 && MT == 128 && resblock_r128_enabled(p.tuning) &&
+  VFX_CHECK(!p.asrc || (MT == 128 && p.dil2 == 0), "resblock: the wide layer runs 128-position tiles, one layer per launch");
+  p.patch_rows = p.asrc ? resblock_w64_patch_rows() : 0;
+  p.r128 = (!p.asrc && !p.rw && p.hionly && p.C == 128 && MT == 128 &&
             (p.dil2 == 0 || resblock_r128_pair_ok(p.C, d, p.dil2, p.tuning))) ? 1 : 0;
   if (p.r128) p.patch_rows = resblock_r128_patch_rows();
-  if (p.s256) p.patch_rows = resblock_s256_patch_rows();
+  // the fp16 trunk exists in the kernels of the 16-bit mode only (resblock_rw / resblock_r128 / resblock_w64)
+  VFX_CHECK(!p.x16 || p.rw || p.r128 || p.asrc, "resblock: no kernel runs this layer (C = %d) on an fp16 trunk", p.C);
   const int PR = p.patch_rows ? p.patch_rows : MT + 64;
-  VFX_CHECK(MT == 64 || MT == 128 || (MT == 256 && p.rw), "resblock: tile of %d positions", MT);
+  VFX_CHECK(MT == 128 || (MT == 256 && p.rw), "resblock: tile of %d positions", MT);
   p.tile_m = MT;
   if (p.dil2 > 0) {
     // layer pair: both layers over the MT-index space of the tile, MT - 4 - 2 dil2 outputs per tile (resblock_rw.hip)
@@ -654,7 +654,7 @@ void plan_resblock(ResBlockParams& p) {
 
 void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   if (hp.asrc) {
-    launch_resblock_act(hp, dparams, stream);
+    launch_resblock_w64(hp, dparams, stream);
     return;
   }
   if (hp.rw) {
@@ -663,10 +663,6 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
   }
   if (hp.r128) {
     launch_resblock_r128(hp, dparams, stream);
-    return;
-  }
-  if (hp.s256) {
-    launch_resblock_s256(hp, dparams, stream);
     return;
   }
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
@@ -684,8 +680,8 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
     if (hp.hionly) launch_rb<64, 4, true>((int)grid, stream, dparams);
     else launch_rb<64, 4, false>((int)grid, stream, dparams);
   } else {
-    if (hp.hionly) launch_rb<128, 8, true>((int)grid, stream, dparams);
-    else launch_rb<128, 8, false>((int)grid, stream, dparams);
+    VFX_CHECK(!hp.hionly, "resblock: the C = 128 layers of the 16-bit mode run on resblock_r128");
+    launch_rb<128, 8, false>((int)grid, stream, dparams);
   }
   VFX_HIP(hipGetLastError());
 }

@@ -1,4 +1,5 @@
-// resblock_r128.hip -- one fused TFGAN ResStack layer of the 16-bit mode at C = 128 (raw fp32 trunk, cf. resblock.hip)
+// resblock_r128.hip -- one fused TFGAN ResStack layer of the 16-bit mode at C = 128 (raw trunk: fp16, or fp32 with
+// VFX_TUNE_F32_TRUNK; cf. resblock.hip)
 //
 //     y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2        conv1: k3, dilation d;  conv2: k3, dilation 1
 //
@@ -18,7 +19,15 @@
 // clobbers in the compute phases.
 //
 // Tile geometry: plan_resblock with patch_rows = 160 (1-D tiles for d <= 16, folded rows of d samples with 14-wide tiles above).
-// Weights: pack_conv mode 2 (fp16 in the hi fragments of 32-channel chunks), the packing of k_resblock<128, 8, HI>.
+// Weights: pack_conv mode 2 (fp16 in the hi fragments of 32-channel chunks).
+//
+// X16 (round 4, default): the trunk between two launches is an fp16 tensor (2 bytes per element).  The layer was byte-bound on
+// an fp32 trunk whose values were rounded to fp16 before every MFMA anyway (2.43 GB per layer at 3.1 TB/s); now a thread's load
+// of 4 channels is 8 bytes, the operand is formed from the packed halves (v_pk_mul_f16 + v_pk_max_f16: no conversion, nothing to
+// saturate), the residual is widened to fp32 once and kept in the same 64 registers, the sum is formed in fp32 and rounded once
+// when it is stored (saturation flagged).  A pair's intermediate tensor stays fp32 in registers as before.
+#include <type_traits>
+
 #include "conv_common.h"
 #include "vfx_internal.h"
 
@@ -32,7 +41,7 @@ constexpr int R128_PR = 160;  // patch rows per chunk buffer
 // the CU: raw, it replaces x in the 64 registers that hold the residual; activated, it is written as the operand patch of the
 // second layer over the first one's.  Both layers work over the 128-index space of the tile: y1 is valid on indices 1 .. 126, the
 // second layer's h on 1 + d2 .. 126 - d2, the outputs on 2 + d2 .. 125 - d2 (plan_resblock: 128 - 4 - 2 d2 positions per tile).
-template <bool PAIR>
+template <bool PAIR, bool X16>
 __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* __restrict__ pp) {
   constexpr int C = 128, NW = 4, NTHR = NW * 64, MT = 128;
   constexpr int NCH = C / 32;                // 32-channel chunks = waves along the couts
@@ -168,10 +177,13 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   f32x4 keep[KEEP];
   {
     unsigned f16_sat = 0;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(unsigned)((int64_t)p.B * T * C * 4), 0x00020000);
-    const unsigned lane_off = (unsigned)(ct * 128 + cgt * 16);
+    constexpr unsigned EB = X16 ? 2u : 4u;  // bytes per element of x
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(unsigned)((int64_t)p.B * T * C * EB), 0x00020000);
+    const unsigned lane_off = (unsigned)(ct * 32 + cgt * 4) * EB;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef typename std::conditional<X16, u32x2, u32x4>::type raw_t;  // 4 channels of one row
     int prow[NROW];
-    u32x4 raw[NROW];
+    raw_t raw[NROW];
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
       const int hh = rt + 8 * (j - KEEP);
@@ -179,23 +191,33 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       const int pi = (int)(((unsigned)prow[j] * inv_pw) >> 20), pj = prow[j] - pi * PW;
       const int pos = base_x + pi * rowstride + pj;
       const bool ok = (prow[j] < P) & ((unsigned)pos < (unsigned)T);
-      const unsigned o = ok ? (unsigned)(img * T + pos) * (unsigned)(C * 4) + lane_off : 0xfffffff0u;
-      raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
+      const unsigned o = ok ? (unsigned)(img * T + pos) * (unsigned)(C * EB) + lane_off : 0xfffffff0u;
+      if constexpr (X16) raw[j] = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)o, 0, 0);
+      else raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // all twenty loads are in flight before the first row is converted
     VFX_TS(1);  // patch requested
+    const f16x2 slope_h = {(_Float16)slope, (_Float16)slope};
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
-      const f32x4 r = __builtin_bit_cast(f32x4, raw[j]);
-      if (j < KEEP) keep[j] = r;
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(r[e], r[e] * slope);
       const int key = (prow[j] >> 1) & 7;
-      *reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((cgt >> 1) ^ key) << 4) + 8 * (cgt & 1)) =
-          make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
+      uint2* const dst = reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((cgt >> 1) ^ key) << 4) + 8 * (cgt & 1));
+      if constexpr (X16) {
+        const f16x2 a = __builtin_bit_cast(f16x2, raw[j][0]), b = __builtin_bit_cast(f16x2, raw[j][1]);
+        if (j < KEEP) keep[j] = f32x4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+        // LeakyReLU on the packed halves: max(x, slope x) for 0 < slope < 1 (v_pk_mul_f16, v_pk_max_f16)
+        const f16x2 va = __builtin_elementwise_max(a, a * slope_h), vb = __builtin_elementwise_max(b, b * slope_h);
+        *dst = make_uint2(__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, vb));
+      } else {
+        const f32x4 r = __builtin_bit_cast(f32x4, raw[j]);
+        if (j < KEEP) keep[j] = r;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(r[e], r[e] * slope);
+        *dst = make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
+      }
     }
-    report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
+    if constexpr (!X16) report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
   }
   VFX_TS(2);  // loaded and transformed
   VFX_TS(3);
@@ -411,7 +433,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     // -- no exec-mask juggling around 16 (+ 16) stores per thread
     constexpr unsigned kOob = 0xfffffff0u;  // beyond every descriptor (plan_resblock: tensors < 4 GiB - 4096); nothing is added to it
     const unsigned ybytes = (unsigned)((int64_t)p.B * T * C * 4);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)ybytes, 0x00020000);
+    // X16: y is an fp16 tensor like ya; NULL (the last layer in front of an upsampler: only ya is read) = an empty descriptor
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y ? (int)(X16 ? ybytes / 2 : ybytes) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(p.ya, 0, p.ya ? (int)(ybytes / 2) : 0, 0x00020000);
     int r0o = r0;
     if constexpr (PAIR) asm volatile("" : "+v"(r0o));  // recomputed here: row values shared with the pass between the layers would be kept (spilled) through the second layer
@@ -424,7 +447,13 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
                            : ((li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d)));
       const f32x4 val = *reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * c4) + bv + keep[q];  // + the residual: this thread's own rows
       const unsigned off = (unsigned)(img * T + pos) * (unsigned)(C * 4) + 16u * c4;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ry, (int)(ok ? off : kOob), 0, 0);
+      if constexpr (X16) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 w = {pack_f16x2(val[0], val[1], ya_sat), pack_f16x2(val[2], val[3], ya_sat)};
+        __builtin_amdgcn_raw_buffer_store_b64(w, ry, (int)(ok ? off / 2 : kOob), 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ry, (int)(ok ? off : kOob), 0, 0);
+      }
       if (p.ya) {
         // last layer of the stack: also the activated fp16 form for the upsampler that follows (2 bytes per element)
         f32x4 u;
@@ -438,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)((ok && even) ? off / 2 : kOob), 0, 0);
       }
     }
-    if (p.ya) report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
+    if (X16 || p.ya) report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
   }
   VFX_TS(12);  // stores issued
   VFX_TS_FLUSH(p.timing, tile, wave_u, NW);
@@ -446,17 +475,15 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 
 int resblock_r128_patch_rows() { return R128_PR; }
 
-// The four-wave, read-x-once form runs the C = 128 layers of the 16-bit mode by default; VFX_TUNE_C128_8WAVE selects k_resblock<128, 8>.
-bool resblock_r128_enabled(int tuning) { return !(tuning & VFX_TUNE_C128_8WAVE); }
-
 // Layer pairs at C = 128: (d, d2) = (1, 3) -- 118 of a tile's 128 indices are outputs; (9, 27) would be 70.
 bool resblock_r128_pair_ok(int C, int dil, int dil2, int tuning) {
-  return !(tuning & VFX_TUNE_NO_PAIRS) && resblock_r128_enabled(tuning) && C == 128 && dil >= 1 && dil <= 16 && dil2 >= 1 && dil2 <= 4;
+  return !(tuning & VFX_TUNE_NO_PAIRS) && C == 128 && dil >= 1 && dil <= 16 && dil2 >= 1 && dil2 <= 4;
 }
 
 void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   VFX_CHECK(!hp.asrc && hp.hionly && hp.C == 128 && !hp.geo2d && hp.tile_m == 128 && hp.patch_rows == R128_PR,
             "resblock_r128: needs the 16-bit mode, C = 128, 128-position tiles planned with %d patch rows", R128_PR);
+  VFX_CHECK(hp.x && (hp.y || (hp.x16 && hp.ya)), "resblock_r128: no input / no output");
   VFX_CHECK(hp.dil2 == 0 || (!hp.fold && hp.w1b && hp.w2b && hp.b1b && hp.b2b && 128 + 2 * hp.dil2 <= R128_PR), "resblock_r128: bad layer pair");
   VFX_CHECK((hp.fold ? hp.PW : hp.dil) <= 32, "resblock_r128: the residual window starts beyond patch row 32");
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
@@ -466,11 +493,19 @@ void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparam
   static_assert((128 / 32) * R128_PR * CROW >= 128 * (128 + 4) * 4 && (128 / 32) * R128_PR * CROW >= 128 * 128 * 4, "overlays must fit");
   static uint64_t attr_devices = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_r128<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  if (hp.dil2 > 0) hipLaunchKernelGGL(k_resblock_r128<true>, dim3((int)grid), dim3(256), lds, stream, dparams);
-  else hipLaunchKernelGGL(k_resblock_r128<false>, dim3((int)grid), dim3(256), lds, stream, dparams);
+  const dim3 g((int)grid), b(256);
+  if (hp.dil2 > 0) {
+    if (hp.x16) hipLaunchKernelGGL((k_resblock_r128<true, true>), g, b, lds, stream, dparams);
+    else hipLaunchKernelGGL((k_resblock_r128<true, false>), g, b, lds, stream, dparams);
+  } else {
+    if (hp.x16) hipLaunchKernelGGL((k_resblock_r128<false, true>), g, b, lds, stream, dparams);
+    else hipLaunchKernelGGL((k_resblock_r128<false, false>), g, b, lds, stream, dparams);
+  }
   VFX_HIP(hipGetLastError());
 }
 

@@ -31,6 +31,12 @@
 //   first layer:  patch R0, h R1;  second layer: patch (= activated y1) R1, h R0;
 //   the accumulators are staged for the epilogue in two halves of 128 rows (35 KB over R0) so that R1 is free for the second
 //   patch while the first epilogue runs.
+//
+// X16 (round 4, default): x and y are fp16 tensors (the fp16 trunk of the 16-bit mode, vfx_internal.h): the stack is
+// bandwidth-bound, and the values of its fp32 trunk were rounded to fp16 before every MFMA anyway.  A thread's row piece is 8
+// bytes (the in-flight patch of the next tile: 20 .. 24 registers instead of 40 .. 48), the operand is formed from the packed
+// halves, the residual is widened to fp32 once; sums are fp32, rounded once when y is stored (saturation flagged).  A pair's
+// intermediate tensor stays fp32 in registers.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -38,7 +44,7 @@
 
 namespace vfx {
 
-template <int NW, bool PAIR>
+template <int NW, bool PAIR, bool X16>
 __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams* __restrict__ pp, int ntiles, int per_block) {
   constexpr int C = 64;
   constexpr int NTHR = NW * 64;
@@ -145,23 +151,26 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     base_h = PAIR ? j0 - 2 - d2 : (p.fold ? ti * TH * d + j0 - 1 : j0 - 1);  // position of h pixel 0 (pairs: of index 0, below)
   };
 
-  f32x4 PC[NCQ], PH[NHQ];  // the raw patch of the NEXT tile, in flight / landed
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef typename std::conditional<X16, u32x2, f32x4>::type ld_t;  // this thread's 4 channels of one row of x
+  ld_t PC[NCQ], PH[NHQ];  // the raw patch of the NEXT tile, in flight / landed
   auto request = [&](int t) __attribute__((always_inline)) {
     int img, j0, base_h;
     tile_geom(t, img, j0, base_h);
     const int base_x = base_h - d;
-    const float* xi = p.x + (int64_t)img * T * C + 4 * cg;
+    // (element offsets; X16: fp16 elements)
+    const char* xi = reinterpret_cast<const char*>(p.x) + ((int64_t)img * T * C + 4 * cg) * (X16 ? 2 : 4);
 #pragma unroll
     for (int q = 0; q < NCQ; ++q) {
       const int rel = rel_of(crow(q)), pos = base_x + rel;
-      PC[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (rel >= 0 && (unsigned)pos < (unsigned)T) PC[q] = *(const VFX_GLOBAL f32x4*)(xi + (int64_t)pos * C);
+      PC[q] = ld_t{};
+      if (rel >= 0 && (unsigned)pos < (unsigned)T) PC[q] = *(const VFX_GLOBAL ld_t*)(xi + (int64_t)pos * C * (X16 ? 2 : 4));
     }
 #pragma unroll
     for (int q = 0; q < NHQ; ++q) {
       const int rel = rel_of(hrow(q)), pos = base_x + rel;
-      PH[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (rel >= 0 && (unsigned)pos < (unsigned)T) PH[q] = *(const VFX_GLOBAL f32x4*)(xi + (int64_t)pos * C);
+      PH[q] = ld_t{};
+      if (rel >= 0 && (unsigned)pos < (unsigned)T) PH[q] = *(const VFX_GLOBAL ld_t*)(xi + (int64_t)pos * C * (X16 ? 2 : 4));
     }
   };
   // raw row -> LeakyReLU -> fp16 -> this thread's 8 bytes of the patch row: piece cg >> 1 (8 channels) at slot piece ^ key
@@ -171,6 +180,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(raw[e], raw[e] * slope);
     *reinterpret_cast<uint2*>(patch + pr * ROWB + (((cg >> 1) ^ ((pr >> 1) & 7)) << 4) + 8 * (cg & 1)) =
         make_uint2(pack_f16x2(v[0], v[1], sat), pack_f16x2(v[2], v[3], sat));
+  };
+  // X16: the row piece is fp16 already -- LeakyReLU on the packed halves (max(x, slope x), 0 < slope < 1), nothing to convert
+  const f16x2 slope_h = {(_Float16)slope, (_Float16)slope};
+  auto to_patch16 = [&](char* patch, const u32x2& raw, int pr) __attribute__((always_inline)) {
+    const f16x2 a = __builtin_bit_cast(f16x2, raw[0]), b = __builtin_bit_cast(f16x2, raw[1]);
+    const f16x2 va = __builtin_elementwise_max(a, a * slope_h), vb = __builtin_elementwise_max(b, b * slope_h);
+    *reinterpret_cast<uint2*>(patch + pr * ROWB + (((cg >> 1) ^ ((pr >> 1) & 7)) << 4) + 8 * (cg & 1)) =
+        make_uint2(__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, vb));
   };
 
   f32x16 acc[WM];
@@ -303,15 +320,27 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     f32x4 K[NCQ];
     {
       unsigned sat = 0;
+      if constexpr (X16) {
 #pragma unroll
-      for (int q = 0; q < NCQ; ++q) {
-        K[q] = PC[q];
-        if (crow(q) < P) to_patch(lds + R0, PC[q], crow(q), sat);
+        for (int q = 0; q < NCQ; ++q) {
+          const f16x2 a = __builtin_bit_cast(f16x2, PC[q][0]), b = __builtin_bit_cast(f16x2, PC[q][1]);
+          K[q] = f32x4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+          if (crow(q) < P) to_patch16(lds + R0, PC[q], crow(q));
+        }
+#pragma unroll
+        for (int q = 0; q < NHQ; ++q)
+          if (hrow(q) < P) to_patch16(lds + R0, PH[q], hrow(q));
+      } else {
+#pragma unroll
+        for (int q = 0; q < NCQ; ++q) {
+          K[q] = PC[q];
+          if (crow(q) < P) to_patch(lds + R0, PC[q], crow(q), sat);
+        }
+#pragma unroll
+        for (int q = 0; q < NHQ; ++q)
+          if (hrow(q) < P) to_patch(lds + R0, PH[q], hrow(q), sat);
+        report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
       }
-#pragma unroll
-      for (int q = 0; q < NHQ; ++q)
-        if (hrow(q) < P) to_patch(lds + R0, PH[q], hrow(q), sat);
-      report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
     }
     __syncthreads();  // the patch is complete
     if (t + 1 < t_end) request(t + 1);  // lands while this tile is computed and stored
@@ -348,7 +377,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
 
     // ---- epilogue: y = conv2 + residual + b2 in the layout of the centre loads ----------------------------------------------
     {
-      float* yi = p.y + (int64_t)img * T * C + 4 * cg;
+      char* const yi = reinterpret_cast<char*>(p.y) + ((int64_t)img * T * C + 4 * cg) * (X16 ? 2 : 4);
+      const bool have_y = p.y != nullptr;  // X16: NULL when only ya is consumed
       const bool even = (tid & 1) == 0;
       const float aslope = p.act_slope;
       unsigned sat = 0;
@@ -371,7 +401,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
             ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
           }
           const f32x4 val = (*reinterpret_cast<const f32x4*>(smem + (m - half * (MT / NHALF)) * LDO + 4 * cg) + K[q]) + b2v;
-          if (ok) *(VFX_GLOBAL f32x4*)(yi + (int64_t)pos * C) = val;
+          if constexpr (X16) {
+            const u32x2 w16 = {pack_f16x2(val[0], val[1], sat), pack_f16x2(val[2], val[3], sat)};
+            if (ok && have_y) *(VFX_GLOBAL u32x2*)(yi + (int64_t)pos * C * 2) = w16;
+          } else {
+            if (ok) *(VFX_GLOBAL f32x4*)(yi + (int64_t)pos * C * 4) = val;
+          }
           if (p.ya) {  // last layer in front of an upsampler: also ya = fp16(LeakyReLU(y, act_slope)), cf. k_resblock
             f32x4 u;
 #pragma unroll
@@ -385,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         }
         __syncthreads();  // the staged rows have been read: the next half / the next patch may overwrite them
       }
-      if (p.ya) report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
+      if (X16 || p.ya) report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
     }
   }
 }
@@ -413,7 +448,7 @@ int cu_count_of_current_device() {
   return cus[dev];
 }
 
-template <int NW, bool PAIR>
+template <int NW, bool PAIR, bool X16>
 static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {
   constexpr int MT = NW * 32;
   // the two operand regions (the staged accumulators overlay them) + biases; pairs: + three sets of weight fragments
@@ -423,21 +458,25 @@ static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t
   const int grid = (int)((ntiles + per_block - 1) / per_block);
   static uint64_t attr_devices = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_rw<NW, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_rw<NW, PAIR, X16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_resblock_rw<NW, PAIR>), dim3(grid), dim3(NW * 64), lds, stream, dparams, (int)ntiles, per_block);
+  hipLaunchKernelGGL((k_resblock_rw<NW, PAIR, X16>), dim3(grid), dim3(NW * 64), lds, stream, dparams, (int)ntiles, per_block);
 }
 
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   VFX_CHECK(hp.rw && hp.hionly && hp.C == 64 && !hp.geo2d && !hp.asrc, "resblock_rw: needs the 16-bit mode and C = 64");
   const int64_t ntiles = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(ntiles > 0 && ntiles < ((int64_t)1 << 30), "resblock_rw: bad tile count");
+  VFX_CHECK(hp.x && (hp.y || (hp.x16 && hp.ya)), "resblock_rw: no input / no output");
+  VFX_CHECK(!hp.x16 || (hp.slope > 0.f && hp.slope <= 1.f), "resblock_rw: the packed LeakyReLU of the fp16 trunk needs 0 < slope <= 1");
   if (hp.dil2 > 0) {
     VFX_CHECK(hp.tile_m == 256 && !hp.fold && hp.w1b && hp.w2b && hp.b1b && hp.b2b, "resblock_rw: bad layer pair");
-    launch_rw<8, true>(dparams, ntiles, stream);
-  } else if (hp.tile_m == 256) launch_rw<8, false>(dparams, ntiles, stream);
-  else if (hp.tile_m == 128) launch_rw<4, false>(dparams, ntiles, stream);
-  else VFX_CHECK(false, "resblock_rw: tile of %d positions", hp.tile_m);
+    if (hp.x16) launch_rw<8, true, true>(dparams, ntiles, stream);
+    else launch_rw<8, true, false>(dparams, ntiles, stream);
+  } else if (hp.tile_m == 256) {
+    if (hp.x16) launch_rw<8, false, true>(dparams, ntiles, stream);
+    else launch_rw<8, false, false>(dparams, ntiles, stream);
+  } else VFX_CHECK(false, "resblock_rw: tile of %d positions", hp.tile_m);
   VFX_HIP(hipGetLastError());
 }
 

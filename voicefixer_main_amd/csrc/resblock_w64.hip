@@ -1,10 +1,18 @@
-// resblock_w64.hip -- the fused wide ResStack layer of the 16-bit mode (C = 256, two-form trunk, cf. resblock_act.hip)
+// resblock_w64.hip -- the fused wide ResStack layer of the 16-bit mode (C = 256)
 //
 //     y  = x + conv2(LeakyReLU(conv1(xa) + b1)) + b2,      ya = fp16(LeakyReLU_next(y))
 //
-// as FOUR-wave blocks with TWO blocks per CU.
+// as FOUR-wave blocks with TWO blocks per CU.  conv1's operand xa = fp16(LeakyReLU(x)) comes from HBM in MFMA operand form
+// (LDS-DMA, no arithmetic).  Two trunk forms:
+//   X16 = false (VFX_TUNE_F32_TRUNK, the round-3 layer): x (raw fp32) is read for the residual, y (raw fp32) and ya are written
+//       -- 12 bytes per element and layer, which made this layer traffic-bound in practice (2.6 GB per launch);
+//   X16 = true (default, round 4): xa is the ONLY form of the trunk.  LeakyReLU with a positive slope is invertible, so the
+//       residual is recovered from the operand form itself, x = min(xa, xa / slope) (for xa < 0 the quotient is the smaller one),
+//       with the relative precision fp16(x) would have; the epilogue reads the tile's own centre rows of xa a second time (they
+//       were fetched for the patch microseconds earlier: L2) and writes ya only -- 4 bytes per element and layer, every byte
+//       fetched from HBM is an MFMA operand.
 //
-// Why (round-3 measurements): the 8-wave / one-block-per-CU form (k_resblock_act) runs a layer in the
+// Why four-wave blocks (round-3 measurements): the 8-wave / one-block-per-CU form (k_resblock_act, deleted in round 4) runs a layer in the
 // SUM of its memory phases (0.50 ms with all arithmetic removed) and its arithmetic (0.48 ms).  The memory phases are not
 // latency chains: a CU streams HBM at ~22 GB/s (10 B/clk) whatever the rest of the chip does, and a tile moves 384 KB -- 17 us
 // during which the MFMA pipe idles, because the block that owns the CU's LDS is the one that waits.  And its arithmetic phase is
@@ -17,6 +25,8 @@
 // are free to move above the MFMAs of this one (the weight registers are ordered by their `use` statements alone).
 //
 // Tile geometry: plan_resblock with patch_rows = 160 (1-D tiles for d <= 16, folded rows of d samples above; d = 27 folds here).
+#include <type_traits>
+
 #include "conv_common.h"
 #include "vfx_internal.h"
 
@@ -26,7 +36,7 @@ namespace {
 constexpr int W64_PR = 160;  // patch rows per chunk buffer
 }
 
-template <int C>
+template <int C, bool X16>
 __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* __restrict__ pp) {
   constexpr int NW = 4, NTHR = NW * 64, MT = 128;
   constexpr int NCH = C / 64;                // 64-channel chunks: 128-byte rows of fp16
@@ -316,11 +326,15 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   // epilogue runs beside the 128 accumulators of the waves that stage second), and a masked row is simply an offset beyond the
   // descriptor's bound -- its load returns zeros, its stores are dropped.
   const unsigned ybytes = (unsigned)((int64_t)p.B * T * C * 4);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)ybytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)ybytes, 0x00020000);
+  // X16: the residual comes from xa itself (fp16); there is no x and no y
+  const __amdgpu_buffer_rsrc_t rx = X16 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.xa), 0, (int)(ybytes / 2), 0x00020000)
+                                        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, X16 ? 0 : (int)ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(p.ya, 0, p.ya ? (int)(ybytes / 2) : 0, 0x00020000);
   constexpr unsigned kOob = 0xC0000000u;  // beyond every descriptor (the launch checks the tensors are < 2 GiB), + 1 KB does not wrap
-  unsigned ooff[NSUB][SUB];  // byte offset of the row's first channel in y (fp32); ya: half of it
+  constexpr unsigned EB = X16 ? 2u : 4u;  // bytes per element of the tensors `ooff` addresses
+  const float inv_slope = 1.f / slope;    // X16: the residual x = min(xa, xa / slope)
+  unsigned ooff[NSUB][SUB];  // byte offset of the row's first channel in y (fp32; ya: half of it) -- X16: in xa / ya (fp16)
 #pragma unroll
   for (int sp = 0; sp < NSUB; ++sp)
 #pragma unroll
@@ -329,19 +343,37 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
       const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
       const int pos = base_h + li * rowstride + lj;
       const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
-      ooff[sp][q] = ok ? (unsigned)(img * T + pos) * (unsigned)(C * 4) : kOob;
+      ooff[sp][q] = ok ? (unsigned)(img * T + pos) * (unsigned)(C * EB) : kOob;
     }
   // The residual runs THREE sub-passes (12 loads, 48 registers) ahead: the first three are requested here, before the staging
   // barriers, sub-pass i + 3 as soon as sub-pass i has consumed its registers.  (Round 3, phase stamps: with the residual
   // requested ONE sub-pass ahead -- and the compiler moving that request behind the stores -- the epilogue was eight exposed
   // memory latencies: 32 k of a block's 91 k cycles.  A whole pass ahead (64 registers) spills beside the 128 accumulators.)
   constexpr int NRB = 3;  // residual register sets: sub-pass i uses set i % NRB and then requests sub-pass i + NRB into it
-  u32x4 res[NRB][SUB];
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef typename std::conditional<X16, u32x2, u32x4>::type res_t;  // 4 channels: fp16 (8 bytes) or fp32 (16 bytes)
+  res_t res[NRB][SUB];
   auto request_res = [&](int idx) __attribute__((always_inline)) {  // idx = pass * NSUB + sub-pass
     const int pass = idx / NSUB, sp = idx % NSUB;
 #pragma unroll
-    for (int q = 0; q < SUB; ++q)
-      res[idx % NRB][q] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ooff[sp][q] + (unsigned)(pass * EPC * 4 + 16 * c4)), 0, 0);
+    for (int q = 0; q < SUB; ++q) {
+      const int o = (int)(ooff[sp][q] + (unsigned)(pass * EPC + 4 * c4) * EB);
+      if constexpr (X16) res[idx % NRB][q] = __builtin_amdgcn_raw_buffer_load_b64(rx, o, 0, 0);
+      else res[idx % NRB][q] = __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0);
+    }
+  };
+  // the residual of row q of the register set: X16: x = min(xa, xa / slope) of the fp16 operand form (a masked row loads zeros)
+  auto res_f32 = [&](const res_t& r) __attribute__((always_inline)) -> f32x4 {
+    if constexpr (X16) {
+      const f16x2 a = __builtin_bit_cast(f16x2, r[0]), b = __builtin_bit_cast(f16x2, r[1]);
+      const f32x4 v = {(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fminf(v[e], v[e] * inv_slope);
+      return o;
+    } else {
+      return __builtin_bit_cast(f32x4, r);
+    }
   };
 #pragma unroll
   for (int i = 0; i < NRB; ++i) request_res(i);
@@ -371,12 +403,14 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
 #pragma unroll
       for (int q = 0; q < SUB; ++q)
         val[q] = *reinterpret_cast<const f32x4*>(smem + (r0 + (sp * SUB + q) * RPP) * LDO + 4 * c4) + bv +
-                 __builtin_bit_cast(f32x4, res[(pass * NSUB + sp) % NRB][q]);
+                 res_f32(res[(pass * NSUB + sp) % NRB][q]);
       if (pass * NSUB + sp + NRB < NEP * NSUB) request_res(pass * NSUB + sp + NRB);  // into the registers just consumed
+      if constexpr (!X16) {
 #pragma unroll
-      for (int q = 0; q < SUB; ++q)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val[q]), ry, (int)(ooff[sp][q] + (unsigned)(ncol * 4)), 0, 0);
-      if (p.ya) {
+        for (int q = 0; q < SUB; ++q)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val[q]), ry, (int)(ooff[sp][q] + (unsigned)(ncol * 4)), 0, 0);
+      }
+      if (X16 || p.ya) {
 #pragma unroll
         for (int q = 0; q < SUB; ++q) {
           f32x4 u;
@@ -388,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
           const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)h23, 0xB1, 0xf, 0xf, false);
           const u32x4 w = {h01, h23, g0, g1};
           // (half of a masked row's offset could land INSIDE ya: the odd lanes and the masked rows get the out-of-bounds offset itself)
-          const unsigned ao = (even && ooff[sp][q] != kOob) ? ooff[sp][q] / 2 + (unsigned)(ncol * 2) : kOob;
+          const unsigned ao = (even && ooff[sp][q] != kOob) ? ooff[sp][q] / (EB / 2) + (unsigned)(ncol * 2) : kOob;
           __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)ao, 0, 0);
         }
       }
@@ -396,19 +430,21 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
     if (pass == 0) { VFX_TS(11); }  // pass 0 stored
     if (pass + 1 < NEP) __syncthreads();  // the staged pass has been consumed
   }
-  if (p.ya) report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
+  if (X16 || p.ya) report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
   VFX_TS(12);
   VFX_TS_FLUSH(p.timing, tile, wave_u, NW);
 }
 
 int resblock_w64_patch_rows() { return W64_PR; }
 
-// The four-wave form runs the wide layers by default; VFX_TUNE_WIDE_8WAVE selects the 8-wave / one-block-per-CU kernel.
-bool resblock_w64_enabled(int tuning) { return !(tuning & VFX_TUNE_WIDE_8WAVE); }
+bool resblock_w64_supported(int C) { return C == 256; }
 
 void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   VFX_CHECK(hp.asrc && hp.hionly && hp.C == 256 && hp.xa && hp.tile_m == 128 && hp.patch_rows == W64_PR,
             "resblock_w64: needs the 16-bit mode, C = 256, 128-position tiles planned with %d patch rows", W64_PR);
+  VFX_CHECK(hp.x16 ? (hp.ya && !hp.x && !hp.y && hp.slope > 0.f) : (hp.x && hp.y),
+            "resblock_w64: %s", hp.x16 ? "the fp16 trunk is the activated tensor alone (ya, no x / y) and needs an invertible LeakyReLU (slope > 0)"
+                                       : "the two-form trunk needs x and y");
   const int64_t grid = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(grid > 0 && grid < ((int64_t)1 << 31), "resblock_w64: bad grid");
   // the epilogue addresses x / y / ya with 32-bit offsets and masks rows with an offset of 3 GiB
@@ -418,9 +454,11 @@ void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams
   static_assert((256 / 64) * W64_PR * CROW >= 128 * (128 + 4) * 4 && (256 / 64) * W64_PR * CROW >= 128 * 256 * 2, "overlays must fit");
   static uint64_t attr_devices = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_w64<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_w64<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_w64<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_resblock_w64<256>), dim3((int)grid), dim3(256), lds, stream, dparams);
+  if (hp.x16) hipLaunchKernelGGL((k_resblock_w64<256, true>), dim3((int)grid), dim3(256), lds, stream, dparams);
+  else hipLaunchKernelGGL((k_resblock_w64<256, false>), dim3((int)grid), dim3(256), lds, stream, dparams);
   VFX_HIP(hipGetLastError());
 }
 

@@ -225,7 +225,7 @@ void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_we
 // lane and row piece), the 7 x C/8 taps of the lane sit in registers, and the 8 partial sums are
 // completed with three DPP-sized xor shuffles each.  One atomicMax per block for the peak.
 // ---------------------------------------------------------------------------------------------
-template <int CPL>  // channels per lane = C / 8 (4, 8 or 16)
+template <int CPL, bool X16>  // channels per lane = C / 8 (4, 8 or 16); X16: x is the fp16 trunk of the 16-bit mode
 __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, int T, const float* __restrict__ w /*[7][C]*/,
                                                     float bias, float slope, float* __restrict__ wav,
                                                     unsigned* __restrict__ peak /*[B] or null*/) {
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, 
   const int grp = threadIdx.x >> 3, g = threadIdx.x & 7;
   const int t0 = (blockIdx.x * 32 + grp) * 8;  // first output sample of the group
   const float* xb = x + (int64_t)b * T * C + g * CPL;
+  const _Float16* xh = reinterpret_cast<const _Float16*>(x) + (int64_t)b * T * C + g * CPL;
   float wk[7][CPL];
 #pragma unroll
   for (int k = 0; k < 7; ++k)
@@ -256,7 +257,14 @@ __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, 
       float v[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; c += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xb + (int64_t)tt * C + c);
+        f32x4 a;
+        if constexpr (X16) {
+          typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+          const f16x4_t hv = *reinterpret_cast<const f16x4_t*>(xh + (int64_t)tt * C + c);
+          a = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        } else {
+          a = *reinterpret_cast<const f32x4*>(xb + (int64_t)tt * C + c);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[c + e] = a[e] >= 0.f ? a[e] : a[e] * slope;
       }
@@ -298,14 +306,17 @@ __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, 
   }
 }
 
-void launch_voc_final(const float* x, int B, int T, int C, const float* w, float bias, float slope, float* wav,
+void launch_voc_final(const float* x, int x_f16, int B, int T, int C, const float* w, float bias, float slope, float* wav,
                       unsigned* peak, hipStream_t s) {
   const dim3 grid((T + 255) / 256, B);
   if (peak) VFX_HIP(hipMemsetAsync(peak, 0, sizeof(unsigned) * B, s));
-  switch (C) {
-    case 32: hipLaunchKernelGGL(k_voc_final<4>, grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
-    case 64: hipLaunchKernelGGL(k_voc_final<8>, grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
-    case 128: hipLaunchKernelGGL(k_voc_final<16>, grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+  switch (C * 2 + (x_f16 ? 1 : 0)) {
+    case 64: hipLaunchKernelGGL((k_voc_final<4, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+    case 65: hipLaunchKernelGGL((k_voc_final<4, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+    case 128: hipLaunchKernelGGL((k_voc_final<8, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+    case 129: hipLaunchKernelGGL((k_voc_final<8, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+    case 256: hipLaunchKernelGGL((k_voc_final<16, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+    case 257: hipLaunchKernelGGL((k_voc_final<16, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
     default: VFX_CHECK(false, "vocoder tail: %d channels are not supported (32, 64 or 128)", C);
   }
   VFX_HIP(hipGetLastError());

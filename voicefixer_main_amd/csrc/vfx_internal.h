@@ -189,11 +189,20 @@ struct ResBlockParams {
   int poff[3];      // patch row offset of conv1's taps
   int hionly;       // fp16 operands in the hi halves only, cf. TapConvParams::hionly
   int* flags;       // the handle's sticky device flags (VFX_FLAG_F16_SATURATED); may be NULL
-  // Wide stacks of the 16-bit mode (resblock_act.hip, C = 256): the trunk travels in two forms -- conv1 reads the
-  // activated fp16 tensor xa = fp16(LeakyReLU(x)) (2 bytes per element), x stays the raw residual; besides y the kernel
+  // Wide stacks of the 16-bit mode (resblock_w64.hip, C = 256): conv1 reads the activated fp16 tensor
+  // xa = fp16(LeakyReLU(x)) (2 bytes per element) through the LDS-DMA engine, no arithmetic on it; besides y the kernel
   // writes ya = fp16(LeakyReLU(y, act_slope)) for the next consumer (NULL: not needed).  Weights: pack_conv mode 3.
+  //   x16 == 0 (VFX_TUNE_F32_TRUNK): two-form trunk -- x is the raw fp32 residual, y the raw fp32 output (12 bytes per element);
+  //   x16 == 1: the activated fp16 tensor is the ONLY form of the trunk (4 bytes per element): x and y are NULL, the residual
+  //   is recovered from xa (LeakyReLU with a positive slope is invertible: x = xa >= 0 ? xa : xa / slope -- the same relative
+  //   precision as fp16(x)), ya must be there.
   int asrc;
-  int tile_m;       // h positions per tile: 0 = 128 (k_resblock); resblock_act: 64 or 128 (resblock_act_tile()); resblock_rw: 128 or 256
+  // fp16 residual trunk of the 16-bit mode (the default; VFX_TUNE_F32_TRUNK = 0 here): x and y point to fp16 tensors (B, T, C),
+  // 2 bytes per element, channels in natural order.  The layer's arithmetic is unchanged -- fp16 operands, fp32 accumulation,
+  // the residual added in fp32 in registers -- only what travels between two launches is rounded (saturation is flagged).
+  // y may be NULL when only ya is consumed (the last layer of a stack in front of an upsampler).
+  int x16;
+  int tile_m;       // h positions per tile: 0 = 128 (k_resblock, resblock_w64, resblock_r128); resblock_rw: 128 or 256
   // Layer pair (resblock_rw.hip, PAIR): dil2 > 0 = a second layer (dilation dil2, weights w1b .. b2b, same slope) follows in the
   // same launch; y is ITS output, the first layer's output is never stored.
   int dil2;
@@ -202,7 +211,6 @@ struct ResBlockParams {
   const float* b1b;
   const float* b2b;
   int r128;         // set by plan_resblock: resblock_r128.hip runs this layer (16-bit mode, C = 128)
-  int s256;         // set by plan_resblock: resblock_s256.hip runs this layer (16-bit mode, C = 256, single-form trunk)
   int rw;           // set by plan_resblock: the persistent register-weights kernel runs this layer (resblock_rw.hip: 16-bit mode, C = 64)
   const float* xa;
   float* ya;
@@ -227,22 +235,13 @@ struct ResBlockParams {
 };
 bool resblock_supported(int C);
 int resblock_block_waves(const ResBlockParams& hp);
-bool resblock_act_supported(int C);
-int resblock_act_tile();
-void launch_resblock_act(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 // resblock_rw.hip: C = 64, 16-bit mode -- persistent blocks, weights in registers, next patch prefetched into registers
 // resblock_w64.hip: the wide layer (C = 256, 16-bit mode) as 4-wave blocks of 64-cout waves, two blocks per CU
-bool resblock_w64_enabled(int tuning);
+bool resblock_w64_supported(int C);
 // resblock_r128.hip: C = 128, 16-bit mode -- 4-wave blocks, two per CU, x read once (the residual stays in registers)
-bool resblock_r128_enabled(int tuning);
 bool resblock_r128_pair_ok(int C, int dil, int dil2, int tuning);  // two layers (dil, dil2) as one launch: (1, 3)
 int resblock_r128_patch_rows();
 void launch_resblock_r128(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
-// resblock_s256.hip: C = 256, 16-bit mode, single-form trunk -- 4-wave blocks of 64-position tiles, two per CU, x read once
-bool resblock_s256_enabled(int tuning);
-int resblock_s256_patch_rows();
-int resblock_s256_tile();
-void launch_resblock_s256(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 int resblock_w64_patch_rows();
 void launch_resblock_w64(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 int resblock_rw_tile(int tuning);
@@ -299,8 +298,8 @@ void launch_final_1x1(const float* y, int B, int Tpad, int W, const float* w32, 
                       const float* aux0, const float* aux1, float* out0, float* out1, hipStream_t s);
 void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_weight, float amp_floor, float min_db,
                      float range, float* cond, hipStream_t s);
-void launch_voc_final(const float* x, int B, int T, int C, const float* w, float bias, float slope, float* wav,
-                      unsigned* peak, hipStream_t s);
+void launch_voc_final(const float* x, int x_f16, int B, int T, int C, const float* w, float bias, float slope, float* wav,
+                      unsigned* peak, hipStream_t s);  // x_f16: x is an fp16 tensor (the fp16 trunk of the 16-bit mode)
 void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int unify, float* sums, float* mel_out,
                      hipStream_t s);
 void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, bool have_peak, float* out,

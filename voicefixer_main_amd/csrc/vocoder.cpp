@@ -37,22 +37,30 @@ int pack_mode(const vfx_config& cfg, bool src_act) {
   return cfg.precision != 0 ? 1 : 0;
 }
 
-// The C = 256 stack of the 16-bit mode on the single-form trunk (resblock_s256.hip): raw fp32 in, raw fp32 out
-bool stack_single_form_wide(const vfx_config& cfg, int channels) {
-  return cfg.precision == 2 && channels == 256 && resblock_s256_enabled(cfg.tuning);
-}
-
-// HBM-bound stacks (C = 64, 128; in the 16-bit mode also C = 256) run each layer as ONE fused launch on the raw trunk
-// (resblock.hip, resblock_s256.hip); the other wide stacks run on a trunk kept in both forms (one or two launches per layer).
-// VFX_TUNE_NO_FUSED_STACKS forces the latter everywhere.
+// HBM-bound stacks (C = 64, 128) run each layer as ONE fused launch on the raw trunk (resblock.hip, resblock_rw.hip,
+// resblock_r128.hip); the wide stacks run on a trunk in activated form (C = 256 in the 16-bit mode: one launch per layer,
+// resblock_w64.hip; otherwise two k_conv launches per layer).  VFX_TUNE_NO_FUSED_STACKS forces the latter everywhere.
 bool stack_fused(const vfx_config& cfg, int channels) {
-  if (stack_single_form_wide(cfg, channels)) return true;
   return cfg.precision != 0 && resblock_supported(channels) && !(cfg.tuning & VFX_TUNE_NO_FUSED_STACKS);
 }
+bool stack_fused_wide(const vfx_config& cfg, int channels) {
+  return !stack_fused(cfg, channels) && cfg.precision == 2 && resblock_w64_supported(channels) && !(cfg.tuning & VFX_TUNE_NO_FUSED_WIDE);
+}
 
-// Packing of the fused layers' weights: pack_mode(raw source), except the single-form wide layer, which takes the fp16
-// 64-channel-chunk fragments of resblock_w64.hip (mode 3)
-int fused_layer_mode(const vfx_config& cfg, int channels) { return stack_single_form_wide(cfg, channels) ? 3 : pack_mode(cfg, false); }
+// Packing of the fused layers' weights: pack_mode(raw source)
+int fused_layer_mode(const vfx_config& cfg, int) { return pack_mode(cfg, false); }
+
+// fp16 trunk of the 16-bit mode (round 4; VFX_TUNE_F32_TRUNK switches it off): the tensors BETWEEN the fused launches of a
+// ResStack are fp16 (ResBlockParams::x16) wherever one of the 16-bit kernels runs the stack -- resblock_rw (C = 64),
+// resblock_r128 (C = 128): the raw trunk as fp16; resblock_w64 (C = 256): the activated fp16 tensor alone.  A wide stack that
+// feeds the vocoder tail (no upsampler behind it) keeps the two-form trunk: the tail reads raw values.
+bool stack_trunk_f16(const vfx_config& cfg, int channels, bool last_stage) {
+  if (cfg.precision != 2 || (cfg.tuning & VFX_TUNE_F32_TRUNK)) return false;
+  if (cfg.voc_res_slope <= 0.f || cfg.voc_res_slope > 1.f) return false;  // packed max(x, slope x); the wide layer inverts the LeakyReLU
+  if (stack_fused_wide(cfg, channels)) return !last_stage;
+  if (!stack_fused(cfg, channels)) return false;
+  return channels == 128 || (channels == 64 && resblock_rw_tile(cfg.tuning) != 0);
+}
 
 // Conv1d weight (Cout, Cin, K) -> packed with taps k = 0..K-1
 VocConvW load_conv1d(vfx_handle* h, const std::string& p, int cin, int cout, int K, bool src_act) {
@@ -128,7 +136,7 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
       snprintf(a, sizeof(a), "generator.%d.res_layers.%d.1", idx + 1, i);
       snprintf(b, sizeof(b), "generator.%d.res_layers.%d.3", idx + 1, i);
       // unfused layers read the activated trunk / the activated h; the fused kernel transforms raw patches itself
-      const bool act = !stack_fused(cfg, c) || stack_single_form_wide(cfg, c);  // (mode 3 = the packing for activated sources)
+      const bool act = !stack_fused(cfg, c);  // (mode 3 = the packing for activated sources)
       stack.push_back({load_conv1d(h, a, c, c, 3, act), load_conv1d(h, b, c, c, 3, act)});
     }
     W->res.push_back(stack);
@@ -239,17 +247,24 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     cur = y;
   }
   int Tlen = Tp;
+  bool trunk_is_f16 = false;  // form of the current stack's raw trunk
   for (int st = 0; st < cfg.voc_n_stages; ++st) {
     const int s = cfg.voc_scales[st], pad = s / 2 + s % 2;
     const VocConvW& up = W->up[st];
     const int Tout = Tlen * s;
     const bool fuse = stack_fused(cfg, up.cout);
-    // 16-bit mode, C = 256: fused as well, on the two-form trunk (resblock_w64.hip); VFX_TUNE_NO_FUSED_WIDE: two launches
-    const bool fuse_act = !fuse && cfg.precision == 2 && resblock_act_supported(up.cout) && !(cfg.tuning & VFX_TUNE_NO_FUSED_WIDE);
+    // 16-bit mode, C = 256: fused as well, on the activated trunk (resblock_w64.hip); VFX_TUNE_NO_FUSED_WIDE: two launches
+    const bool fuse_act = stack_fused_wide(cfg, up.cout);
     const bool last_stage = st + 1 == cfg.voc_n_stages;
+    // fp16 trunk: the upsampler writes ONE fp16 tensor -- the raw trunk for resblock_rw / resblock_r128 (stored through the
+    // epilogue's activated output with the identity as activation), the activated trunk for resblock_w64
+    const bool t16 = stack_trunk_f16(cfg, up.cout, last_stage);
+    trunk_is_f16 = t16 && fuse;
+    const int64_t nel = (int64_t)B * Tout * up.cout;
     Forms y;
-    y.raw = pb.alloc_f((int64_t)B * Tout * up.cout);
-    if (!fuse) y.act = pb.alloc_f(act_floats((int64_t)B * Tout * up.cout));
+    if (t16 && fuse) y.raw = pb.alloc_f(act_floats(nel));
+    else if (!t16) y.raw = pb.alloc_f(nel);
+    if (!fuse) y.act = pb.alloc_f(act_floats(nel));
     const bool up_src_act = cur.act != kNone;  // the producer already applied LeakyReLU(up_slope)
     VFX_CHECK(up.mode == pack_mode(cfg, up_src_act), "vocoder plan: upsampler %d is packed for another source form", st);
     {
@@ -264,11 +279,15 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
       p.Cout = s * up.cout;
       p.sh = p.sw = 1;
       p.bias = up.bias;
-      p.out = const_cast<float*>(rel_ptr(y.raw));
       p.act_slope = 1.f;
-      if (!fuse) {
-        p.out_act = const_cast<float*>(rel_ptr(y.act));
-        p.act_slope = cfg.voc_res_slope;
+      if (t16 && fuse) {
+        p.out_act = const_cast<float*>(rel_ptr(y.raw));  // fp16(y): LeakyReLU with slope 1
+      } else {
+        if (!t16) p.out = const_cast<float*>(rel_ptr(y.raw));
+        if (!fuse) {
+          p.out_act = const_cast<float*>(rel_ptr(y.act));
+          p.act_slope = cfg.voc_res_slope;
+        }
       }
       p.nseg = 1;
       std::vector<TapSeg> phases(s);
@@ -308,10 +327,9 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     for (size_t li = 0; li < nlayers; ++li) {
       auto& layer = W->res[st][li];
       if (fuse) {
-        const size_t y2 = pb.alloc_f((int64_t)B * Tlen * up.cout);
         ResBlockParams rp{};
         rp.x = rel_ptr(cur.raw);
-        rp.y = const_cast<float*>(rel_ptr(y2));
+        rp.x16 = t16 ? 1 : 0;
         rp.w1 = layer.first.w;
         rp.w2 = layer.second.w;
         rp.b1 = layer.first.bias;
@@ -340,9 +358,13 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
           rp.b2b = next.second.bias;
         }
         Forms ynew;
-        ynew.raw = y2;
-        if (cfg.precision == 2 && li + 1 == nlayers && !last_stage) {
-          // last layer in front of an upsampler: also the activated fp16 form (LeakyReLU(up_slope)) for it
+        const bool feeds_upsampler = cfg.precision == 2 && li + 1 == nlayers && !last_stage;
+        if (!(t16 && feeds_upsampler)) {  // (fp16 trunk: the upsampler reads ya only -- the raw output is not stored at all)
+          ynew.raw = pb.alloc_f(t16 ? act_floats((int64_t)B * Tlen * up.cout) : (int64_t)B * Tlen * up.cout);
+          rp.y = const_cast<float*>(rel_ptr(ynew.raw));
+        }
+        if (feeds_upsampler) {
+          // last layer in front of an upsampler: the activated fp16 form (LeakyReLU(up_slope)) for it
           ynew.act = pb.alloc_f(act_floats((int64_t)B * Tlen * up.cout));
           rp.ya = const_cast<float*>(rel_ptr(ynew.act));
           rp.act_slope = cfg.voc_up_slope;
@@ -356,16 +378,16 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         // (the next layer: LeakyReLU(res_slope); the next upsampler: LeakyReLU(up_slope))
         const bool last_layer = li + 1 == nlayers;
         Forms y2;
-        y2.raw = pb.alloc_f((int64_t)B * Tlen * up.cout);
+        if (!t16) y2.raw = pb.alloc_f((int64_t)B * Tlen * up.cout);
         if (!(last_layer && last_stage)) y2.act = pb.alloc_f(act_floats((int64_t)B * Tlen * up.cout));
         VFX_CHECK(layer.first.mode == 3 && layer.second.mode == 3, "vocoder plan: the fused wide layer needs fp16 64-channel weights");
         ResBlockParams rp{};
         rp.asrc = 1;
+        rp.x16 = t16 ? 1 : 0;  // the activated tensor is the only form of the trunk: no x, no y
         rp.tuning = cfg.tuning;
-        rp.tile_m = resblock_act_tile();
-        rp.x = rel_ptr(cur.raw);
+        rp.x = t16 ? nullptr : rel_ptr(cur.raw);
         rp.xa = rel_ptr(cur.act);
-        rp.y = const_cast<float*>(rel_ptr(y2.raw));
+        rp.y = t16 ? nullptr : const_cast<float*>(rel_ptr(y2.raw));
         rp.ya = y2.act != kNone ? const_cast<float*>(rel_ptr(y2.act)) : nullptr;
         rp.act_slope = last_layer ? cfg.voc_up_slope : cfg.voc_res_slope;
         rp.w1 = layer.first.w;
@@ -406,8 +428,9 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     const int Tl = Tlen;
     const bool want_peak = peak != nullptr;
     const BufRef pk = peak ? *peak : BufRef{};
+    const int tail_f16 = trunk_is_f16 ? 1 : 0;  // the last stack left its raw trunk as fp16
     pl->ops.push_back([=](const RunCtx& c) {
-      launch_voc_final(reinterpret_cast<const float*>(pl->bound_base + xo), B, Tl, W->final_c, W->final_w, W->final_b,
+      launch_voc_final(reinterpret_cast<const float*>(pl->bound_base + xo), tail_f16, B, Tl, W->final_c, W->final_w, W->final_b,
                        cfg.voc_up_slope, resolve(c, wav_out), want_peak ? reinterpret_cast<unsigned*>(resolve(c, pk)) : nullptr,
                        c.stream);
     });
