@@ -198,6 +198,8 @@ int vfx_spectral_metrics(vfx_handle* h, const float* est, const float* target, i
 
 /* Read-and-clear the sticky device flags (synchronises `stream`). */
 int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out);
+/* ... only the bits in `mask` (VFX_FLAG_*): the others stay raised for a later check. */
+int vfx_take_flags_masked(vfx_handle* h, void* stream, int mask, int* flags_out);
 
 /*
  * Live kernel timing for the roofline report: between vfx_profile_begin and vfx_profile_end

@@ -63,6 +63,56 @@ def test_wav_io_roundtrip_and_resample(tmp_path):
     assert abs(len(z) - 44100) <= 2
 
 
+def test_streaming_wav_reader_equals_load_wav(tmp_path):
+    """handlers._WavReader (segment-by-segment reads) returns, concatenated, exactly what load_wav returns -- mono / stereo PCM16
+    at 44.1 kHz through its streaming path, 8- / 32-bit and 48 kHz files through its whole-file fallback -- and ends at the last
+    frame the file really holds when the header promises more (a truncated file)."""
+    import wave
+    from voicefixer_main_amd import handlers
+    rng = np.random.default_rng(3)
+
+    def write(path, ch, width, sr, n):
+        x = rng.uniform(-0.9, 0.9, (n, ch))
+        with wave.open(path, "wb") as f:
+            f.setnchannels(ch); f.setsampwidth(width); f.setframerate(sr)
+            if width == 2:
+                f.writeframes((x * 32767).astype("<i2").tobytes())
+            elif width == 4:
+                f.writeframes((x * 2147483647).astype("<i4").tobytes())
+            else:
+                f.writeframes(((x * 127) + 128).astype(np.uint8).tobytes())
+
+    for i, (ch, width, sr, n) in enumerate([(1, 2, 44100, 10000), (2, 2, 44100, 10001), (1, 1, 44100, 5000), (2, 4, 44100, 5000),
+                                             (1, 2, 48000, 9600), (2, 2, 22050, 4410)]):
+        p = str(tmp_path / ("r%d.wav" % i))
+        write(p, ch, width, sr, n)
+        want = handlers.load_wav(p, 44100)
+        r = handlers._WavReader(p, 44100)
+        assert len(r) == want.shape[0]
+        parts = []
+        while sum(a.shape[0] for a in parts) < len(r):
+            parts.append(r.read(3000))
+            assert parts[-1].shape[0] > 0
+        r.close()
+        got = np.concatenate(parts)
+        assert got.dtype == np.float32 and np.array_equal(got, want), (ch, width, sr)
+    # truncated data chunk: the header says 10000 frames, the file holds 6500
+    p = str(tmp_path / "t.wav")
+    write(p, 1, 2, 44100, 10000)
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[:44 + 2 * 6500])
+    r = handlers._WavReader(p, 44100)
+    assert len(r) == 10000
+    parts = []
+    while sum(a.shape[0] for a in parts) < len(r):
+        seg = r.read(3000)
+        if seg.shape[0] == 0:
+            break
+        parts.append(seg)
+    r.close()
+    assert sum(a.shape[0] for a in parts) == 6500 and len(r) == 6500 and [a.shape[0] for a in parts] == [3000, 3000, 500]
+
+
 def test_handler_glue_matches_oracle_glue():
     from oracle import pipeline
     from voicefixer_main_amd import handlers

@@ -57,6 +57,7 @@ SIGNATURES = {
     "vfx_vocoder": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vfx_restore_gsr": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "vfx_take_flags": (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
+    "vfx_take_flags_masked": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "vfx_profile_begin": (c_int, [c_void_p]),
     "vfx_profile_end": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "vfx_op_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,

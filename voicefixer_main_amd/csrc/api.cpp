@@ -595,6 +595,14 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
 
 static char* ensure_arena(vfx_handle* h, size_t bytes) {
   if (bytes <= h->arena_bytes) return h->arena;
+  // A hipGraph captured from a plan (Plan::pinned) replays kernels whose parameter blocks hold ABSOLUTE pointers into the arena
+  // as it was at capture time.  Growing the arena frees that memory: the next replay would read and write freed memory with no
+  // error.  So a handle with a captured plan refuses to grow; the caller reserves the largest shape first (vfx_reserve), then
+  // captures.
+  for (auto& kv : h->plans)
+    VFX_CHECK(!(kv.second->pinned && h->arena), "the workspace arena would have to grow from %zu to %zu bytes, but a hipGraph was captured from plan '%s' "
+              "and replays kernels that point into the current arena: vfx_reserve() the largest (model, B, T) BEFORE capturing "
+              "(or destroy the graph and the handle)", h->arena_bytes, bytes, kv.first.c_str());
   VFX_HIP(hipDeviceSynchronize());
   if (h->arena) VFX_HIP(hipFree(h->arena));
   h->arena = nullptr;
@@ -882,6 +890,21 @@ int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out) {
   VFX_HIP(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
   VFX_HIP(hipStreamSynchronize(s));
   *flags_out = v;
+  VFX_API_END
+}
+
+// Read-and-clear only the bits in `mask`: the other sticky bits stay raised for whoever checks them later (a deferred
+// saturation check of the vocoder must survive the UNet stage's negative-input check, models.VoiceFixer.forward).
+int vfx_take_flags_masked(vfx_handle* h, void* stream, int mask, int* flags_out) {
+  VFX_API_BEGIN_H(h)
+  VFX_CHECK(h && flags_out, "NULL argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int v = 0;
+  VFX_HIP(hipMemcpyAsync(&v, h->d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
+  VFX_HIP(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+  VFX_HIP(hipStreamSynchronize(s));
+  if (v & ~mask) launch_or_flags(h->d_flags, v & ~mask, s);  // in stream order, before anything the caller enqueues next
+  *flags_out = v & mask;
   VFX_API_END
 }
 

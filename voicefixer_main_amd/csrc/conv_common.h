@@ -11,7 +11,26 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Four fp16 values (8 bytes: this thread's 4 channels of one row of the fp16 trunk of the 16-bit mode) as ONE vector.
+// hipcc 7.2 miscompiles __builtin_bit_cast(T, v[i]) of a vector ELEMENT lvalue: it reads element 0 whatever i is (found on the
+// gfx950 assembly in round 4 -- an 8-byte load narrowed to 4 bytes, both halves of a row piece equal); so the halves are never
+// picked out of the u32x2 one by one: the whole vector is cast.
+__device__ __forceinline__ f32x4 f16x4_widen(u32x2 r) {
+  const f16x4 h = __builtin_bit_cast(f16x4, r);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+// LeakyReLU on the packed halves, max(x, slope x) for 0 < slope <= 1 (v_pk_mul_f16 + v_pk_max_f16): the MFMA operand form of a
+// raw fp16 row piece -- no conversion, nothing to saturate
+__device__ __forceinline__ u32x2 f16x4_lrelu(u32x2 r, float slope) {
+  const f16x4 h = __builtin_bit_cast(f16x4, r);
+  const _Float16 s = (_Float16)slope;
+  const f16x4 sv = {s, s, s, s};
+  return __builtin_bit_cast(u32x2, __builtin_elementwise_max(h, h * sv));
+}
 
 // fp16 operand form of the 16-bit mode (TapConvParams::hionly): round to nearest, saturate instead of overflowing
 __device__ __forceinline__ unsigned pack_f16x2(float a, float b) {

@@ -180,7 +180,6 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     constexpr unsigned EB = X16 ? 2u : 4u;  // bytes per element of x
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(unsigned)((int64_t)p.B * T * C * EB), 0x00020000);
     const unsigned lane_off = (unsigned)(ct * 32 + cgt * 4) * EB;
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef typename std::conditional<X16, u32x2, u32x4>::type raw_t;  // 4 channels of one row
     int prow[NROW];
     raw_t raw[NROW];
@@ -197,17 +196,14 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     }
     __builtin_amdgcn_sched_barrier(0);  // all twenty loads are in flight before the first row is converted
     VFX_TS(1);  // patch requested
-    const f16x2 slope_h = {(_Float16)slope, (_Float16)slope};
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
       const int key = (prow[j] >> 1) & 7;
       uint2* const dst = reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((cgt >> 1) ^ key) << 4) + 8 * (cgt & 1));
       if constexpr (X16) {
-        const f16x2 a = __builtin_bit_cast(f16x2, raw[j][0]), b = __builtin_bit_cast(f16x2, raw[j][1]);
-        if (j < KEEP) keep[j] = f32x4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
-        // LeakyReLU on the packed halves: max(x, slope x) for 0 < slope < 1 (v_pk_mul_f16, v_pk_max_f16)
-        const f16x2 va = __builtin_elementwise_max(a, a * slope_h), vb = __builtin_elementwise_max(b, b * slope_h);
-        *dst = make_uint2(__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, vb));
+        if (j < KEEP) keep[j] = f16x4_widen(raw[j]);
+        const u32x2 v = f16x4_lrelu(raw[j], slope);  // packed: v_pk_mul_f16, v_pk_max_f16
+        *dst = make_uint2(v.x, v.y);
       } else {
         const f32x4 r = __builtin_bit_cast(f32x4, raw[j]);
         if (j < KEEP) keep[j] = r;
@@ -448,7 +444,6 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       const f32x4 val = *reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * c4) + bv + keep[q];  // + the residual: this thread's own rows
       const unsigned off = (unsigned)(img * T + pos) * (unsigned)(C * 4) + 16u * c4;
       if constexpr (X16) {
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 w = {pack_f16x2(val[0], val[1], ya_sat), pack_f16x2(val[2], val[3], ya_sat)};
         __builtin_amdgcn_raw_buffer_store_b64(w, ry, (int)(ok ? off / 2 : kOob), 0, 0);
       } else {

@@ -151,7 +151,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     base_h = PAIR ? j0 - 2 - d2 : (p.fold ? ti * TH * d + j0 - 1 : j0 - 1);  // position of h pixel 0 (pairs: of index 0, below)
   };
 
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef typename std::conditional<X16, u32x2, f32x4>::type ld_t;  // this thread's 4 channels of one row of x
   ld_t PC[NCQ], PH[NHQ];  // the raw patch of the NEXT tile, in flight / landed
   auto request = [&](int t) __attribute__((always_inline)) {
@@ -182,12 +181,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         make_uint2(pack_f16x2(v[0], v[1], sat), pack_f16x2(v[2], v[3], sat));
   };
   // X16: the row piece is fp16 already -- LeakyReLU on the packed halves (max(x, slope x), 0 < slope < 1), nothing to convert
-  const f16x2 slope_h = {(_Float16)slope, (_Float16)slope};
   auto to_patch16 = [&](char* patch, const u32x2& raw, int pr) __attribute__((always_inline)) {
-    const f16x2 a = __builtin_bit_cast(f16x2, raw[0]), b = __builtin_bit_cast(f16x2, raw[1]);
-    const f16x2 va = __builtin_elementwise_max(a, a * slope_h), vb = __builtin_elementwise_max(b, b * slope_h);
-    *reinterpret_cast<uint2*>(patch + pr * ROWB + (((cg >> 1) ^ ((pr >> 1) & 7)) << 4) + 8 * (cg & 1)) =
-        make_uint2(__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, vb));
+    const u32x2 v = f16x4_lrelu(raw, slope);
+    *reinterpret_cast<uint2*>(patch + pr * ROWB + (((cg >> 1) ^ ((pr >> 1) & 7)) << 4) + 8 * (cg & 1)) = make_uint2(v.x, v.y);
   };
 
   f32x16 acc[WM];
@@ -323,8 +319,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       if constexpr (X16) {
 #pragma unroll
         for (int q = 0; q < NCQ; ++q) {
-          const f16x2 a = __builtin_bit_cast(f16x2, PC[q][0]), b = __builtin_bit_cast(f16x2, PC[q][1]);
-          K[q] = f32x4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+          K[q] = f16x4_widen(PC[q]);
           if (crow(q) < P) to_patch16(lds + R0, PC[q], crow(q));
         }
 #pragma unroll

@@ -350,7 +350,6 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   // requested ONE sub-pass ahead -- and the compiler moving that request behind the stores -- the epilogue was eight exposed
   // memory latencies: 32 k of a block's 91 k cycles.  A whole pass ahead (64 registers) spills beside the 128 accumulators.)
   constexpr int NRB = 3;  // residual register sets: sub-pass i uses set i % NRB and then requests sub-pass i + NRB into it
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef typename std::conditional<X16, u32x2, u32x4>::type res_t;  // 4 channels: fp16 (8 bytes) or fp32 (16 bytes)
   res_t res[NRB][SUB];
   auto request_res = [&](int idx) __attribute__((always_inline)) {  // idx = pass * NSUB + sub-pass
@@ -365,8 +364,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   // the residual of row q of the register set: X16: x = min(xa, xa / slope) of the fp16 operand form (a masked row loads zeros)
   auto res_f32 = [&](const res_t& r) __attribute__((always_inline)) -> f32x4 {
     if constexpr (X16) {
-      const f16x2 a = __builtin_bit_cast(f16x2, r[0]), b = __builtin_bit_cast(f16x2, r[1]);
-      const f32x4 v = {(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+      const f32x4 v = f16x4_widen(r);
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fminf(v[e], v[e] * inv_slope);

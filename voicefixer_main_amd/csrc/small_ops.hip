@@ -1,6 +1,7 @@
 // small_ops.hip -- HBM-bound edge kernels around the tap-convolution engine (gfx950).
 // All activations are channels-last fp32; every kernel is written for 16-byte-per-lane
 // coalesced access along the channel axis (or along the innermost spatial axis when C == 1).
+#include "conv_common.h"
 #include "vfx_internal.h"
 
 namespace vfx {
@@ -388,12 +389,12 @@ __global__ void k_trim_scale(const float* __restrict__ x, int64_t Llong, int L, 
   if (n >= L) return;
   const float p = __uint_as_float(peak[b]);
   // eval_gsr_voicefixer.py:68-70 prints "Warning: Exceed energy limit" here: the handlers read this sticky bit once per file
-  if (n == 0 && p > 1.0f && flags) atomicOr(flags, VFX_FLAG_PEAK_NORMALISED);
+  if (n == 0 && p > 1.0f && flags) or_flag_global(flags, VFX_FLAG_PEAK_NORMALISED);
   const float v = x[(int64_t)b * Llong + off + n];
   out[(int64_t)b * L + n] = p > 1.0f ? v / p : v;
 }
 
-__global__ void k_or_flags(int* flags, int bits) { atomicOr(flags, bits); }
+__global__ void k_or_flags(int* flags, int bits) { or_flag_global(flags, bits); }  // (no FLAT atomics anywhere: conv_common.h)
 void launch_or_flags(int* flags, int bits, hipStream_t s) {
   if (!flags) return;
   hipLaunchKernelGGL(k_or_flags, dim3(1), dim3(1), 0, s, flags, bits);

@@ -131,9 +131,13 @@ class Engine:
     def workspace_bytes(self, model, B, T):
         return int(self.lib.vfx_workspace_bytes(self.h, model, B, T))
 
-    def take_flags(self):
+    def take_flags(self, mask=None):
+        """Read and clear the sticky device flags (one device sync); with `mask`, only those bits -- the others stay raised."""
         f = ctypes.c_int(0)
-        _lib.check(self.lib.vfx_take_flags(self.h, self._stream(), ctypes.byref(f)), "vfx_take_flags")
+        if mask is None:
+            _lib.check(self.lib.vfx_take_flags(self.h, self._stream(), ctypes.byref(f)), "vfx_take_flags")
+        else:
+            _lib.check(self.lib.vfx_take_flags_masked(self.h, self._stream(), int(mask), ctypes.byref(f)), "vfx_take_flags_masked")
         return f.value
 
     # ------------------------------------------------------------------ stages
@@ -251,6 +255,12 @@ class Engine:
         _lib.check(self.lib.vfx_restore_gsr(self.h, _ptr(wav), B, L, _ptr(out), _ptr(logmel), int(bool(unify_energy)),
                                             self._stream()), "vfx_restore_gsr")
         return (out, logmel) if want_logmel else out
+
+    def check_negative_input(self):
+        """`to_log`'s assert alone (pytorch_util.py:158): reads and clears ONLY the negative-input bit -- a saturation bit a
+        deferred vocoder check still has to see stays raised."""
+        if self.take_flags(_lib.FLAG_NEGATIVE_INPUT) & _lib.FLAG_NEGATIVE_INPUT:
+            raise AssertionError("to_log: input has negative values")
 
     def check_flags(self, rerun=None):
         """Reads and clears the handle's sticky device flags (one device sync, like `to_log`'s assert in the reference).

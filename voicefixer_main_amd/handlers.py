@@ -190,6 +190,10 @@ class _WavReader:
             x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
             x = x.reshape(-1, self.ch).mean(axis=1) if self.ch > 1 else x
         self.pos += x.shape[0]
+        if x.shape[0] < count:
+            # the data chunk ended: `load_wav` would have returned exactly the frames that are there, whatever the header
+            # promised (a truncated file, a streamed header) -- the segment loop ends here instead of reading empty segments
+            self.n = self.pos
         return x
 
     def close(self):
@@ -282,6 +286,9 @@ def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=Fals
 
     def run(model, output):
         nonlocal metrics
+        # every file starts with clean flags: an exception in the middle of the previous file (frame mismatch, a short tail
+        # segment, out of memory) skipped its flag check and would otherwise hand this file a stale saturation / negative bit
+        model.engine.take_flags()
         reader = _WavReader(input, 44100)
         tgt = load_wav(target, sample_rate=44100) if target is not None else None
         writer = _WavWriter(output, 44100)
@@ -292,6 +299,8 @@ def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=Fals
         try:
             while break_point < len(reader) + seg_length:
                 segment = reader.read(seg_length)
+                if segment.shape[0] == 0:      # the header promised more frames than the file holds
+                    break
                 _, mel_noisy, seg_t = _pre(model, torch.from_numpy(segment).pin_memory().to(device, non_blocking=True), device)
                 out_model = model(mel_noisy, check=False)
                 denoised_mel = from_log(out_model["mel"])
@@ -345,6 +354,9 @@ def handler_ssr_unet(input, output, target, ckpt, device, needrefresh=False, met
     model = _state["model"].to(device)
     metrics = {}
     with torch.no_grad():
+        # every file starts with clean flags: an exception in the middle of the previous file (frame mismatch, a short tail
+        # segment, out of memory) skipped its flag check and would otherwise hand this file a stale saturation / negative bit
+        model.engine.take_flags()
         reader = _WavReader(input, 44100)
         tgt = load_wav(target, sample_rate=44100) if target is not None else None
         writer = _WavWriter(output, 44100)
@@ -355,6 +367,8 @@ def handler_ssr_unet(input, output, target, ckpt, device, needrefresh=False, met
         try:
             while break_point < len(reader) + seg_length:
                 segment = reader.read(seg_length)
+                if segment.shape[0] == 0:      # the header promised more frames than the file holds
+                    break
                 sp, _, seg_t = _pre(model, torch.from_numpy(segment).pin_memory().to(device, non_blocking=True), device)
                 out = model(sp, seg_t)["wav"]
                 if tgt is not None:

@@ -157,7 +157,9 @@ class Vocoder:
         the handlers."""
         assert mel.size()[-1] == 128
         out = self.engine.vocoder(mel[:, 0])
-        if check:
+        # only the 16-bit mode can raise a flag here (saturation); the negative-input flag belongs to the UNet stage's prep
+        # kernel.  The reference's vocoder has no assert and no sync: precision 0 / 1 pay none either.
+        if check and self.engine.precision == 2:
             out = _rerun_if_saturated(self.engine, out, lambda e: e.vocoder(mel[:, 0]))
         return out[:, None]
 
@@ -344,7 +346,9 @@ class VoiceFixer(_Base):
         gsr_voicefixer.py:86-91).  `check` reproduces to_log's assert (one device sync)."""
         out = self.engine.resunet_mel(mel_orig[:, 0])[:, None]
         if check:
-            self.engine.check_flags(lambda e: None)   # raises on a negative input; a saturation flag belongs to the vocoder call
+            # to_log's assert; a saturation bit left by a deferred vocoder check (Vocoder.__call__(check=False), raw engine calls)
+            # is NOT consumed here -- it stays raised for that check
+            self.engine.check_negative_input()
         return {"mel": out}
 
     __call__ = forward
