@@ -83,6 +83,37 @@ def test_read_lightning_checkpoint_with_unimportable_hparams(tmp_path):
     assert set(read_checkpoint(bare)) == set(unet_sd)
 
 
+def test_read_gan_style_vocoder_checkpoint(tmp_path):
+    """The pip vocoder's own file is a GAN-trainer container, `{'generator': state_dict, 'discriminator': ..., 'steps': ...}`
+    (the reference builds `Vocoder(sample_rate=44100)`, models/gsr_voicefixer.py:113; the file itself is not obtainable
+    offline): read_checkpoint picks the generator's tensors, weight-norm pairs and a DataParallel prefix are undone by
+    Vocoder.load_from_checkpoint's host half (checked here without a GPU)."""
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.models import fold_weight_norm, read_checkpoint
+    voc_sd = synth.make_vocoder_state_dict(1)
+    gen = {}
+    for k, v in voc_sd.items():
+        if k.endswith(".weight"):
+            norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape((-1,) + (1,) * (v.dim() - 1))
+            gen["module." + k[:-len("weight")] + "weight_g"] = norm
+            gen["module." + k[:-len("weight")] + "weight_v"] = v * 1.7
+        else:
+            gen["module." + k] = v
+    path = str(tmp_path / "model.ckpt-1490000_trimed.pt")
+    torch.save({"generator": gen, "discriminator": {"d.weight": torch.zeros(2)}, "steps": 1490000}, path)
+    got = read_checkpoint(path)
+    assert set(got) == set(gen)
+    plain = fold_weight_norm({k[len("module."):]: v for k, v in got.items()})
+    assert set(plain) == set(voc_sd)
+    for k in voc_sd:
+        assert torch.allclose(plain[k], voc_sd[k], rtol=1e-6, atol=1e-8), k
+    torch.save({"model": {"w": torch.ones(2)}}, path)
+    assert set(read_checkpoint(path)) == {"w"}
+    torch.save({"steps": 3}, path)
+    with pytest.raises(ValueError):
+        read_checkpoint(path)
+
+
 class _Evil:
     def __reduce__(self):
         return (os.system, ("touch %s" % _Evil.marker,))
@@ -128,3 +159,22 @@ def test_load_from_checkpoint_equals_load_state_dict(tmp_path):
     assert err < 2e-5, err
     mel = a.pre(wav)[1]
     assert torch.equal(a(mel)["mel"], b(mel)["mel"])          # the ResUNet weights are bit-identical
+    # ... and against the ORACLE (HIP vs HIP alone would not notice a key mapped to the wrong layer in both loaders): the
+    # checkpoint-loaded model restores what oracle.pipeline.restore_gsr computes from the plain tensors, within the bars
+    # of the library's default arithmetic (split-bf16)
+    from conftest import TOL
+    from oracle import pipeline
+    ref = pipeline.restore_gsr(unet_sd, voc_sd, wav.cpu().numpy())
+    w = ya.cpu().numpy().astype(np.float64)[:, 0]
+    rw = ref["wav"][:, 0].astype(np.float64)
+    sisdr = 10 * np.log10((rw ** 2).sum() / (((w - rw) ** 2).sum() + 1e-30))
+    assert sisdr > TOL[1]["sisdr"], sisdr
+    lm = a(mel)["mel"][:, 0].cpu().numpy()
+    assert np.abs(lm - ref["logmel"][:, 0]).mean() < TOL[1]["logmel_l1"]
+    # the vocoder's own file through Vocoder.load_from_checkpoint: the same waveform as the plain tensors
+    vpath = str(tmp_path / "vocoder.pt")
+    torch.save({"generator": {"module." + k: v for k, v in voc_sd.items()}, "steps": 1}, vpath)
+    c = models.VoiceFixer(None, channels=2, type_target="vocals")
+    c.load_state_dict({"generator.analysis_module." + k: v for k, v in unet_sd.items()})
+    c.vocoder.load_from_checkpoint(vpath)
+    assert torch.equal(c.restore(wav), yb)

@@ -49,13 +49,16 @@ def _gsr_oracle(n_clips, seconds, seed):
 
 
 @functools.lru_cache(maxsize=None)
-def _ssr_oracle(n_clips, n_samples, seed):
+def _ssr_oracle(n_clips, n_samples, seed, mode="lowpass"):
     from oracle import pipeline
     from voicefixer_main_amd import synth
     _threads()
-    wav = synth.make_clips(n_clips, n_samples / 44100.0, seed=seed, mode="lowpass")
+    wav = synth.make_clips(n_clips, n_samples / 44100.0, seed=seed, mode=mode)
     assert wav.shape[-1] == n_samples
-    # float64 oracle: two fp32 evaluations of this trunk (linear-magnitude input, 1024 bins) agree to ~58 dB only
+    # float64 oracle.  On LOW-PASSED clips (configs[2]'s input) two fp32 evaluations of this path agree to ~58-66 dB only: the
+    # bins above the cut-off are numerically empty, their phase is rounding noise / 1e-4 (the clamp of fDomainHelper.py:60-65)
+    # -- different noise in every implementation, multiplied by the energy the network writes there.  On FULL-BAND clips
+    # (mode "noise") fp32 agrees with float64 to > 100 dB (scripts/ssr_conditioning.py, tests/test_oracle_golden.py).
     sd = {k: (v.double() if v.is_floating_point() else v) for k, v in synth.make_resunet_state_dict(2).items()}
     return wav, pipeline.restore_ssr(sd, wav, dtype=torch.float64)
 
@@ -99,18 +102,21 @@ def test_reference_segment_1x60s(engine):
     _check_gsr(engine, wav, ref, stages=False)
 
 
-# SI-SDR of the spectrogram path against the FLOAT64 oracle, per arithmetic mode: measured on MI355X (round 3,
-# gpurun_out/parity_shapes.json -> profiles/r03_parity_shapes.json), the bars sit 5 dB under the measurement.
-SSR_SISDR_BAR = {"fp32": 55.0, "split-bf16": 52.0, "fp16-vocoder": 52.0}   # measured: split-bf16 57.8 dB (both lengths)
+# SI-SDR of the spectrogram path against the FLOAT64 oracle, per arithmetic mode and input kind.
+#   full-band clips: ACCURACY bars for the kernels (the comparison is not limited by the input, see _ssr_oracle);
+#   low-passed clips (configs[2]'s super-resolution input): the empty-bin phase noise bounds every fp32 implementation at
+#   58-66 dB; the bar is a regression guard 5 dB under what was measured on MI355X (round 3: 57.8 dB in EVERY mode, fp32 included).
+SSR_SISDR_BAR = {"noise": {"fp32": 85.0, "split-bf16": 70.0, "fp16-vocoder": 70.0},
+                 "lowpass": {"fp32": 55.0, "split-bf16": 52.0, "fp16-vocoder": 52.0}}
 
 
-@pytest.mark.parametrize("n_samples", [132300, 132300 + 200])
-def test_ssr_unet_3s_shape(engine, n_samples):
+@pytest.mark.parametrize("n_samples,mode", [(132300, "noise"), (132300 + 200, "noise"), (132300 + 200, "lowpass")])
+def test_ssr_unet_3s_shape(engine, n_samples, mode):
     """configs[2] shape: T = 301, Tpad = 320, F = 1024; the second length is not a multiple of the hop, so the ISTFT
     tail (tools/dsp/base.py:196-200) is part of the comparison -- relative to the TAIL's own peak."""
     from voicefixer_main_amd import synth
     from voicefixer_main_amd.engine import MODEL_UNET_SPEC
-    wav, ref = _ssr_oracle(2, n_samples, 5)
+    wav, ref = _ssr_oracle(2, n_samples, 5, mode)
     engine.load_state_dict(MODEL_UNET_SPEC, synth.make_resunet_state_dict(2))
     x = torch.from_numpy(wav[:, 0]).cuda()
     sp = engine.stft(x, want_mel=False, want_sp=True)["sp"]
@@ -118,13 +124,13 @@ def test_ssr_unet_3s_shape(engine, n_samples):
     got = engine.resunet_spec(sp, x).cpu().numpy()
     assert got.shape == (2, n_samples)
     s = _sisdr(got, ref["wav"][:, 0])
-    _report("ssr_3s_sisdr_db[%s,%d]" % (engine.tol["name"], n_samples), s)
-    assert s > SSR_SISDR_BAR[engine.tol["name"]], s
+    _report("ssr_3s_sisdr_db[%s,%d,%s]" % (engine.tol["name"], n_samples, mode), s)
+    assert s > SSR_SISDR_BAR[mode][engine.tol["name"]], s
     tail = n_samples % 441
     if tail:
         rt = ref["wav"][:, 0, -tail:]
         rel = float(np.abs(got[:, -tail:] - rt).max() / np.abs(rt).max())
-        _report("ssr_3s_tail_rel_err[%s]" % engine.tol["name"], rel)
+        _report("ssr_3s_tail_rel_err[%s,%s]" % (engine.tol["name"], mode), rel)
         assert np.abs(rt).max() > 0 and rel < 1e-3, rel            # measured: 8.6e-5 (split-bf16)
 
 
@@ -174,7 +180,7 @@ def test_handler_ssr_unet_two_segments(engine, tmp_path):
     _report("ssr_handler_sisdr_db_60s_segment", s60)
     _report("ssr_handler_sisdr_db_1s_segment", s1)
     # PCM16 output: quantisation noise alone is ~ -101 dB re full scale
-    assert s60 > SSR_SISDR_BAR["split-bf16"] - 4.0 and s1 > SSR_SISDR_BAR["split-bf16"], (s60, s1)
+    assert s60 > SSR_SISDR_BAR["lowpass"]["split-bf16"] - 4.0 and s1 > SSR_SISDR_BAR["lowpass"]["split-bf16"], (s60, s1)
     # the metrics of the last segment, from the oracle's waveform with the formulas of evaluation_proc (torch, CPU)
     from oracle import dsp
     lo = 44100 * 60

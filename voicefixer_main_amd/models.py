@@ -152,6 +152,17 @@ class Vocoder:
     def load_state_dict(self, sd, prefix=""):
         self.engine.load_state_dict(MODEL_VOCODER, fold_weight_norm(sd), prefix)
 
+    def load_from_checkpoint(self, ckpt):
+        """The pip package keeps its own generator file beside the Lightning checkpoint (the reference constructs
+        `Vocoder(sample_rate=44100)`, models/gsr_voicefixer.py:113, and the weights come from the package cache): a
+        `{'generator': state_dict}` container (read_checkpoint), weight-norm pairs folded here, a DataParallel `module.` prefix
+        dropped."""
+        sd = read_checkpoint(ckpt)
+        if sd and all(k.startswith("module.") for k in sd):
+            sd = {k[len("module."):]: v for k, v in sd.items()}
+        self.load_state_dict(sd)
+        return self
+
     def __call__(self, mel, cuda=None, check=True):
         """`check` = False defers the flag check (one device sync) to the caller: Engine.check_flags, once per file in
         the handlers."""
@@ -258,15 +269,20 @@ class _PickleModule:
 
 
 def read_checkpoint(path):
-    """Lightning .ckpt (``{'state_dict': ..., 'hyper_parameters': ...}``, eval_gsr_voicefixer.py:33) or a bare
-    state_dict file -> state_dict of CPU tensors.  Tries torch's `weights_only` reader first; a file that only fails
-    there because it pickles project classes is re-read with the allow-listing unpickler above (nothing the file
-    names is imported or executed)."""
+    """Lightning .ckpt (``{'state_dict': ..., 'hyper_parameters': ...}``, eval_gsr_voicefixer.py:33), a GAN-style container
+    (``{'generator': state_dict, ...}``: the pip vocoder's own file; ``{'model': ...}``) or a bare state_dict file ->
+    state_dict of CPU tensors.  Tries torch's `weights_only` reader first; a file that only fails there because it pickles
+    project classes is re-read with the allow-listing unpickler above (nothing the file names is imported or executed)."""
     try:
         obj = torch.load(path, map_location="cpu", weights_only=True)
     except pickle.UnpicklingError:
         obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
-    sd = obj["state_dict"] if isinstance(obj, dict) and "state_dict" in obj else obj
+    sd = obj
+    for key in ("state_dict", "generator", "model"):
+        if isinstance(obj, dict) and isinstance(obj.get(key), dict) and obj[key] and \
+                all(isinstance(v, torch.Tensor) for v in obj[key].values()):
+            sd = obj[key]
+            break
     if not isinstance(sd, dict) or not sd or not all(isinstance(v, torch.Tensor) for v in sd.values()):
         raise ValueError("%s holds no state_dict of tensors" % path)
     return sd

@@ -71,7 +71,13 @@ def _xavier(shape, gen, gain=1.0):
     return (torch.rand(shape, generator=gen, dtype=torch.float32) * 2.0 - 1.0) * bound
 
 
-def make_resunet_state_dict(seed=0, channels_in=1):
+def make_resunet_state_dict(seed=0, channels_in=1, res_gain=1.0):
+    """`res_gain` < 1 damps the residual branch of every ConvBlockRes (its conv2) -- the WELL-CONDITIONED network of the
+    spectrogram-path parity tests: with every branch at full Xavier gain the 50-block residual stream grows by orders of
+    magnitude and the last 1x1 convolution cancels it back down, so two fp32 evaluations of the same trunk agree to ~58 dB
+    only and no kernel can be told from another below that; at res_gain = 0.25 the stream stays O(1) and fp32 agrees with
+    float64 to > 80 dB (measured in tests/test_oracle_golden.py), so a bar of 70 dB on the split-bf16 kernels is an accuracy
+    statement.  The random draws are the same for every gain (same seed -> the same tensors up to that factor)."""
     gen = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     for key, shape in resunet_layout(channels_in):
@@ -83,6 +89,8 @@ def make_resunet_state_dict(seed=0, channels_in=1):
             sd[key] = torch.randn(shape, generator=gen) * 0.1          # beta, running_mean, conv biases
         else:
             sd[key] = _xavier(shape, gen)
+            if res_gain != 1.0 and key.endswith(".conv2.weight"):
+                sd[key] = sd[key] * res_gain
     return sd
 
 
