@@ -79,6 +79,10 @@ def parse():
     ap.add_argument("--no-aux", action="store_true", help="skip the nested ssr_sr64 / stream1s measurements of the default run")
     ap.add_argument("--aux-steps", type=int, default=3)
     ap.add_argument("--cpu-repeats", type=int, default=3, help="timed calls of the CPU oracle (the median is reported)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="TEST ONLY (tests/test_host.py): run this script's own rank plumbing -- process group, weight broadcast, "
+                         "sharding, barrier + max-over-ranks clock, the JSON line -- on CPU over gloo with the engine replaced by "
+                         "an identity stub; the line says dry_run_cpu and its value means nothing")
     ap.add_argument("--tuning", type=int, default=0, help="vfx_config.tuning mask (include/vfx.h VFX_TUNE_*); 0 = the shipped kernel selection")
     ap.add_argument("--precision", type=int, default=2, help="0 = exact fp32 MFMA, 1 = split-bf16 (hi+lo, 3 bf16 MFMAs), 2 = ResUNet split-bf16 + vocoder fp16 (1 MFMA per product)")
     args = ap.parse_args()
@@ -492,6 +496,23 @@ class PowerSampler:
 # ---------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------
+class _StubEngine:
+    """--dry-run-cpu: stands where the libvfx handle stands, computes nothing (identity).  Never used by a measurement."""
+
+    def __init__(self, device, config=None):
+        self.device, self.loaded = torch.device(device), {}
+
+    def load_state_dict(self, model, sd, prefix=""):
+        self.loaded[model] = sum(int(v.numel()) for v in sd.values())
+
+    def restore_gsr(self, wav, unify_energy=False, want_logmel=False, out=None):
+        res = wav.clone() if out is None else out.copy_(wav)
+        return (res, torch.zeros((wav.shape[0], wav.shape[1] // 441 + 1, 128))) if want_logmel else res
+
+    def take_flags(self, mask=None):
+        return 0
+
+
 class Workload:
     """One BASELINE.json config on one rank: `step()` enqueues one pass of the hot path over its batch of clips, which are
     resident in HBM before the clock starts."""
@@ -500,6 +521,10 @@ class Workload:
         from voicefixer_main_amd import dist as vdist
         from voicefixer_main_amd import synth
         from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER
+        self.cuda = torch.device(device).type == "cuda"
+        if not self.cuda:          # --dry-run-cpu
+            assert args.dry_run_cpu and wl in ("gsr16x10", "sharded1024")
+            Engine = _StubEngine
         d_clips, d_sec = {"gsr16x10": (16, 10.0), "sharded1024": (128, 10.0), "ssr_sr64": (64, 3.0), "stream1s": (1, 1.0)}[wl]
         self.wl, self.device, self.rank, self.world, self.precision = wl, device, rank, world, precision
         self.B = B = clips_n or d_clips
@@ -552,7 +577,7 @@ class Workload:
                 full = None
             self.phases = phases = {"scatter_ms": 0.0, "restore_ms": 0.0, "gather_ms": 0.0}
             self.gathered = gathered = [None]
-            sync = lambda: torch.cuda.synchronize(device)
+            sync = (lambda: torch.cuda.synchronize(device)) if self.cuda else (lambda: None)
 
             def step(e=eng, acc=phases):
                 back, t = vdist.sharded_step(lambda x: e.restore_gsr(x), full, n_total, L, device, sync=sync)
@@ -599,25 +624,28 @@ class Workload:
 
     def timed(self, steps, warmup, barrier=lambda: None):
         """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides -> seconds."""
+        sync = (lambda: torch.cuda.synchronize(self.device)) if self.cuda else (lambda: None)
         for _ in range(warmup):
             self.step()
-        torch.cuda.synchronize(self.device)
+        sync()
         if self.phases:
             for k in self.phases:
                 self.phases[k] = 0.0
         # one event per step boundary on the launch stream (torch's current stream is the one handed to libvfx): the spread of
         # the K steps inside the SAME timed region -- the clock around the region stays the host's, as the contract says
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if self.cuda else None
         barrier()
         t0 = time.perf_counter()
-        ev[0].record()
+        if ev:
+            ev[0].record()
         for i in range(steps):
             self.step()
-            ev[i + 1].record()
-        torch.cuda.synchronize(self.device)
+            if ev:
+                ev[i + 1].record()
+        sync()
         barrier()
         dt = time.perf_counter() - t0
-        self.step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        self.step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)] if ev else []
         return dt
 
     def flags(self):
@@ -698,12 +726,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    if args.dry_run_cpu:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        device = torch.device("cpu")
+    else:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
 
     from voicefixer_main_amd import dist as vdist
 
@@ -744,7 +778,7 @@ def main():
             "config": {"workload": wl, "precision_mode": args.precision, "tuning": args.tuning, "clips_per_gpu": B, "clip_seconds": w.seconds,
                        "parallelism": "dp%d" % world, "weights": "seeded random (no checkpoint available offline)"
                        + ("; built on rank 0, one flat broadcast to the other ranks" if world > 1 else "")},
-            "rccl_ranks": rccl_ranks, "negative_input_flag": int(flags["negative_input"]), "f16_saturated": flags["f16_saturated"],
+            "rccl_ranks": rccl_ranks, "dry_run_cpu": bool(args.dry_run_cpu), "negative_input_flag": int(flags["negative_input"]), "f16_saturated": flags["f16_saturated"],
         }
         res.update(w.extra)
         res["power"] = sampler.result()
@@ -776,7 +810,7 @@ def main():
     elif rank == 0:
         res["outputs_finite"] = bool(torch.isfinite(w.holder[0]).all().item())
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.dry_run_cpu:
         traffic = None
         if not args.no_roofline:
             if args.traffic == "live" and gsr:

@@ -10,6 +10,6 @@ mkdir -p $ROOT/voicefixer_main_amd/abl /tmp/vfx_timing
 for f in resblock resblock_w64 resblock_r128; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -DVFX_TIMING -c $CS/$f.hip -o /tmp/vfx_timing/$f.o
 done
-objs=$(ls $CS/build/*.o | grep -v "/resblock.o\|/resblock_w64.o\|/resblock_r128.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/voicefixer_main_amd/abl/libvfx_timing.so $objs /tmp/vfx_timing/*.o
+objs=$(ls $CS/build/*.o | grep -v "/ops_debug.o\|/resblock.o\|/resblock_w64.o\|/resblock_r128.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libvfx.so -o $ROOT/voicefixer_main_amd/abl/libvfx_timing.so $objs /tmp/vfx_timing/*.o
 ls -la $ROOT/voicefixer_main_amd/abl/libvfx_timing.so

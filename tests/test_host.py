@@ -20,6 +20,19 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libvfx.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    # ... and NOTHING else with C linkage: the product library is the reference-surface entry points + the profile hooks; the
+    # kernel-level test entry points live in libvfx_test.so (include/vfx_test.h), which the product never loads
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    c_syms = {l.split()[-1] for l in nm.splitlines() if len(l.split()) == 3 and l.split()[1] in "TW" and l.split()[-1].startswith("vfx_")}
+    assert c_syms == declared, sorted(c_syms ^ declared)
+    thdr = open(os.path.join(ROOT, "include", "vfx_test.h")).read()
+    tdecl = set(re.findall(r"\b(vfx_[a-z0-9_]+)\s*\(", thdr))
+    assert tdecl and not (tdecl & declared) and tdecl == set(_lib.TEST_SIGNATURES), (tdecl ^ set(_lib.TEST_SIGNATURES))
+    tlib = _lib.load_test()
+    for name in sorted(tdecl):
+        assert hasattr(tlib, name), "libvfx_test.so does not export %s" % name
+    for f in ("models.py", "handlers.py", "dist.py", "chunker.py", "simulate.py", "synth.py"):
+        assert "load_test" not in open(os.path.join(ROOT, "voicefixer_main_amd", f)).read(), f
 
 
 def test_default_config_and_error_channel():
@@ -240,6 +253,39 @@ got = vdist.broadcast_state_dict(sd, dev)
 g = torch.Generator().manual_seed(3)
 want = {"a.weight": torch.randn(4, 3, 3, 3, generator=g), "a.bias": torch.randn(4, generator=g), "s": torch.randn((), generator=g)}
 assert set(got) == set(want) and all(got[k].shape == want[k].shape and torch.equal(got[k], want[k].float()) for k in want), rank
+# a test set of clips of UNEQUAL lengths (SURVEY 8e: sorted by length, dealt round-robin; equal lengths batch together):
+# 5 clips of 3 lengths on 2 ranks; the stand-in engine marks every element with its clip's batch size, so the batching shows
+calls = []
+def eng(x):
+    calls.append(tuple(x.shape))
+    return x * 2.0 + float(x.shape[0])
+lens = [100, 37, 100, 64, 37]
+clips = [torch.arange(L, dtype=torch.float32) + 1000.0 * i for i, L in enumerate(lens)] if rank == 0 else None
+assert vdist.deal_by_length(lens, 2) == [0, 1, 1, 0, 0]          # by length: 100, 100, 64, 37, 37 -> ranks 0, 1, 0, 1, 0
+back = vdist.restore_sharded_lengths(eng, clips, dev)
+assert sorted(calls) == ([(1, 37), (1, 64), (1, 100)] if rank == 0 else [(1, 37), (1, 100)]), (rank, calls)
+if rank == 0:
+    assert [int(b.shape[0]) for b in back] == lens
+    assert all(torch.equal(b, c * 2.0 + 1.0) for b, c in zip(back, clips))
+else:
+    assert back is None
+# equal lengths on one rank DO share a call: 4 clips of one length -> two per rank, one call each; max_batch splits a bucket
+calls.clear()
+clips = [torch.full((50,), float(i)) for i in range(4)] if rank == 0 else None
+back = vdist.restore_sharded_lengths(eng, clips, dev)
+assert calls == [(2, 50)], (rank, calls)
+if rank == 0:
+    assert all(torch.equal(b, c * 2.0 + 2.0) for b, c in zip(back, clips))
+calls.clear()
+back = vdist.restore_sharded_lengths(eng, clips, dev, max_batch=1)
+assert calls == [(1, 50), (1, 50)]
+# fewer clips than ranks: an EMPTY rank takes part in nothing but the length broadcast
+calls.clear()
+clips = [torch.arange(9, dtype=torch.float32)] if rank == 0 else None
+back = vdist.restore_sharded_lengths(eng, clips, dev)
+assert calls == ([(1, 9)] if rank == 0 else [])
+if rank == 0:
+    assert torch.equal(back[0], clips[0] * 2.0 + 1.0)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -254,6 +300,54 @@ def test_scatter_gather_two_ranks_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
+
+
+@pytest.mark.parametrize("workload,launcher", [("gsr16x10", "torchrun"), ("sharded1024", "torchrun"), ("gsr16x10", "self-spawn")])
+def test_bench_rank_plumbing_dry_run_two_ranks(workload, launcher):
+    """bench.py's OWN N > 1 branch has never run on hardware (no multi-GPU box in rounds 1-4): `--dry-run-cpu` runs exactly
+    that code -- process group, one-flat-broadcast of the weights, per-rank clips / scatter + gather, barrier + max-over-ranks
+    clock, rank 0's JSON line -- over gloo with an identity stub where the libvfx handle stands, launched the way the driver
+    launches it (`python -m torch.distributed.run ... bench.py --gpus N`) and the way `bench.py --gpus N` spawns itself."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu", "--workload", workload,
+            "--clips", "3", "--seconds", "0.2"]
+    port = {"gsr16x10": 29641, "sharded1024": 29643}[workload]
+    cmd = [sys.executable] + ((["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                "--master-port", str(port)]) if launcher == "torchrun" else []) + tail
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd="/tmp")
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]                   # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["dry_run_cpu"] is True and d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["config"]["workload"] == workload and d["config"]["parallelism"] == "dp2" and d["outputs_finite"] is True
+    total_audio = (2 * 3 if workload == "gsr16x10" else 6) * 0.2
+    assert abs(d["value"] - total_audio / (d["ms_per_step"] * 1e-3)) < 2e-2 * d["value"]      # whole-job aggregate over both ranks
+    if workload == "sharded1024":
+        assert d["clips_total"] == 6 and d["gather_matches_direct_restore"] is True
+        assert all(d[k] >= 0 for k in ("scatter_ms", "restore_ms", "gather_ms"))
+    # a WORLD_SIZE that disagrees with --gpus is refused
+    bad = subprocess.run([sys.executable] + tail, capture_output=True, text=True, env=dict(env, WORLD_SIZE="4"), timeout=120, cwd="/tmp")
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_length_bucketing_in_a_world_of_one():
+    """dist.restore_sharded_lengths without a process group = the single-GPU length-bucketing helper: clips of equal length share
+    a call (at most max_batch), the results come back in file order."""
+    from voicefixer_main_amd import dist as vdist
+    calls = []
+
+    def eng(x):
+        calls.append(tuple(x.shape))
+        return -x
+    lens = [30, 10, 30, 30, 10, 7]
+    clips = [torch.arange(L, dtype=torch.float32) + i for i, L in enumerate(lens)]
+    back = vdist.restore_sharded_lengths(eng, clips, torch.device("cpu"), max_batch=2)
+    assert calls == [(2, 30), (1, 30), (2, 10), (1, 7)]
+    assert all(torch.equal(b, -c) for b, c in zip(back, clips))
+    assert vdist.restore_sharded_lengths(eng, [], torch.device("cpu")) == []
 
 
 def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
@@ -347,7 +441,7 @@ def test_resblock_tiles_cover_every_position_once(C, precision, tuning):
     of conv1 stay inside the patch."""
     import ctypes
     from voicefixer_main_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_test()
     out = (ctypes.c_int * 12)()
     cases = [(d, 0) for d in (1, 3, 9, 27, 81, 243, 729, 2187)]
     if C == 64 and precision == 2 and tuning == 0:

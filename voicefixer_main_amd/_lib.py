@@ -1,4 +1,4 @@
-"""ctypes binding of libvfx.so (the C ABI declared in include/vfx.h).
+"""ctypes binding of libvfx.so (the C ABI declared in include/vfx.h) and, for the tests, libvfx_test.so (include/vfx_test.h).
 
 The product path has NO fallback: if the shared library cannot be loaded, or a call
 fails, a RuntimeError is raised.  PyTorch is used only for device memory and streams.
@@ -10,6 +10,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFX_LIB_PATH") or os.path.join(HERE, "libvfx.so")   # VFX_LIB_PATH: ablation builds (scripts/)
+TEST_LIB_PATH = os.path.join(HERE, "libvfx_test.so")
 CSRC = os.path.join(HERE, "csrc")
 
 VFX_MAX_STAGES = 8
@@ -60,6 +61,11 @@ SIGNATURES = {
     "vfx_take_flags_masked": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "vfx_profile_begin": (c_int, [c_void_p]),
     "vfx_profile_end": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+}
+
+# name -> (restype, argtypes): every symbol include/vfx_test.h declares (libvfx_test.so: kernel-level entry points of the parity
+# tests; the product path never loads it)
+TEST_SIGNATURES = {
     "vfx_op_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                             c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfx_op_conv_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
@@ -75,6 +81,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_test_lib = None
 
 
 def build(verbose=False):
@@ -98,7 +105,8 @@ def load():
             "libvfx.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the product path)" % LIB_PATH)
     try:
-        lib = ctypes.CDLL(LIB_PATH)
+        # RTLD_GLOBAL: libvfx_test.so (load_test) resolves the library's internals from THIS copy, whichever path it came from
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     except OSError as e:  # e.g. libamdhip64 missing
         raise RuntimeError("cannot load %s: %s" % (LIB_PATH, e))
     for name, (res, args) in SIGNATURES.items():
@@ -106,6 +114,26 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+def load_test():
+    """Load libvfx_test.so (kernel-level entry points of the parity tests) on top of libvfx.so; raises when it is missing."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    load()
+    if not os.path.exists(TEST_LIB_PATH):
+        raise RuntimeError("libvfx_test.so not found at %s -- build it with `make -C voicefixer_main_amd/csrc`" % TEST_LIB_PATH)
+    try:
+        lib = ctypes.CDLL(TEST_LIB_PATH)
+    except OSError as e:
+        raise RuntimeError("cannot load %s: %s" % (TEST_LIB_PATH, e))
+    for name, (res, args) in TEST_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _test_lib = lib
     return lib
 
 

@@ -1,8 +1,10 @@
-// ops_debug.cpp -- kernel-level C entry points used by the parity tests (vfx_op_*).
-// They pack PyTorch-layout weights on the fly, run one tap-convolution and synchronise.
+// ops_debug.cpp -- libvfx_test.so: kernel-level C entry points used by the parity tests (include/vfx_test.h).
+// They pack PyTorch-layout weights on the fly, run one kernel family of libvfx.so and synchronise.  Not part of the product
+// library: built into its own shared object that resolves the internals it uses from libvfx.so.
 #include <cmath>
 
 #include "vfx_internal.h"
+#include "vfx_test.h"
 
 using namespace vfx;
 

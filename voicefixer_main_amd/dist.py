@@ -144,6 +144,102 @@ def sharded_step(engine_fn, full, n, length, device, src=0, sync=None):
     return back, {"scatter_ms": (t1 - t0) * 1e3, "restore_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3}
 
 
+def deal_by_length(lengths, world):
+    """"clip list sorted by length, dealt round-robin".  -> owner[i] = rank that restores clip i.
+    Longest first, so the ranks' total audio differs by at most one clip of the shortest kind; ties keep the file order (the
+    deal is a pure function of the lengths: every rank computes the same one)."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    owner = [0] * len(lengths)
+    for pos, i in enumerate(order):
+        owner[i] = pos % world
+    return owner
+
+
+def restore_sharded_lengths(engine_fn, clips, device, src=0, max_batch=37, dtype=torch.float32):
+    """A test set of clips of ARBITRARY lengths (the reference iterates files of any length, one handler call each:
+    evaluation_proc/eval.py:119-134) on N ranks.  `clips`: list of 1-D tensors on rank `src` (ignored elsewhere).  Returns the
+    restored clips, same lengths, original order, on `src` (None elsewhere).
+
+    * dealt by length (deal_by_length): the per-rank work is balanced without knowing the speed of anything;
+    * every rank receives its clips as ONE flat buffer (one message per peer and direction, all of rank `src`'s links driven
+      concurrently by the grouped isend / irecv) -- the lengths travel first, as one small object;
+    * within a rank, clips of EQUAL length run as one batch (engine_fn: (B, L) -> (B, L); at most `max_batch` clips per call:
+      the kernels address a tensor with 32-bit byte offsets, 37 clips of 10 s).  Equal length, not equal padded frame count:
+      padding a clip to a neighbour's length would replace the reflection at its end (fDomainHelper.py:26-28, center / reflect)
+      and the ResUNet's own zero padding of the frame axis (unet.py:75-77) by other samples, i.e. change its last frames --
+      batched this way every clip's result is the one a batch-of-one call gives (the kernels' results do not depend on the
+      batch a clip is in, tests/test_gpu_models.py);
+    * a world of one is the length-bucketing helper for a single GPU (no process group needed)."""
+    world, rank = world_rank()
+    meta = [None]
+    if rank == src:
+        meta[0] = [int(c.shape[-1]) for c in clips]
+    if world > 1:
+        dist.broadcast_object_list(meta, src=src)
+    lengths = meta[0]
+    owner = deal_by_length(lengths, world)
+    mine = [i for i in range(len(lengths)) if owner[i] == rank]
+    total = sum(lengths[i] for i in mine)
+    # ---- scatter: one flat buffer per rank
+    if rank == src:
+        ops, flat = [], None
+        for r in range(world):
+            idx = [i for i in range(len(lengths)) if owner[i] == r]
+            if not idx:
+                continue
+            buf = torch.cat([clips[i].reshape(-1).to(device=device, dtype=dtype) for i in idx])
+            if r == src:
+                flat = buf
+            else:
+                ops.append(dist.P2POp(dist.isend, buf, r))
+        if flat is None:
+            flat = torch.empty(0, device=device, dtype=dtype)
+    else:
+        flat = torch.empty(total, device=device, dtype=dtype)
+        ops = [dist.P2POp(dist.irecv, flat, src)] if total else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    # ---- restore: equal lengths as one batch
+    pieces, off = {}, 0
+    for i in mine:
+        pieces[i] = flat[off:off + lengths[i]]
+        off += lengths[i]
+    by_len = {}
+    for i in mine:
+        by_len.setdefault(lengths[i], []).append(i)
+    done = {}
+    for L in sorted(by_len, reverse=True):
+        idx = by_len[L]
+        for a in range(0, len(idx), max_batch):
+            chunk = idx[a:a + max_batch]
+            out = engine_fn(torch.stack([pieces[i] for i in chunk]))
+            for j, i in enumerate(chunk):
+                done[i] = out[j]
+    back = torch.cat([done[i].reshape(-1) for i in mine]) if mine else torch.empty(0, device=device, dtype=dtype)
+    # ---- gather
+    if rank == src:
+        bufs, ops = {src: back}, []
+        for r in range(world):
+            n_r = sum(lengths[i] for i in range(len(lengths)) if owner[i] == r)
+            if r != src and n_r:
+                bufs[r] = torch.empty(n_r, device=device, dtype=back.dtype)
+                ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+    else:
+        ops = [dist.P2POp(dist.isend, back.contiguous(), src)] if total else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if rank != src:
+        return None
+    result, offs = [None] * len(lengths), {r: 0 for r in range(world)}
+    for i in range(len(lengths)):
+        r = owner[i]
+        result[i] = bufs[r][offs[r]:offs[r] + lengths[i]]
+        offs[r] += lengths[i]
+    return result
+
+
 def selfcheck(device, n=11, length=4096):
     """Round-trip a small tensor through scatter/gather; raises on mismatch."""
     _, rank = world_rank()

@@ -304,7 +304,7 @@ class Engine:
         _lib.check(self.lib.vfx_profile_end(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "vfx_profile_end")
         return n.value, ms.value, fl.value
 
-    # ------------------------------------------------------------------ kernel-level ops (tests)
+    # ------------------------------------------------------------------ kernel-level ops (tests: libvfx_test.so, include/vfx_test.h)
     def op_conv(self, x, weight, scale=None, shift=None, act=0, slope=0.0, bias=None, residual=None, dil_w=1,
                 reflect_w=False):
         """x (B,H,W,Cin) channels-last; weight (Cout,Cin,kh,kw) torch layout (host)."""
@@ -317,7 +317,7 @@ class Engine:
         scale, shift, bias = hp(scale), hp(shift), hp(bias)
         cp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
         res = None if residual is None else _dev_f32(residual, self.device)
-        _lib.check(self.lib.vfx_op_conv(self.h, _ptr(x), B, H, W, Cin, cp(w), Cout, kh, kw, dil_w, int(reflect_w), cp(scale),
+        _lib.check(_lib.load_test().vfx_op_conv(self.h, _ptr(x), B, H, W, Cin, cp(w), Cout, kh, kw, dil_w, int(reflect_w), cp(scale),
                                         cp(shift), act, float(slope), cp(bias), _ptr(res), _ptr(y), self._stream()),
                    "vfx_op_conv")
         return y
@@ -330,7 +330,7 @@ class Engine:
         w1, b1, w2, b2 = hp(w1), hp(b1), hp(w2), hp(b2)
         cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         y = torch.empty_like(x)
-        _lib.check(self.lib.vfx_op_resblock(self.h, _ptr(x), B, T, C, cp(w1), cp(b1), cp(w2), cp(b2), int(dil), float(slope),
+        _lib.check(_lib.load_test().vfx_op_resblock(self.h, _ptr(x), B, T, C, cp(w1), cp(b1), cp(w2), cp(b2), int(dil), float(slope),
                                             int(bool(fused)), _ptr(y), self._stream()), "vfx_op_resblock")
         return y
 
@@ -342,7 +342,7 @@ class Engine:
         la, lb = [hp(a) for a in layer_a], [hp(a) for a in layer_b]
         cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         y = torch.empty_like(x)
-        _lib.check(self.lib.vfx_op_resblock_pair(self.h, _ptr(x), B, T, C, cp(la[0]), cp(la[1]), cp(la[2]), cp(la[3]), int(dil_a),
+        _lib.check(_lib.load_test().vfx_op_resblock_pair(self.h, _ptr(x), B, T, C, cp(la[0]), cp(la[1]), cp(la[2]), cp(la[3]), int(dil_a),
                                                  cp(lb[0]), cp(lb[1]), cp(lb[2]), cp(lb[3]), int(dil_b), float(slope), _ptr(y),
                                                  self._stream()), "vfx_op_resblock_pair")
         return y
@@ -356,7 +356,7 @@ class Engine:
         w1, sc1, sh1, w2, sc2, sh2 = hp(w1), hp(sc1), hp(sh1), hp(w2), hp(sc2), hp(sh2)
         cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         y = torch.empty_like(x)
-        _lib.check(self.lib.vfx_op_block2d(self.h, _ptr(x), B, H, W, C, cp(w1), cp(sc1), cp(sh1), cp(w2), cp(sc2), cp(sh2),
+        _lib.check(_lib.load_test().vfx_op_block2d(self.h, _ptr(x), B, H, W, C, cp(w1), cp(sc1), cp(sh1), cp(w2), cp(sc2), cp(sh2),
                                            float(slope), _ptr(y), self._stream()), "vfx_op_block2d")
         return y
 
@@ -373,7 +373,7 @@ class Engine:
         hp = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
         scale, shift, bias = hp(scale), hp(shift), hp(bias)
         cp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
-        _lib.check(self.lib.vfx_op_conv_transpose(self.h, _ptr(x), B, H, W, Cin, cp(w), Cout, kh, kw, stride, int(prune_w),
+        _lib.check(_lib.load_test().vfx_op_conv_transpose(self.h, _ptr(x), B, H, W, Cin, cp(w), Cout, kh, kw, stride, int(prune_w),
                                                   cp(scale), cp(shift), act, float(slope), cp(bias), _ptr(y), self._stream()),
                    "vfx_op_conv_transpose")
         return y
