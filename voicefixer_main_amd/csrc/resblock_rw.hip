@@ -421,7 +421,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
 }
 
 // h positions per tile of the register-weights kernel: 256; 0 = off (VFX_TUNE_NO_PERSISTENT_C64: k_resblock runs the layer)
-int resblock_rw_tile(int tuning) { return (tuning & VFX_TUNE_NO_PERSISTENT_C64) ? 0 : 256; }
+int resblock_rw_tile(int tuning) { return (tuning & VFX_TUNE_NO_PERSISTENT_C64) ? 0 : ((tuning & VFX_TUNE_C64_TILE128) ? 128 : 256); }
 
 // Two consecutive layers as one launch: 256-position tiles, the first layer's patch must fit (d <= 32) and a tile must still
 // advance by at least half of its positions (d2 <= 62).  VFX_TUNE_NO_PAIRS: one launch per layer.
@@ -471,6 +471,9 @@ void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams,
   } else if (hp.tile_m == 256) {
     if (hp.x16) launch_rw<8, false, true>(dparams, ntiles, stream);
     else launch_rw<8, false, false>(dparams, ntiles, stream);
+  } else if (hp.tile_m == 128) {
+    if (hp.x16) launch_rw<4, false, true>(dparams, ntiles, stream);
+    else launch_rw<4, false, false>(dparams, ntiles, stream);
   } else VFX_CHECK(false, "resblock_rw: tile of %d positions", hp.tile_m);
   VFX_HIP(hipGetLastError());
 }

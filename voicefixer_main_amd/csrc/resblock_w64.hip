@@ -349,7 +349,12 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   // barriers, sub-pass i + 3 as soon as sub-pass i has consumed its registers.  (Round 3, phase stamps: with the residual
   // requested ONE sub-pass ahead -- and the compiler moving that request behind the stores -- the epilogue was eight exposed
   // memory latencies: 32 k of a block's 91 k cycles.  A whole pass ahead (64 registers) spills beside the 128 accumulators.)
-  constexpr int NRB = 3;  // residual register sets: sub-pass i uses set i % NRB and then requests sub-pass i + NRB into it
+#ifndef VFX_W64_NRB
+#define VFX_W64_NRB 3
+#endif
+  // residual register sets: sub-pass i uses set i % NRB and then requests sub-pass i + NRB into it (X16: a set is 8 registers
+  // instead of 16; -DVFX_W64_NRB=4 = a whole pass ahead, measured in round 4: profiles/r04_*)
+  constexpr int NRB = X16 ? VFX_W64_NRB : 3;
   typedef typename std::conditional<X16, u32x2, u32x4>::type res_t;  // 4 channels: fp16 (8 bytes) or fp32 (16 bytes)
   res_t res[NRB][SUB];
   auto request_res = [&](int idx) __attribute__((always_inline)) {  // idx = pass * NSUB + sub-pass
