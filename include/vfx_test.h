@@ -44,7 +44,7 @@ int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int C, const fl
 
 /* Host-only (no GPU, no handle): the tile geometry the plan gives one fused ResStack layer -- or a layer pair, dil2 > 0 -- of
  * C channels over sequences of T positions in precision mode `precision`.  out[12] = fold, TH, W1, TWo, tiles_h, tiles_w, PW, P,
- * tile_m, rw, rl, asrc (ResBlockParams).  The CPU tests use it to check that the tiles cover every position exactly once. */
+ * tile_m, rw, patch_rows, asrc (ResBlockParams; the trunk form is the one the vocoder plan would use: fp16 unless VFX_TUNE_F32_TRUNK).  The CPU tests use it to check that the tiles cover every position exactly once. */
 int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int precision, int* out);
 /* ... for a handle configured with vfx_config.tuning = `tuning` (the function above is tuning = 0). */
 int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2, int precision, int tuning, int* out);

@@ -451,9 +451,11 @@ def test_resblock_tiles_cover_every_position_once(C, precision, tuning):
     for T in (3, 90, 1000, 49049, 70001):
         for d, d2 in cases:
             assert lib.vfx_plan_resblock_geometry_tuned(C, T, d, d2, precision, tuning, out) == 0, (T, d, d2)
-            fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, MT, rw, rl, asrc = list(out)
+            fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, MT, rw, patch_rows, asrc = list(out)
             MT = MT or 128
-            assert P <= MT + 64 and TH * W1 <= MT and TH >= 1
+            assert P <= (patch_rows or MT + 64) and TH * W1 <= MT and TH >= 1
+            if C == 64 and precision == 2 and tuning == 0 and d2 == 0 and d >= 243 and T > 8 * d:
+                assert patch_rows == 384 and TH * TWo >= 240, (d, T, TH, TWo)     # wide folded tiles on the fp16 trunk
             hits = np.zeros(T, dtype=np.int32)
             m = np.arange(MT)
             for ti in range(tiles_h):

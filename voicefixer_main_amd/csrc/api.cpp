@@ -411,6 +411,8 @@ void finish_params(TapConvParams& p) {
     VFX_CHECK((int64_t)p.B * p.in_img_stride * p.seg[s].C * 4 < ((int64_t)1 << 32) - 4096,
               "conv: source tensor of segment %d exceeds 4 GiB", s);
   VFX_CHECK(p.out || p.out_act, "conv: no output");
+  VFX_CHECK(!p.residual_act || (p.hionly && !p.residual && p.Cout % 4 == 0 && p.residual_inv_slope >= 1.f),
+            "conv: an activated residual needs the 16-bit mode, no raw residual beside it and an invertible LeakyReLU");
   plan_conv(p);
   p.nstages = count_stages(p);
 }
@@ -465,6 +467,7 @@ static double conv_algo_bytes(const TapConvParams& q) {
     for (int s2 = 0; s2 < q.nseg; ++s2) b += in_px * q.seg[s2].C * ((q.hionly && q.seg[s2].src_act) ? 2.0 : 4.0);
   }
   if (q.residual) b += out_px * q.Cout * 4.0;
+  if (q.residual_act) b += out_px * q.Cout * 2.0;
   if (q.out) b += out_px * q.Cout * 4.0;
   if (q.out_act) b += out_px * q.Cout * (q.hionly ? 2.0 : 4.0);
   return b;
@@ -636,6 +639,7 @@ void bind_plan(vfx_handle* h, Plan& plan) {
   for (auto& p : abs) {
     for (int s = 0; s < p.nseg; ++s) p.seg[s].src = rebase(p.seg[s].src);
     if (p.residual) p.residual = rebase(p.residual);
+    if (p.residual_act) p.residual_act = rebase(p.residual_act);
     if (p.out) p.out = const_cast<float*>(rebase(p.out));
     if (p.out_act) p.out_act = const_cast<float*>(rebase(p.out_act));
     if (p.ws) p.ws = const_cast<float*>(rebase(p.ws));
@@ -808,12 +812,12 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   h->device = device;
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
   VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
-  VFX_CHECK((h->cfg.tuning & ~255) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
+  VFX_CHECK((h->cfg.tuning & ~127) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
   if (h->cfg.tuning) {  // never silent: a non-default kernel selection is announced
     static const char* names[] = {"NO_FUSED_STACKS", "NO_FUSED_WIDE", "NO_FUSED_UNET", "NO_PERSISTENT_C64", "NO_PAIRS", "NO_SPLITK",
-                                  "F32_TRUNK", "C64_TILE128"};
+                                  "F32_TRUNK"};
     std::string msg;
-    for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < 7; ++b)
       if (h->cfg.tuning & (1 << b)) msg += std::string(msg.empty() ? "" : " | ") + "VFX_TUNE_" + names[b];
     fprintf(stderr, "[libvfx] handle on device %d uses non-default kernel selection: tuning = 0x%x (%s)\n", device, h->cfg.tuning,
             msg.c_str());

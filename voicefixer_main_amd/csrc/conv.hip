@@ -67,9 +67,11 @@ namespace vfx {
 // chunk, a tap is four K = 16 steps on four fp16 weight fragments (half the stages, barriers and DMA instructions of
 // the 32-channel form, and every fetched byte is an operand).  HI without H64: raw fp32 sources, 32-channel stages,
 // transformed in place to fp16 in the first half of the row, two K = 16 steps per tap.
-template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false>
+// RA (with H64): the launch's residual is an activated fp16 tensor, inverted in the epilogue (TapConvParams::residual_act).
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false>
 __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
   static_assert(!H64 || (HI && SPLIT), "H64 is a variant of the 16-bit mode");
+  static_assert(!RA || H64, "an activated residual exists in the 16-bit mode's activated-source launches only");
   constexpr bool HI32 = HI && !H64;  // the hi fragments (f[0], f[2]) only
   constexpr int WAVES_N = BN / 32;
   constexpr int WM = BN / 32;  // 32-row blocks per wave (= 4 / WAVES_M)
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     if (keep == 12345.678f) p.out_act[tid] = keep;  // keeps the accumulators live
   } else {
     float* partial = KS > 1 ? p.ws + (int64_t)ks * ((int64_t)p.B * p.out_img_stride * p.Cout) : nullptr;
-    conv_epilogue<BN, WM, 1, WAVES_N, SPLIT, EPI_HALVES>(p, smem, otab, acc, n0, partial);
+    conv_epilogue<BN, WM, 1, WAVES_N, SPLIT, EPI_HALVES, RA>(p, smem, otab, acc, n0, partial);
   }
 }
 
@@ -472,15 +474,15 @@ static size_t conv_lds_bytes(int BN, bool hi) {
   return main_bytes + CBM * 4;
 }
 
-template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false>
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false>
 static void launch_one(int grid, hipStream_t stream, const TapConvParams* dparams) {
   const size_t lds = conv_lds_bytes(BN, HI);
   static uint64_t attr_devices = 0;  // one static per instantiation
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64>),
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64, RA>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64>), dim3(grid), dim3(256), lds, stream, dparams);
+  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64, RA>), dim3(grid), dim3(256), lds, stream, dparams);
 }
 
 #ifdef VFX_ABLATION_BUILD
@@ -503,14 +505,14 @@ static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvP
 }
 #endif
 
-template <bool ELU, bool SPLIT, bool HI = false, bool H64 = false>
+template <bool ELU, bool SPLIT, bool HI = false, bool H64 = false, bool RA = false>
 static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams* dparams) {
   switch (BN) {
     // H64: a tap is four K = 16 steps (as long as two taps of the 32-channel form), so one tap of look-ahead covers the
     // same time with a third less ring registers (with three groups the BN = 128 tile spills at three waves per SIMD)
-    case 128: launch_one<128, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64>(grid, stream, dparams); break;
-    case 64: launch_one<64, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64>(grid, stream, dparams); break;
-    default: launch_one<32, ELU, SPLIT, 0, 2, HI, H64>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
+    case 128: launch_one<128, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA>(grid, stream, dparams); break;
+    case 64: launch_one<64, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA>(grid, stream, dparams); break;
+    default: launch_one<32, ELU, SPLIT, 0, 2, HI, H64, RA>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
   }
 }
 
@@ -547,9 +549,11 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
     int n_act = 0;
     for (int s = 0; s < hp.nseg; ++s) n_act += hp.seg[s].src_act ? 1 : 0;
     VFX_CHECK(n_act == 0 || n_act == hp.nseg, "conv: 16-bit launches cannot mix activated and raw sources");
+    VFX_CHECK(!hp.residual_act || n_act, "conv: an activated residual goes with activated sources");
     if (n_act) {
       VFX_CHECK(!elu, "conv: an activated source has no prologue");
-      launch_bn<false, true, true, true>(BN, (int)grid, stream, dparams);
+      if (hp.residual_act) launch_bn<false, true, true, true, true>(BN, (int)grid, stream, dparams);
+      else launch_bn<false, true, true, true>(BN, (int)grid, stream, dparams);
     } else if (elu) {
       launch_bn<true, true, true>(BN, (int)grid, stream, dparams);
     } else {

@@ -60,6 +60,25 @@ __device__ __forceinline__ unsigned pack_f16x2(float a, float b, unsigned& sat) 
 }
 __device__ __forceinline__ bool f16_sat_bits_bad(unsigned sat) { return sat > 0x477fe000u; }
 
+// h = LeakyReLU(t) as fp16 MFMA operands, cheaper (round 4: the h-write phase of the fused ResStack kernels was ~40 % VALU issue,
+// 14 instructions per pair of values): convert FIRST (saturating, 3 instructions per pair), then activate the packed halves
+// (v_pk_mul_f16 + v_pk_max_f16 per PAIR instead of v_mul + v_max per value), and keep the saturation record on the packed result:
+// `sat16` = per-half maximum of |h| as two u16 (v_and + v_pk_max_u16 per pair); a half that reached 0x7bff = 65504 was clamped
+// (or was exactly 65504 / a NaN: med3 sends a NaN to -65504) -- f16_sat16_bad().  8 instructions per pair with the mask select.
+// fp16(LeakyReLU(t)) and LeakyReLU16(fp16(t)) differ by one more rounding of the (100 x smaller) negative values only.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_f16x2_sat16(float a, float b, unsigned& sat16) {
+  const unsigned p = pack_f16x2(a, b);
+  const u16x2 m = __builtin_bit_cast(u16x2, p & 0x7fff7fffu);
+  sat16 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, sat16), m));
+  return p;
+}
+__device__ __forceinline__ bool f16_sat16_bad(unsigned s) { return (s & 0xffffu) >= 0x7bffu || (s >> 16) >= 0x7bffu; }
+__device__ __forceinline__ unsigned lrelu_f16x2(unsigned p, f16x2 slope2) {
+  const f16x2 h = __builtin_bit_cast(f16x2, p);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, h * slope2));
+}
+
 // One atomic per wave that saw a clamp (rare path).
 // The atomic goes through a GLOBAL-address-space pointer on purpose.  atomicOr on a generic `int*` is a flat_atomic_or, and
 // the compiler's wait-count insertion treats a FLAT operation as one that may complete out of order on vmcnt AND lgkmcnt:

@@ -27,7 +27,7 @@ typedef __bf16 ce_bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 ce_f16x2 __attribute__((ext_vector_type(2)));
 #define VFX_CE_GLOBAL __attribute__((address_space(1)))
 
-template <int BN, int WM, int WN, int WAVES_N, bool SPLIT, int HALVES = 1>
+template <int BN, int WM, int WN, int WAVES_N, bool SPLIT, int HALVES = 1, bool RESACT = false>
 __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* smem, const int* otab,
                                               ce_f32x16 (&acc)[WM][WN], int n0, float* partial = nullptr) {
   // partial != nullptr (split-K): the raw accumulators go to that slice of the workspace, nothing else happens here
@@ -82,7 +82,29 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
         if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(partial + (int64_t)opix[q] * Cout + ncol) = val[q];
       continue;
     }
-    if (p.residual) {
+    if constexpr (RESACT) {
+      // 16-bit mode on the fp16 trunk: the residual comes as the ACTIVATED fp16 form of it (TapConvParams::residual_act, 8 bytes
+      // per lane and row); the raw value is recovered as min(v, v / slope).  A compile-time variant: both residual forms in one
+      // body spill in the 168-register BN = 128 tile.  The four halves are bit-cast as a whole vector (hipcc 7.2 miscompiles
+      // __builtin_bit_cast of a vector ELEMENT: conv_common.h).
+      typedef unsigned ce_u32x2 __attribute__((ext_vector_type(2)));
+      typedef _Float16 ce_f16x4 __attribute__((ext_vector_type(4)));
+      const float inv = p.residual_inv_slope;
+      ce_u32x2 rh[NPASS];
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q)
+        rh[q] = *(const VFX_CE_GLOBAL ce_u32x2*)(reinterpret_cast<const _Float16*>(p.residual_act) +
+                                                (int64_t)(opix[q] < 0 ? 0 : opix[q]) * Cout + ncol);
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+        const ce_f16x4 h = __builtin_bit_cast(ce_f16x4, rh[q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (float)h[e];
+          val[q][e] += __builtin_fminf(v, v * inv);
+        }
+      }
+    } else if (p.residual) {
       ce_f32x4 res[NPASS];
 #pragma unroll
       for (int q = 0; q < NPASS; ++q)

@@ -292,7 +292,7 @@ extern "C" int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int 
 // Host-only: the tile geometry plan_resblock() gives one fused ResStack layer (or layer pair, dil2 > 0) of `C` channels over
 // sequences of `T` positions in precision mode `precision` -- so that the CPU test suite can check that the tiles of every
 // kernel family (1-D, folded, pairs; 128- and 256-position tiles) write each output position exactly once.
-// out[12] = fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, tile_m, rw, 0, asrc.  Needs no GPU and no handle.
+// out[12] = fold, TH, W1, TWo, tiles_h, tiles_w, PW, P, tile_m, rw, patch_rows, asrc.  Needs no GPU and no handle.
 extern "C" int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2, int precision, int tuning, int* out);
 extern "C" int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int precision, int* out) {
   return vfx_plan_resblock_geometry_tuned(C, T, dil, dil2, precision, 0, out);
@@ -310,8 +310,10 @@ extern "C" int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2,
     rp.hionly = precision == 2;
     rp.tuning = tuning;
     if (precision == 2 && resblock_w64_supported(C)) rp.asrc = 1;
+    // the trunk form the vocoder plan would give this layer (vocoder.cpp stack_trunk_f16)
+    rp.x16 = (precision == 2 && !(tuning & VFX_TUNE_F32_TRUNK) && (C == 256 || C == 128 || (C == 64 && resblock_rw_tile(tuning) != 0))) ? 1 : 0;
     plan_resblock(rp);
-    const int v[12] = {rp.fold, rp.TH, rp.W1, rp.TWo, rp.tiles_h, rp.tiles_w, rp.PW, rp.P, rp.tile_m, rp.rw, 0, rp.asrc};
+    const int v[12] = {rp.fold, rp.TH, rp.W1, rp.TWo, rp.tiles_h, rp.tiles_w, rp.PW, rp.P, rp.tile_m, rp.rw, rp.patch_rows, rp.asrc};
     for (int i = 0; i < 12; ++i) out[i] = v[i];
   } catch (const vfx::Error&) {
     return 1;

@@ -627,21 +627,37 @@ void plan_resblock(ResBlockParams& p) {
     // tile width: the widest (<= 16) that cuts a row of d samples into equal parts -- d = 81 as 6 x 16 wastes 15 of 96 columns
     // (the d = 81 layers ran 15 % longer than the other folded ones), as 6 x 14 it wastes 3; the h tile is 16 x 16 instead of 14 x 18
     // (160-row patches: 14-wide tiles at most -- the h tile is then 8 x 16 = all 128 positions; 16-wide tiles would be 6 x 18)
-    const int twmax = p.patch_rows ? 14 : 16;
-    const int nparts = (d + twmax - 1) / twmax;
-    const int TW = d >= twmax ? (d + nparts - 1) / nparts : d;
-    p.W1 = TW + 2;
     const int rows = (p.T + d - 1) / d;
-    const int th_max = std::min(MT / p.W1, PR / p.W1 - 2);
-    p.tiles_h = (rows + th_max - 1) / th_max;
-    p.TH = (rows + p.tiles_h - 1) / p.tiles_h;  // equal parts here too: 23 rows are 4 x 6, not 4 x 7
-    p.TWo = TW;
-    p.tiles_w = (d + TW - 1) / TW;
-    p.PW = p.W1;
-    p.P = (p.TH + 2) * p.W1;
-    for (int k = 0; k < 3; ++k) p.poff[k] = k * p.W1;
+    auto geometry = [&](int twmax, int pr, ResBlockParams& q) -> int64_t {  // fills q, returns the tiles per sequence
+      const int nparts = (d + twmax - 1) / twmax;
+      const int TW = d >= twmax ? (d + nparts - 1) / nparts : d;
+      q.W1 = TW + 2;
+      const int th_max = std::min(MT / q.W1, pr / q.W1 - 2);
+      if (th_max < 1) return (int64_t)1 << 60;
+      q.tiles_h = (rows + th_max - 1) / th_max;
+      q.TH = (rows + q.tiles_h - 1) / q.tiles_h;  // equal parts here too: 23 rows are 4 x 6, not 4 x 7
+      q.TWo = TW;
+      q.tiles_w = (d + TW - 1) / TW;
+      q.PW = q.W1;
+      q.P = (q.TH + 2) * q.W1;
+      for (int k = 0; k < 3; ++k) q.poff[k] = k * q.W1;
+      return (int64_t)q.tiles_h * q.tiles_w;
+    };
+    int64_t tiles = geometry(p.patch_rows ? 14 : 16, PR, p);
+    if (p.rw && p.x16 && MT == 256) {
+      // persistent C = 64 kernel on the fp16 trunk: tiles up to 62 wide on a (MT + 128)-row patch (resblock_rw.hip, HALO = 128)
+      // where they need fewer tiles -- d = 243 .. 2187: 4 x 63 h tiles with 244 outputs instead of 14 x 18 with 224
+      ResBlockParams q = p;
+      const int64_t wide = geometry(62, MT + 128, q);
+      if (wide < tiles) {
+        q.patch_rows = MT + 128;
+        p = q;
+        tiles = wide;
+      }
+    }
   }
-  VFX_CHECK(p.P <= PR && p.TH * p.W1 <= MT && p.TH >= 1, "resblock: bad tile geometry (dil=%d)", d);
+  const int PRc = p.patch_rows ? p.patch_rows : MT + 64;  // (the wide folded tiles of resblock_rw enlarge the patch)
+  VFX_CHECK(p.P <= PRc && p.TH * p.W1 <= MT && p.TH >= 1, "resblock: bad tile geometry (dil=%d)", d);
   p.inv_pw = ((1u << 20) + p.PW - 1) / p.PW;
   p.inv_w1 = ((1u << 20) + p.W1 - 1) / p.W1;
   const int64_t tpi = (int64_t)p.tiles_w * p.tiles_h;

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   // Lane (l31, lh) of position block a holds h pixel m = 64 wm + 32 a + l31 and, in registers 4j .. 4j+3 of cout block n, channels
   // (2 wn + n) * 32 + 8j + 4lh .. +3: chunk 2 wn + n of the pixel's row, piece j, half lh.
   auto write_h = [&](const float* bias, const bool (&valid)[WM]) __attribute__((always_inline)) {
-    unsigned f16_sat = 0;
+    unsigned sat16 = 0;
+    const f16x2 slope2 = {(_Float16)slope, (_Float16)slope};
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
       const int ch = 2 * wn + n;
@@ -318,18 +319,16 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         const int key = (m >> 1) & 7;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x4 u;
+          // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
+          const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[n][a][4 * j] + b1v[j][0], acc[n][a][4 * j + 1] + b1v[j][1], sat16), slope2);
+          const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[n][a][4 * j + 2] + b1v[j][2], acc[n][a][4 * j + 3] + b1v[j][3], sat16), slope2);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = acc[n][a][4 * j + e] + b1v[j][e];
-            u[e] = valid[a] ? fmaxf(t, t * slope) : 0.f;
-            acc[n][a][4 * j + e] = 0.f;
-          }
-          *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1], f16_sat), pack_f16x2(u[2], u[3], f16_sat));
+          for (int e = 0; e < 4; ++e) acc[n][a][4 * j + e] = 0.f;
+          *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(valid[a] ? h01 : 0u, valid[a] ? h23 : 0u);
         }
       }
     }
-    report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
+    report_f16_saturation(f16_sat16_bad(sat16), p.flags);
   };
   // the accumulators of a conv2 staged in LDS as whole rows
   auto stage_acc = [&]() __attribute__((always_inline)) {

@@ -44,16 +44,21 @@
 
 namespace vfx {
 
-template <int NW, bool PAIR, bool X16>
+// HALO: patch rows beyond the tile's MT positions (PR = MT + HALO).  64 = the round-2 geometry; 128 (fp16 trunk, folded layers
+// only): folded tiles as TH x (TW + 2) with TW up to 62 -- a 4 x 63 h tile gives 4 x 61 = 244 outputs of 256 positions where
+// 14 x 18 (16-wide tiles) gave 224; its patch is 6 x 63 = 378 rows.  One block per CU owns 160 KB of LDS, the larger patch
+// region is free; the two extra row pieces per thread are 4 registers on the fp16 trunk (8 on the fp32 one: over 256).
+template <int NW, bool PAIR, bool X16, int HALO = 64>
 __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams* __restrict__ pp, int ntiles, int per_block) {
   constexpr int C = 64;
   constexpr int NTHR = NW * 64;
   constexpr int WM = 2;                     // 32-row MFMA blocks per wave: wave = 64 positions x 32 channels
   constexpr int MT = NW * 32;               // h positions per tile
-  constexpr int PR = MT + 64;               // patch rows (plan_resblock)
+  constexpr int PR = MT + HALO;             // patch rows (plan_resblock)
   constexpr int RQ = NTHR / 16;             // rows per load group: 16 lanes x 16 bytes = one 256-byte row of raw x
   constexpr int NCQ = MT / RQ;              // centre loads per thread (8)
-  constexpr int NHQ = 64 / RQ;              // halo loads per thread (2 or 4)
+  constexpr int NHQ = HALO / RQ;            // halo loads per thread (2 or 4)
+  static_assert(HALO == 64 || (HALO == 128 && X16 && !PAIR), "the wide patch exists for single layers on the fp16 trunk");
   constexpr int ROWB = 128;                 // bytes per LDS row: 64 channels of fp16
   constexpr int R0 = 0, R1 = PR * ROWB;     // the two operand regions: R0 = PR rows, R1 = MT rows
   constexpr int LDO = C + 4;                // staged output row (floats)
@@ -245,7 +250,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       }
     // h = LeakyReLU(conv1 + b1) as fp16 operands, zero outside the sequence
     {
-      unsigned sat = 0;
+      unsigned sat16 = 0;
+      const f16x2 slope2 = {(_Float16)slope, (_Float16)slope};
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
         const int m = (wm * WM + a) * 32 + l31_v;
@@ -254,18 +260,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         const int key = (m >> 1) & 7;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x4 u;
           const f32x4 b1v = *reinterpret_cast<const f32x4*>(bias1 + wn * 32 + 8 * j + 4 * lh);
+          // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
+          const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j] + b1v[0], acc[a][4 * j + 1] + b1v[1], sat16), slope2);
+          const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j + 2] + b1v[2], acc[a][4 * j + 3] + b1v[3], sat16), slope2);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float tt = acc[a][4 * j + e] + b1v[e];
-            u[e] = hval ? fmaxf(tt, tt * slope) : 0.f;
-            acc[a][4 * j + e] = 0.f;
-          }
-          *reinterpret_cast<uint2*>(rowp + (((wn * 4 + j) ^ key) << 4)) = make_uint2(pack_f16x2(u[0], u[1], sat), pack_f16x2(u[2], u[3], sat));
+          for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = 0.f;
+          *reinterpret_cast<uint2*>(rowp + (((wn * 4 + j) ^ key) << 4)) = make_uint2(hval ? h01 : 0u, hval ? h23 : 0u);
         }
       }
-      report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
+      report_f16_saturation(f16_sat16_bad(sat16), p.flags);
     }
     __syncthreads();  // h is complete
     // conv2 from the resident h
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
 }
 
 // h positions per tile of the register-weights kernel: 256; 0 = off (VFX_TUNE_NO_PERSISTENT_C64: k_resblock runs the layer)
-int resblock_rw_tile(int tuning) { return (tuning & VFX_TUNE_NO_PERSISTENT_C64) ? 0 : ((tuning & VFX_TUNE_C64_TILE128) ? 128 : 256); }
+int resblock_rw_tile(int tuning) { return (tuning & VFX_TUNE_NO_PERSISTENT_C64) ? 0 : 256; }
 
 // Two consecutive layers as one launch: 256-position tiles, the first layer's patch must fit (d <= 32) and a tile must still
 // advance by at least half of its positions (d2 <= 62).  VFX_TUNE_NO_PAIRS: one launch per layer.
@@ -443,19 +447,19 @@ int cu_count_of_current_device() {
   return cus[dev];
 }
 
-template <int NW, bool PAIR, bool X16>
+template <int NW, bool PAIR, bool X16, int HALO = 64>
 static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {
   constexpr int MT = NW * 32;
   // the two operand regions (the staged accumulators overlay them) + biases; pairs: + three sets of weight fragments
-  const size_t lds = (size_t)(MT + 64 + MT) * 128 + (PAIR ? (size_t)72 * 1024 + 4 * 64 * sizeof(float) : 64 * sizeof(float));
+  const size_t lds = (size_t)(MT + HALO + MT) * 128 + (PAIR ? (size_t)72 * 1024 + 4 * 64 * sizeof(float) : 64 * sizeof(float));
   const int slots = cu_count_of_current_device() * (NW == 4 ? 2 : 1);  // 256 registers per wave: 8 waves per CU
   const int per_block = (int)((ntiles + slots - 1) / slots);
   const int grid = (int)((ntiles + per_block - 1) / per_block);
   static uint64_t attr_devices = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_rw<NW, PAIR, X16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_rw<NW, PAIR, X16, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_resblock_rw<NW, PAIR, X16>), dim3(grid), dim3(NW * 64), lds, stream, dparams, (int)ntiles, per_block);
+  hipLaunchKernelGGL((k_resblock_rw<NW, PAIR, X16, HALO>), dim3(grid), dim3(NW * 64), lds, stream, dparams, (int)ntiles, per_block);
 }
 
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
@@ -469,11 +473,10 @@ void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams,
     if (hp.x16) launch_rw<8, true, true>(dparams, ntiles, stream);
     else launch_rw<8, true, false>(dparams, ntiles, stream);
   } else if (hp.tile_m == 256) {
-    if (hp.x16) launch_rw<8, false, true>(dparams, ntiles, stream);
+    VFX_CHECK(hp.patch_rows == 0 || (hp.patch_rows == 256 + 128 && hp.x16 && hp.fold), "resblock_rw: bad patch geometry");
+    if (hp.x16 && hp.patch_rows) launch_rw<8, false, true, 128>(dparams, ntiles, stream);
+    else if (hp.x16) launch_rw<8, false, true>(dparams, ntiles, stream);
     else launch_rw<8, false, false>(dparams, ntiles, stream);
-  } else if (hp.tile_m == 128) {
-    if (hp.x16) launch_rw<4, false, true>(dparams, ntiles, stream);
-    else launch_rw<4, false, false>(dparams, ntiles, stream);
   } else VFX_CHECK(false, "resblock_rw: tile of %d positions", hp.tile_m);
   VFX_HIP(hipGetLastError());
 }

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   // Lane (l31, lh) of position block a holds h pixel m = a*32 + l31 and, in registers 4j .. 4j+3 of cout block cb, channels
   // (2w + cb)*32 + 8j + 4lh .. +3: chunk w of the pixel's row, piece cb*4 + j, half lh.
   {
-    unsigned f16_sat = 0;
+    unsigned sat16 = 0;
+    const f16x2 slope2 = {(_Float16)slope, (_Float16)slope};
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       f32x4 b1v[4];
@@ -291,19 +292,16 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
         const int key = (m >> 1) & 7;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x4 u;
+          // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
+          unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[cb][a][4 * j] + b1v[j][0], acc[cb][a][4 * j + 1] + b1v[j][1], sat16), slope2);
+          unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[cb][a][4 * j + 2] + b1v[j][2], acc[cb][a][4 * j + 3] + b1v[j][3], sat16), slope2);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = acc[cb][a][4 * j + e] + b1v[j][e];
-            u[e] = hval[a] ? fmaxf(t, t * slope) : 0.f;
-            acc[cb][a][4 * j + e] = 0.f;
-          }
-          *reinterpret_cast<uint2*>(rowp + (((cb * 4 + j) ^ key) << 4)) =
-              make_uint2(pack_f16x2(u[0], u[1], f16_sat), pack_f16x2(u[2], u[3], f16_sat));
+          for (int e = 0; e < 4; ++e) acc[cb][a][4 * j + e] = 0.f;
+          *reinterpret_cast<uint2*>(rowp + (((cb * 4 + j) ^ key) << 4)) = make_uint2(hval[a] ? h01 : 0u, hval[a] ? h23 : 0u);
         }
       }
     }
-    report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
+    report_f16_saturation(f16_sat16_bad(sat16), p.flags);
   }
   VFX_TS(7);
   __syncthreads();  // h is complete

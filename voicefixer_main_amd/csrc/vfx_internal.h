@@ -148,6 +148,11 @@ struct TapConvParams {
   double flops_override;  // algorithmic flops when they are not 2 * M * Cout * K (phased launches)
   const float* bias;     // [Cout] or nullptr
   const float* residual; // (B, Ho, Wo, Cout) or nullptr, added in the epilogue
+  // 16-bit mode, fp16 trunk (round 4): the residual as the ACTIVATED fp16 tensor fp16(LeakyReLU(r, slope)) that the launch's
+  // producer chain already stores for a convolution -- the raw value is recovered as min(v, v * residual_inv_slope) (LeakyReLU
+  // with a positive slope is invertible; cf. ResBlockParams::x16), so a two-launch ResStack layer keeps NO raw tensor at all.
+  const float* residual_act;
+  float residual_inv_slope;
   float* out;            // raw fp32 output (B, Ho, Wo, Cout) or nullptr
   // Optional ACTIVATED output for a tensor whose only consumer is the next convolution: the epilogue
   // applies that consumer's prologue (per-channel affine, LeakyReLU / ELU) once per element and stores

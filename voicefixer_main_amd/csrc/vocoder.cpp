@@ -58,7 +58,9 @@ bool stack_trunk_f16(const vfx_config& cfg, int channels, bool last_stage) {
   if (cfg.precision != 2 || (cfg.tuning & VFX_TUNE_F32_TRUNK)) return false;
   if (cfg.voc_res_slope <= 0.f || cfg.voc_res_slope > 1.f) return false;  // packed max(x, slope x); the wide layer inverts the LeakyReLU
   if (stack_fused_wide(cfg, channels)) return !last_stage;
-  if (!stack_fused(cfg, channels)) return false;
+  // two k_conv launches per layer (C = 512; every stack under VFX_TUNE_NO_FUSED_*): the activated fp16 tensor alone, conv2
+  // recovers its residual from it (TapConvParams::residual_act) -- 10 instead of 16 bytes per element and layer
+  if (!stack_fused(cfg, channels)) return !last_stage && channels % 64 == 0;
   return channels == 128 || (channels == 64 && resblock_rw_tile(cfg.tuning) != 0);
 }
 
@@ -197,15 +199,22 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
   };
   // Conv1d src -> (raw and / or activated) output.  `src_act`: src is the activated form (no prologue here);
   // `next_act` != ACT_NONE: also / only store the output activated for its consumer.
+  // `residual_act`: *residual is the ACTIVATED fp16 form of the residual (LeakyReLU(res_slope)), inverted in the epilogue
   auto conv1d = [&](const VocConvW& cw, size_t src, int Tlen, int K, int dil, int act, float slope, bool reflect,
-                    const size_t* residual, bool src_act, bool want_raw, int next_act, float next_slope) -> Forms {
+                    const size_t* residual, bool src_act, bool want_raw, int next_act, float next_slope,
+                    bool residual_act = false) -> Forms {
     Forms out;
     TapConvParams p{};
     set_conv1d_geometry(p, B, Tlen, K, dil, reflect);
     p.hionly = cfg.precision == 2;
     p.Cout = cw.cout;
     p.bias = cw.bias;
-    p.residual = residual ? rel_ptr(*residual) : nullptr;
+    if (residual && residual_act) {
+      p.residual_act = rel_ptr(*residual);
+      p.residual_inv_slope = 1.f / cfg.voc_res_slope;
+    } else {
+      p.residual = residual ? rel_ptr(*residual) : nullptr;
+    }
     p.act_slope = 1.f;
     VFX_CHECK(cw.mode == pack_mode(cfg, src_act), "vocoder plan: weights of a %d -> %d convolution are packed for another source form", cw.cin, cw.cout);
     if (want_raw) {
@@ -410,10 +419,12 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         const bool last_layer = li + 1 == nlayers;
         const Forms hbuf = conv1d(layer.first, cur.act, Tlen, 3, dil, ACT_LEAKY, cfg.voc_res_slope, false, nullptr,
                                   /*src_act=*/true, /*want_raw=*/false, ACT_LEAKY, cfg.voc_res_slope);
-        const bool want_raw = !last_layer || last_stage;
+        // fp16 trunk (t16): no raw tensor in the stack -- conv2's residual is the activated trunk itself, inverted
+        const bool want_raw = !t16 && (!last_layer || last_stage);
         const int next_act = last_layer && last_stage ? ACT_NONE : ACT_LEAKY;
-        const Forms y2 = conv1d(layer.second, hbuf.act, Tlen, 3, 1, ACT_LEAKY, cfg.voc_res_slope, false, &cur.raw,
-                                /*src_act=*/true, want_raw, next_act, last_layer ? cfg.voc_up_slope : cfg.voc_res_slope);
+        const Forms y2 = conv1d(layer.second, hbuf.act, Tlen, 3, 1, ACT_LEAKY, cfg.voc_res_slope, false, t16 ? &cur.act : &cur.raw,
+                                /*src_act=*/true, want_raw, next_act, last_layer ? cfg.voc_up_slope : cfg.voc_res_slope,
+                                /*residual_act=*/t16);
         free_forms(hbuf);
         free_forms(cur);
         cur = y2;
