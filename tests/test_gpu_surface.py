@@ -90,7 +90,8 @@ def test_ssr_unet_vs_reference_golden_batch_of_two(engine):
     """The spectrogram path against the REFERENCE module's own output on B = 2 full-band clips of T = 130 frames (Tpad = 192,
     unaligned length; tests/golden/unet_spec_b2.npz).  On full-band input the comparison is not limited by the phase of empty
     bins (two fp32 evaluations agree to > 90 dB, tests/test_oracle_golden.py), so these bars are accuracy statements for the
-    kernels: >= 70 dB with split-bf16 operands, >= 85 dB in the exact-fp32 mode."""
+    kernels: >= 88 dB with split-bf16 operands, >= 105 dB in the exact-fp32 mode (measured on MI355X: 95.2 / 110.8-113.1 dB,
+    profiles/r04_ssr_golden_b2.txt)."""
     from voicefixer_main_amd import synth
     from voicefixer_main_amd.models import SSR_UNet
     g = np.load(os.path.join(G, "unet_spec_b2.npz"))
@@ -107,7 +108,7 @@ def test_ssr_unet_vs_reference_golden_batch_of_two(engine):
         os.makedirs("gpurun_out", exist_ok=True)
         with open("gpurun_out/ssr_golden_b2.txt", "a") as f:
             f.write("%s clip %d: %.2f dB\n" % (engine.tol['name'], b, s))
-        assert s > (85.0 if engine.tol['name'] == 'fp32' else 70.0), (b, s)
+        assert s > (105.0 if engine.tol['name'] == 'fp32' else 88.0), (b, s)
     tail = ref.shape[1] % 441
     rel = np.abs(got[:, -tail:] - ref[:, -tail:]).max() / np.abs(ref[:, -tail:]).max()
     assert rel < (1e-4 if engine.tol['name'] == 'fp32' else 1e-3), rel
