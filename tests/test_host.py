@@ -364,7 +364,9 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
     import re
     # kernels that are allowed a few bytes of scratch: opt-in experiments and the opt-in 64-position form of the C = 256 layer
     # (and k_conv<64, ELU, split, ring 3>: 8 bytes since round 1, split-bf16 mode of the vocoder's ELU convolutions only)
-    may_spill = ("k_convILi64ELb1ELb1ELi0ELi3ELb0ELb0E",)
+    # k_conv<256, H64> (round 4): 16 bytes -- four values that live across the tap loop (epilogue constants) are parked before it
+    # and fetched back behind it, nothing inside the loop; k_conv<128, ELU, HI32>: the ELU prologue exists for vfx_op_conv (tests) only
+    may_spill = ("k_convILi64ELb1ELb1ELi0ELi3ELb0ELb0E", "k_convILi256ELb0ELb1ELi0ELi2ELb1ELb1E", "k_convILi128ELb1ELb1ELi0ELi3ELb1ELb0E")
     for name in ("conv.hip", "resblock.hip", "resblock_w64.hip", "resblock_r128.hip", "resblock_rw.hip", "stft.hip", "small_ops.hip"):
         out = str(tmp_path / (name + ".s"))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
@@ -380,6 +382,8 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
             kernel, scratch = m.group(1), int(m.group(2))
             if not any(k in kernel for k in may_spill):
                 assert scratch == 0, (name, kernel, scratch)
+            else:
+                assert scratch <= 16, (name, kernel, scratch)
         # no FLAT memory instruction anywhere: the compiler's wait-count insertion answers one with lgkmcnt(0) / vmcnt(0) on every later
         # wait, which un-pipelines the fragment reads of kernels whose vmcnt waits are hand-counted asm (conv_common.h: or_flag_global)
         assert not re.search(r"\n\s*flat_(load|store|atomic)", asm), name

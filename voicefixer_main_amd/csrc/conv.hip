@@ -17,6 +17,9 @@
 // Work decomposition
 //   block   = 4 waves, tile = TH x TW (<= 128) pixels of ONE image x BN in {128, 64, 32} couts;
 //   wave    = (128 / WAVES_M) pixels x 32 couts, WAVES_N = BN / 32;
+//   BN = 256 (round 4; 16-bit launches on activated fp16 sources only): wave = 128 pixels x 64 couts -- a pixel fragment read
+//             from LDS feeds TWO MFMAs (0.5 KB of LDS per MFMA instead of 1 KB: the BN = 128 tile takes a fragment per MFMA,
+//             128 B/clk/CU at full MFMA rate = all the LDS delivers; resblock_w64.hip gained 15 % from the same change);
 //   stage   = one 32-channel chunk of one source tensor and the taps that read it.  The host
 //             flattens every launch into a table of stages (ConvStage, vfx_internal.h).
 //
@@ -69,15 +72,17 @@ namespace vfx {
 // transformed in place to fp16 in the first half of the row, two K = 16 steps per tap.
 // RA (with H64): the launch's residual is an activated fp16 tensor, inverted in the epilogue (TapConvParams::residual_act).
 template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false>
-__global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
+__global__ __launch_bounds__(256, BN == 256 ? 2 : ((BN <= 64 || HI) ? 3 : 2)) void k_conv(const TapConvParams* __restrict__ pp) {
   static_assert(!H64 || (HI && SPLIT), "H64 is a variant of the 16-bit mode");
   static_assert(!RA || H64, "an activated residual exists in the 16-bit mode's activated-source launches only");
+  static_assert(BN != 256 || (H64 && !ELU && RING == 2 && ABL == 0), "the 64-cout wave tile exists for activated fp16 sources");
   constexpr bool HI32 = HI && !H64;  // the hi fragments (f[0], f[2]) only
-  constexpr int WAVES_N = BN / 32;
-  constexpr int WM = BN / 32;  // 32-row blocks per wave (= 4 / WAVES_M)
+  constexpr int WNB = BN == 256 ? 2 : 1;      // 32-cout blocks per wave
+  constexpr int WAVES_N = BN / (32 * WNB);
+  constexpr int WM = WAVES_N;                 // 32-row blocks per wave (= 4 / WAVES_M, WAVES_M = 4 / WAVES_N)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int EPI_HALVES = (BN == 128 && HI) ? 2 : 1;  // 16-bit BN = 128 tile: half-width epilogue staging -> three blocks per CU
+  constexpr int EPI_HALVES = (BN >= 128 && HI) ? 2 : 1;  // 16-bit BN = 128 tile: half-width epilogue staging -> three blocks per CU (BN = 256: two)
   constexpr int kEpiBytes = CBM * (BN / EPI_HALVES + 4) * 4;
   constexpr int kMainBytes = (2 * CPATCH > kEpiBytes) ? 2 * CPATCH : kEpiBytes;
   char* const lds = reinterpret_cast<char*>(smem);
@@ -152,11 +157,13 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     otab[tid] = idx;
   }
 
-  f32x16 acc[WM][1];
+  f32x16 acc[WM][WNB];
 #pragma unroll
   for (int a = 0; a < WM; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
+    for (int b = 0; b < WNB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int lane = tid & 63;
   const int wm = wave_u / WAVES_N, wn = wave_u % WAVES_N;
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     arow[a] = li < TH ? li * PW + lj : 0;
     ak0[a] = li < TH ? (((lj >> 1) + hTW * li) | ((lj & 1) << 16)) : 0;
   }
-  const unsigned nb_off = (unsigned)(((n0w >> 5) + wn) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block
+  const unsigned nb_off = (unsigned)(((n0w >> 5) + wn * WNB) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block (BN = 256: the wave's second cout block is 4096 bytes further)
 
   // ---- patch (A) staging ------------------------------------------------------------------------
   // The byte offset of every patch pixel is kept in registers and only recomputed when the patch
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     if (dh != o_dh || dw != o_dw || C != o_C) set_origin(dh, dw, C);  // uniform; VALU only
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((const float*)S.src), 0, (int)S.nbytes, 0x00020000);
-    praw = (S.flags & 1) == 0;
+    praw = BN == 256 ? false : (S.flags & 1) == 0;  // (the 256-cout tile is launched on activated sources only: no transform code)
 #pragma unroll
     for (int q = 0; q < CNQ; ++q) {
       // the lane's bytes always land in slot cg: an activated source is fetched pre-swizzled (piece cg ^ key)
@@ -274,7 +281,8 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   };
 
   // `tap` = ConvStage::poff entry: patch row offset of the tap in bits 0..15, its column shift in 16..23, row shift in 24..31
-  auto compute = [&](const BFrag& R, int src, int tap) __attribute__((always_inline)) {
+  auto compute = [&](const BGroup<WNB>& RG, int src, int tap) __attribute__((always_inline)) {
+    const BFrag& R = RG.f[0];
     const char* base[WM];
     int key[WM];
     const int toff = tap & 0xffff, dpj = (tap >> 16) & 0xff, kdi = hTW * (tap >> 24);
@@ -291,12 +299,15 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       // f[0], f[2]; 64-channel stages (H64): pieces 0..7, fragments f[0..3] = k 0..15, 16..31, 32..47, 48..63
 #pragma unroll
       for (int s = 0; s < (H64 ? 4 : 2); ++s) {
-        const f16x8 bh = __builtin_bit_cast(f16x8, R.f[H64 ? s : 2 * s]);
         f16x8 ah[WM];
 #pragma unroll
         for (int a = 0; a < WM; ++a) ah[a] = *reinterpret_cast<const f16x8*>(base[a] + ((32 * s + 16 * lh) ^ key[a]));
 #pragma unroll
-        for (int a = 0; a < WM; ++a) acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah[a], acc[a][0], 0, 0, 0);
+        for (int b = 0; b < WNB; ++b) {
+          const f16x8 bh = __builtin_bit_cast(f16x8, RG.f[b].f[H64 ? s : 2 * s]);
+#pragma unroll
+          for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah[a], acc[a][b], 0, 0, 0);
+        }
       }
     } else if constexpr (SPLIT) {
 #pragma unroll
@@ -357,8 +368,8 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   //                 stage's end;
   //   t == NT-1     everything in flight (next taps' weights, the patch) lands before the transform / barrier.
   constexpr int AHEAD = RING - 1;
-  constexpr int WL = HI32 ? 2 : 4;  // weight loads per tap and wave
-  BFrag R0 = {}, R1 = {}, R2 = {};
+  constexpr int WL = (HI32 ? 2 : 4) * WNB;  // weight loads per tap and wave
+  BGroup<WNB> R0 = {}, R1 = {}, R2 = {};
   const int nstages = st_hi - st_lo;  // stages of this block
   const int last = nstages - 1;
   // Cursor state lives in scalar registers; table fields are re-read only when a cursor enters a new stage, and the
@@ -370,12 +381,13 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   int fnt = stages[0].ntaps;               // (clamped to the last stage: refetched, never consumed)
   int64_t fstride = stages[0].tap_stride;
   const float* fw = (const float*)stages[0].wt;
-  auto fetch = [&](BFrag& R) __attribute__((always_inline)) {
+  auto fetch = [&](BGroup<WNB>& R) __attribute__((always_inline)) {
     if constexpr (ABL & 2) {
     } else if constexpr (HI32) {
-      load_b_asm_hi(R, fw, nb_off);
+      load_b_asm_hi(R.f[0], fw, nb_off);
     } else {
-      load_b_asm(R, fw, nb_off);
+      load_b_asm(R.f[0], fw, nb_off);
+      if constexpr (WNB == 2) load_b_asm(R.f[1], fw, nb_off + 4096u);
     }
     if (++ft >= fnt) {
       ft = 0;
@@ -388,7 +400,15 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       fw += fstride;
     }
   };
-  auto step = [&](BFrag& cur_r, BFrag& fetch_r) __attribute__((always_inline)) {
+  auto use_group = [&](BGroup<WNB>& R) __attribute__((always_inline)) {
+    if constexpr (HI32) {
+      use_b_hi(R.f[0]);
+    } else {
+      use_b(R.f[0]);
+      if constexpr (WNB == 2) use_b(R.f[1]);
+    }
+  };
+  auto step = [&](BGroup<WNB>& cur_r, BGroup<WNB>& fetch_r) __attribute__((always_inline)) {
     const int TP = NT > AHEAD ? NT - 1 - AHEAD : 0;
     const int cur = (st & 1) * CPATCH, nxt = CPATCH - cur;
     if (t == 0 && !(ABL & 4)) __syncthreads();
@@ -402,8 +422,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       if (t >= TP) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD + CNQ) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
     }
-    if constexpr (HI32) use_b_hi(cur_r);
-    else use_b(cur_r);
+    use_group(cur_r);
     compute(cur_r, cur, tap);
     __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of the next tap below the MFMAs of this one (register pressure)
     if (t == NT - 1) {
@@ -426,11 +445,9 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   // Ring groups that no fetch has filled yet are defined by copies made AFTER the wait: a copy of a group whose
   // load is still in flight reads stale registers, and since a copy makes the two groups the same value for the
   // compiler, the stale one may end up feeding the first tap.
-  if constexpr (HI32) use_b_hi(R0);
-  else use_b(R0);
+  use_group(R0);
   if constexpr (RING == 3) {
-    if constexpr (HI32) use_b_hi(R1);
-    else use_b(R1);
+    use_group(R1);
   } else {
     R1 = R0;
   }
@@ -460,16 +477,16 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
 #pragma unroll
     for (int a = 0; a < WM; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) keep += acc[a][0][r];
+      for (int r = 0; r < 16; ++r) keep += acc[a][0][r] + acc[a][WNB - 1][r];
     if (keep == 12345.678f) p.out_act[tid] = keep;  // keeps the accumulators live
   } else {
     float* partial = KS > 1 ? p.ws + (int64_t)ks * ((int64_t)p.B * p.out_img_stride * p.Cout) : nullptr;
-    conv_epilogue<BN, WM, 1, WAVES_N, SPLIT, EPI_HALVES, RA>(p, smem, otab, acc, n0, partial);
+    conv_epilogue<BN, WM, WNB, WAVES_N, SPLIT, EPI_HALVES, RA>(p, smem, otab, acc, n0, partial);
   }
 }
 
 static size_t conv_lds_bytes(int BN, bool hi) {
-  const int halves = (BN == 128 && hi) ? 2 : 1;  // as EPI_HALVES in the kernel
+  const int halves = (BN >= 128 && hi) ? 2 : 1;  // as EPI_HALVES in the kernel
   const size_t main_bytes = std::max<size_t>((size_t)2 * CPATCH, (size_t)CBM * (BN / halves + 4) * 4);
   return main_bytes + CBM * 4;
 }
@@ -508,6 +525,10 @@ static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvP
 template <bool ELU, bool SPLIT, bool HI = false, bool H64 = false, bool RA = false>
 static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams* dparams) {
   switch (BN) {
+    case 256:
+      if constexpr (H64 && !ELU) launch_one<256, false, SPLIT, 0, 2, HI, H64, RA>(grid, stream, dparams);
+      else VFX_CHECK(false, "conv: the 256-cout tile runs activated fp16 sources only");
+      break;
     // H64: a tap is four K = 16 steps (as long as two taps of the 32-channel form), so one tap of look-ahead covers the
     // same time with a third less ring registers (with three groups the BN = 128 tile spills at three waves per SIMD)
     case 128: launch_one<128, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA>(grid, stream, dparams); break;
@@ -522,6 +543,10 @@ int conv_block_n(const TapConvParams& hp) {
   const int64_t spatial = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   const int cdiv = hp.nphase > 1 ? hp.cout_phase : hp.Cout;  // a block never straddles two phases
   int bn = cdiv % 128 == 0 ? 128 : (cdiv % 64 == 0 ? 64 : 32);
+  // 16-bit launches whose sources are all activated fp16 tensors (the vocoder's C = 512 stack, k7, upsamplers): 64-cout waves
+  bool all_act = hp.hionly && hp.nseg > 0 && !(hp.tuning & VFX_TUNE_NO_WIDE_CONV);
+  for (int s = 0; s < hp.nseg; ++s) all_act = all_act && hp.seg[s].src_act;
+  if (all_act && cdiv % 256 == 0 && spatial * (hp.Cout / 256) >= 1024) bn = 256;
   while (bn > 32 && spatial * (hp.Cout / bn) < 384) bn >>= 1;
   return bn;
 }

@@ -66,9 +66,12 @@ __device__ __forceinline__ bool f16_sat_bits_bad(unsigned sat) { return sat > 0x
 // `sat16` = per-half maximum of |h| as two u16 (v_and + v_pk_max_u16 per pair); a half that reached 0x7bff = 65504 was clamped
 // (or was exactly 65504 / a NaN: med3 sends a NaN to -65504) -- f16_sat16_bad().  8 instructions per pair with the mask select.
 // fp16(LeakyReLU(t)) and LeakyReLU16(fp16(t)) differ by one more rounding of the (100 x smaller) negative values only.
+// The position mask goes BETWEEN the conversion and the record: an h position outside the tile / the sequence may have been
+// computed from LDS rows that hold anything (the second layer of a pair reads operand rows that the staged fp32 tile overlaid),
+// its value is discarded and must not raise the flag (found on the GPU in round 4: the record briefly sat before the mask).
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack_f16x2_sat16(float a, float b, unsigned& sat16) {
-  const unsigned p = pack_f16x2(a, b);
+__device__ __forceinline__ unsigned pack_f16x2_sat16(float a, float b, bool valid, unsigned& sat16) {
+  const unsigned p = valid ? pack_f16x2(a, b) : 0u;
   const u16x2 m = __builtin_bit_cast(u16x2, p & 0x7fff7fffu);
   sat16 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, sat16), m));
   return p;
@@ -125,6 +128,11 @@ constexpr int CPATCH = kPatchMaxRows * CROW; // bytes per patch buffer
 // One weight fragment group = the four 16-byte-per-lane fragments of a (tap, 32-channel chunk, 32 couts).
 struct BFrag {
   f32x4 f[4];  // split: (hi, lo) of k 0..15, (hi, lo) of k 16..31; fp32: the four k8 groups
+};
+
+template <int N>
+struct BGroup {  // the weight fragments of one tap for a wave's N cout blocks (k_conv: N = 2 for the 64-cout wave tile)
+  BFrag f[N];
 };
 
 // Hidden from the compiler's s_waitcnt bookkeeping on purpose (see the file header): the destination

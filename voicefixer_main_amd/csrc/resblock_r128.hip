@@ -320,11 +320,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
-          const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[n][a][4 * j] + b1v[j][0], acc[n][a][4 * j + 1] + b1v[j][1], sat16), slope2);
-          const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[n][a][4 * j + 2] + b1v[j][2], acc[n][a][4 * j + 3] + b1v[j][3], sat16), slope2);
+          const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[n][a][4 * j] + b1v[j][0], acc[n][a][4 * j + 1] + b1v[j][1], valid[a], sat16), slope2);
+          const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[n][a][4 * j + 2] + b1v[j][2], acc[n][a][4 * j + 3] + b1v[j][3], valid[a], sat16), slope2);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[n][a][4 * j + e] = 0.f;
-          *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(valid[a] ? h01 : 0u, valid[a] ? h23 : 0u);
+          *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(h01, h23);  // LeakyReLU(0) = 0: masked stays 0
         }
       }
     }

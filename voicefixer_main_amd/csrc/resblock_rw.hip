@@ -262,11 +262,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         for (int j = 0; j < 4; ++j) {
           const f32x4 b1v = *reinterpret_cast<const f32x4*>(bias1 + wn * 32 + 8 * j + 4 * lh);
           // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
-          const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j] + b1v[0], acc[a][4 * j + 1] + b1v[1], sat16), slope2);
-          const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j + 2] + b1v[2], acc[a][4 * j + 3] + b1v[3], sat16), slope2);
+          const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j] + b1v[0], acc[a][4 * j + 1] + b1v[1], hval, sat16), slope2);
+          const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j + 2] + b1v[2], acc[a][4 * j + 3] + b1v[3], hval, sat16), slope2);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = 0.f;
-          *reinterpret_cast<uint2*>(rowp + (((wn * 4 + j) ^ key) << 4)) = make_uint2(hval ? h01 : 0u, hval ? h23 : 0u);
+          *reinterpret_cast<uint2*>(rowp + (((wn * 4 + j) ^ key) << 4)) = make_uint2(h01, h23);  // LeakyReLU(0) = 0: masked stays 0
         }
       }
       report_f16_saturation(f16_sat16_bad(sat16), p.flags);

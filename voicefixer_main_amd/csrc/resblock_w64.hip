@@ -293,11 +293,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
-          unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[cb][a][4 * j] + b1v[j][0], acc[cb][a][4 * j + 1] + b1v[j][1], sat16), slope2);
-          unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[cb][a][4 * j + 2] + b1v[j][2], acc[cb][a][4 * j + 3] + b1v[j][3], sat16), slope2);
+          const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[cb][a][4 * j] + b1v[j][0], acc[cb][a][4 * j + 1] + b1v[j][1], hval[a], sat16), slope2);
+          const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[cb][a][4 * j + 2] + b1v[j][2], acc[cb][a][4 * j + 3] + b1v[j][3], hval[a], sat16), slope2);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[cb][a][4 * j + e] = 0.f;
-          *reinterpret_cast<uint2*>(rowp + (((cb * 4 + j) ^ key) << 4)) = make_uint2(hval[a] ? h01 : 0u, hval[a] ? h23 : 0u);
+          *reinterpret_cast<uint2*>(rowp + (((cb * 4 + j) ^ key) << 4)) = make_uint2(h01, h23);  // LeakyReLU(0) = 0: masked stays 0
         }
       }
     }
