@@ -55,11 +55,9 @@ enum {
   VFX_TUNE_NO_PERSISTENT_C64 = 8,  /* 16-bit mode, C = 64 layers on k_resblock instead of the persistent kernel */
   VFX_TUNE_NO_PAIRS = 16,          /* 16-bit mode, C = 64 / 128: one launch per layer (no layer pairs) */
   VFX_TUNE_NO_SPLITK = 32,         /* no split-K in the deep ResUNet levels */
-  VFX_TUNE_F32_TRUNK = 64,         /* 16-bit mode: the residual trunk of the fused ResStacks (C = 64 / 128 / 256) travels as fp32
+  VFX_TUNE_F32_TRUNK = 64          /* 16-bit mode: the residual trunk of the fused ResStacks (C = 64 / 128 / 256) travels as fp32
                                       between the layers (the round-3 form: 8 - 12 bytes per element and layer) instead of
                                       fp16 (4 bytes per element and layer; the sums themselves are fp32 in registers either way) */
-  VFX_TUNE_NO_WIDE_CONV = 128      /* 16-bit mode: the tap-convolutions on activated fp16 sources (C = 512 stack, k7, upsamplers) on
-                                      128-cout tiles with 32-cout waves instead of 256-cout tiles with 64-cout waves */
 };
 
 typedef struct vfx_config {

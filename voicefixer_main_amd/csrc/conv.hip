@@ -17,9 +17,9 @@
 // Work decomposition
 //   block   = 4 waves, tile = TH x TW (<= 128) pixels of ONE image x BN in {128, 64, 32} couts;
 //   wave    = (128 / WAVES_M) pixels x 32 couts, WAVES_N = BN / 32;
-//   BN = 256 (round 4; 16-bit launches on activated fp16 sources only): wave = 128 pixels x 64 couts -- a pixel fragment read
-//             from LDS feeds TWO MFMAs (0.5 KB of LDS per MFMA instead of 1 KB: the BN = 128 tile takes a fragment per MFMA,
-//             128 B/clk/CU at full MFMA rate = all the LDS delivers; resblock_w64.hip gained 15 % from the same change);
+//   (round 4 measured a BN = 256 tile with 64-cout waves for the 16-bit launches on activated sources -- half the LDS fragment
+//   reads per MFMA, two blocks per CU instead of three: +-0 on the C = 512 stack and the upsamplers, bit-identical results;
+//   deleted, numbers in profiles/r04_c5_wide_conv_tile_ab.jsonl)
 //   stage   = one 32-channel chunk of one source tensor and the taps that read it.  The host
 //             flattens every launch into a table of stages (ConvStage, vfx_internal.h).
 //
@@ -72,17 +72,16 @@ namespace vfx {
 // transformed in place to fp16 in the first half of the row, two K = 16 steps per tap.
 // RA (with H64): the launch's residual is an activated fp16 tensor, inverted in the epilogue (TapConvParams::residual_act).
 template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false>
-__global__ __launch_bounds__(256, BN == 256 ? 2 : ((BN <= 64 || HI) ? 3 : 2)) void k_conv(const TapConvParams* __restrict__ pp) {
+__global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
   static_assert(!H64 || (HI && SPLIT), "H64 is a variant of the 16-bit mode");
   static_assert(!RA || H64, "an activated residual exists in the 16-bit mode's activated-source launches only");
-  static_assert(BN != 256 || (H64 && !ELU && RING == 2 && ABL == 0), "the 64-cout wave tile exists for activated fp16 sources");
   constexpr bool HI32 = HI && !H64;  // the hi fragments (f[0], f[2]) only
-  constexpr int WNB = BN == 256 ? 2 : 1;      // 32-cout blocks per wave
-  constexpr int WAVES_N = BN / (32 * WNB);
-  constexpr int WM = WAVES_N;                 // 32-row blocks per wave (= 4 / WAVES_M, WAVES_M = 4 / WAVES_N)
+  constexpr int WNB = 1;                      // 32-cout blocks per wave
+  constexpr int WAVES_N = BN / 32;
+  constexpr int WM = BN / 32;                 // 32-row blocks per wave (= 4 / WAVES_M)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int EPI_HALVES = (BN >= 128 && HI) ? 2 : 1;  // 16-bit BN = 128 tile: half-width epilogue staging -> three blocks per CU (BN = 256: two)
+  constexpr int EPI_HALVES = (BN == 128 && HI) ? 2 : 1;  // 16-bit BN = 128 tile: half-width epilogue staging -> three blocks per CU
   constexpr int kEpiBytes = CBM * (BN / EPI_HALVES + 4) * 4;
   constexpr int kMainBytes = (2 * CPATCH > kEpiBytes) ? 2 * CPATCH : kEpiBytes;
   char* const lds = reinterpret_cast<char*>(smem);
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(256, BN == 256 ? 2 : ((BN <= 64 || HI) ? 3 : 2)) vo
     arow[a] = li < TH ? li * PW + lj : 0;
     ak0[a] = li < TH ? (((lj >> 1) + hTW * li) | ((lj & 1) << 16)) : 0;
   }
-  const unsigned nb_off = (unsigned)(((n0w >> 5) + wn * WNB) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block (BN = 256: the wave's second cout block is 4096 bytes further)
+  const unsigned nb_off = (unsigned)(((n0w >> 5) + wn) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block
 
   // ---- patch (A) staging ------------------------------------------------------------------------
   // The byte offset of every patch pixel is kept in registers and only recomputed when the patch
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(256, BN == 256 ? 2 : ((BN <= 64 || HI) ? 3 : 2)) vo
     if (dh != o_dh || dw != o_dw || C != o_C) set_origin(dh, dw, C);  // uniform; VALU only
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((const float*)S.src), 0, (int)S.nbytes, 0x00020000);
-    praw = BN == 256 ? false : (S.flags & 1) == 0;  // (the 256-cout tile is launched on activated sources only: no transform code)
+    praw = (S.flags & 1) == 0;
 #pragma unroll
     for (int q = 0; q < CNQ; ++q) {
       // the lane's bytes always land in slot cg: an activated source is fetched pre-swizzled (piece cg ^ key)
@@ -486,7 +485,7 @@ __global__ __launch_bounds__(256, BN == 256 ? 2 : ((BN <= 64 || HI) ? 3 : 2)) vo
 }
 
 static size_t conv_lds_bytes(int BN, bool hi) {
-  const int halves = (BN >= 128 && hi) ? 2 : 1;  // as EPI_HALVES in the kernel
+  const int halves = (BN == 128 && hi) ? 2 : 1;  // as EPI_HALVES in the kernel
   const size_t main_bytes = std::max<size_t>((size_t)2 * CPATCH, (size_t)CBM * (BN / halves + 4) * 4);
   return main_bytes + CBM * 4;
 }
@@ -525,10 +524,6 @@ static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvP
 template <bool ELU, bool SPLIT, bool HI = false, bool H64 = false, bool RA = false>
 static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams* dparams) {
   switch (BN) {
-    case 256:
-      if constexpr (H64 && !ELU) launch_one<256, false, SPLIT, 0, 2, HI, H64, RA>(grid, stream, dparams);
-      else VFX_CHECK(false, "conv: the 256-cout tile runs activated fp16 sources only");
-      break;
     // H64: a tap is four K = 16 steps (as long as two taps of the 32-channel form), so one tap of look-ahead covers the
     // same time with a third less ring registers (with three groups the BN = 128 tile spills at three waves per SIMD)
     case 128: launch_one<128, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA>(grid, stream, dparams); break;
@@ -543,10 +538,6 @@ int conv_block_n(const TapConvParams& hp) {
   const int64_t spatial = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   const int cdiv = hp.nphase > 1 ? hp.cout_phase : hp.Cout;  // a block never straddles two phases
   int bn = cdiv % 128 == 0 ? 128 : (cdiv % 64 == 0 ? 64 : 32);
-  // 16-bit launches whose sources are all activated fp16 tensors (the vocoder's C = 512 stack, k7, upsamplers): 64-cout waves
-  bool all_act = hp.hionly && hp.nseg > 0 && !(hp.tuning & VFX_TUNE_NO_WIDE_CONV);
-  for (int s = 0; s < hp.nseg; ++s) all_act = all_act && hp.seg[s].src_act;
-  if (all_act && cdiv % 256 == 0 && spatial * (hp.Cout / 256) >= 1024) bn = 256;
   while (bn > 32 && spatial * (hp.Cout / bn) < 384) bn >>= 1;
   return bn;
 }

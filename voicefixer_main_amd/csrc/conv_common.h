@@ -131,7 +131,7 @@ struct BFrag {
 };
 
 template <int N>
-struct BGroup {  // the weight fragments of one tap for a wave's N cout blocks (k_conv: N = 2 for the 64-cout wave tile)
+struct BGroup {  // the weight fragments of one tap for a wave's N cout blocks (k_conv: N = 1)
   BFrag f[N];
 };
 

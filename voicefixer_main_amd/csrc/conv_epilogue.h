@@ -69,114 +69,108 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
     const int ncol = n0 + hh * BH + 4 * c4;
     ce_f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && !partial) bv = *(const VFX_CE_GLOBAL ce_f32x4*)(p.bias + ncol);
-    // rows of the pass in chunks of at most 8 per thread: the BN = 256 tile has 16 (val[], the residual and the row table of 16
-    // rows beside the 128 accumulators of the waves that stage second do not fit the register file)
-    constexpr int CH = WN == 2 ? 4 : (NPASS > 8 ? 8 : NPASS);  // (64-cout waves: 128 accumulators stay live through the first pass)
-#pragma unroll 1
-    for (int c0 = 0; c0 < NPASS; c0 += CH) {  // (a real loop: unrolled, the 256-cout tile would carry eight copies of the body)
-      int opix[CH];
-      ce_f32x4 val[CH];
+    int opix[NPASS];
+    ce_f32x4 val[NPASS];
 #pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        opix[q] = otab[r0 + (c0 + q) * RPP];
-        val[q] = *reinterpret_cast<const ce_f32x4*>(smem + (r0 + (c0 + q) * RPP) * LDO + 4 * c4) + bv;
-      }
-      if (partial) {
+    for (int q = 0; q < NPASS; ++q) {
+      opix[q] = otab[r0 + q * RPP];
+      val[q] = *reinterpret_cast<const ce_f32x4*>(smem + (r0 + q * RPP) * LDO + 4 * c4) + bv;
+    }
+    if (partial) {
 #pragma unroll
-        for (int q = 0; q < CH; ++q)
-          if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(partial + (int64_t)opix[q] * Cout + ncol) = val[q];
-        continue;
-      }
-      if constexpr (RESACT) {
-        // 16-bit mode on the fp16 trunk: the residual comes as the ACTIVATED fp16 form of it (TapConvParams::residual_act, 8 bytes
-        // per lane and row); the raw value is recovered as min(v, v / slope).  A compile-time variant: both residual forms in one
-        // body spill in the 168-register BN = 128 tile.  The four halves are bit-cast as a whole vector (hipcc 7.2 miscompiles
-        // __builtin_bit_cast of a vector ELEMENT: conv_common.h).
-        typedef unsigned ce_u32x2 __attribute__((ext_vector_type(2)));
-        typedef _Float16 ce_f16x4 __attribute__((ext_vector_type(4)));
-        const float inv = p.residual_inv_slope;
-        ce_u32x2 rh[CH];
+      for (int q = 0; q < NPASS; ++q)
+        if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(partial + (int64_t)opix[q] * Cout + ncol) = val[q];
+      continue;
+    }
+    if constexpr (RESACT) {
+      // 16-bit mode on the fp16 trunk: the residual comes as the ACTIVATED fp16 form of it (TapConvParams::residual_act, 8 bytes
+      // per lane and row); the raw value is recovered as min(v, v / slope).  A compile-time variant: both residual forms in one
+      // body spill in the 168-register BN = 128 tile.  The four halves are bit-cast as a whole vector (hipcc 7.2 miscompiles
+      // __builtin_bit_cast of a vector ELEMENT: conv_common.h).
+      typedef unsigned ce_u32x2 __attribute__((ext_vector_type(2)));
+      typedef _Float16 ce_f16x4 __attribute__((ext_vector_type(4)));
+      const float inv = p.residual_inv_slope;
+      ce_u32x2 rh[NPASS];
 #pragma unroll
-        for (int q = 0; q < CH; ++q)
-          rh[q] = *(const VFX_CE_GLOBAL ce_u32x2*)(reinterpret_cast<const _Float16*>(p.residual_act) +
-                                                  (int64_t)(opix[q] < 0 ? 0 : opix[q]) * Cout + ncol);
+      for (int q = 0; q < NPASS; ++q)
+        rh[q] = *(const VFX_CE_GLOBAL ce_u32x2*)(reinterpret_cast<const _Float16*>(p.residual_act) +
+                                                (int64_t)(opix[q] < 0 ? 0 : opix[q]) * Cout + ncol);
 #pragma unroll
-        for (int q = 0; q < CH; ++q) {
-          const ce_f16x4 h = __builtin_bit_cast(ce_f16x4, rh[q]);
+      for (int q = 0; q < NPASS; ++q) {
+        const ce_f16x4 h = __builtin_bit_cast(ce_f16x4, rh[q]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = (float)h[e];
-            val[q][e] += __builtin_fminf(v, v * inv);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float v = (float)h[e];
+          val[q][e] += __builtin_fminf(v, v * inv);
         }
-      } else if (p.residual) {
-        ce_f32x4 res[CH];
-#pragma unroll
-        for (int q = 0; q < CH; ++q)
-          res[q] = *(const VFX_CE_GLOBAL ce_f32x4*)(p.residual + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * Cout + ncol);
-#pragma unroll
-        for (int q = 0; q < CH; ++q) val[q] += res[q];
       }
-      if (p.out) {
+    } else if (p.residual) {
+      ce_f32x4 res[NPASS];
 #pragma unroll
-        for (int q = 0; q < CH; ++q)
-          if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out + (int64_t)opix[q] * Cout + ncol) = val[q];
-      }
-      if (p.out_act) {
-        bool f16_sat = false;  // 16-bit mode: an activation left the fp16 range and was clamped (VFX_FLAG_F16_SATURATED)
-        ce_f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
-        if (p.act_scale) asc = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_scale + ncol);
-        if (p.act_shift) ash = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_shift + ncol);
-        const float slope = p.act_slope;
-        const bool elu = p.act_elu != 0;
-        // split: the pair's 8 channels live in chunk ncol/32; hi block at +0, lo block at +16 floats, 8 channels = 4 floats
-        // 16-bit mode: the activated tensor is an fp16 tensor (2 bytes per element, Cout / 2 floats per pixel); the even
-        // lane of a pair stores the pair's 8 consecutive channels (16 bytes) at channel ncol
-        const int aoff = (SPLIT && f16) ? (ncol >> 1) : SPLIT ? (ncol & ~31) + ((ncol & 31) >> 3) * 4 + (even ? 0 : 16) : ncol;
-        const int64_t astride = (SPLIT && f16) ? (Cout >> 1) : Cout;
+      for (int q = 0; q < NPASS; ++q)
+        res[q] = *(const VFX_CE_GLOBAL ce_f32x4*)(p.residual + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * Cout + ncol);
 #pragma unroll
-        for (int q = 0; q < CH; ++q) {
-          ce_f32x4 u;
+      for (int q = 0; q < NPASS; ++q) val[q] += res[q];
+    }
+    if (p.out) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = val[q][e] * asc[e] + ash[e];
-            u[e] = elu ? (t > 0.f ? t : expm1f(t)) : fmaxf(t, t * slope);
-          }
-          ce_f32x4 o;
-          if constexpr (SPLIT) {
-            unsigned h01, h23, l01, l23;
-            if (f16) {  // 16-bit mode: fp16 (saturating) in the hi half, the lo half is never read
-              const ce_f32x2 c01 = {__builtin_fminf(__builtin_fmaxf(u[0], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[1], -65504.f), 65504.f)};
-              const ce_f32x2 c23 = {__builtin_fminf(__builtin_fmaxf(u[2], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[3], -65504.f), 65504.f)};
-              h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(c01, ce_f16x2));
-              h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(c23, ce_f16x2));
-              l01 = l23 = 0u;
-              // the predicate of conv_common.h's f16_out_of_range (this header is also used without it)
-              f16_sat = f16_sat | !(__builtin_fabsf(u[0]) <= 65504.f) | !(__builtin_fabsf(u[1]) <= 65504.f) |
-                        !(__builtin_fabsf(u[2]) <= 65504.f) | !(__builtin_fabsf(u[3]) <= 65504.f);
-            } else {
-              h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[0], u[1]}, ce_bf16x2));
-              h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[2], u[3]}, ce_bf16x2));
-              const ce_f32x2 r01 = {u[0] - __builtin_bit_cast(float, h01 << 16), u[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
-              const ce_f32x2 r23 = {u[2] - __builtin_bit_cast(float, h23 << 16), u[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
-              l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, ce_bf16x2));
-              l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, ce_bf16x2));
-            }
-            // quad_perm [1,0,3,2]: swap with the neighbouring lane (the other half of the 8-channel group)
-            const unsigned s0 = even ? l01 : h01, s1 = even ? l23 : h23;
-            const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, false);
-            const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, false);
-            const ce_u32x4 w = even ? ce_u32x4{h01, h23, g0, g1} : ce_u32x4{g0, g1, l01, l23};
-            o = __builtin_bit_cast(ce_f32x4, w);
-          } else {
-            o = u;
-          }
-          // 16-bit mode: the lo half (odd lanes) is never read by a consumer -- not written either
-          if (opix[q] >= 0 && !(SPLIT && f16 && !even)) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * astride + aoff) = o;
+      for (int q = 0; q < NPASS; ++q)
+        if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out + (int64_t)opix[q] * Cout + ncol) = val[q];
+    }
+    if (p.out_act) {
+      bool f16_sat = false;  // 16-bit mode: an activation left the fp16 range and was clamped (VFX_FLAG_F16_SATURATED)
+      ce_f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+      if (p.act_scale) asc = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_scale + ncol);
+      if (p.act_shift) ash = *(const VFX_CE_GLOBAL ce_f32x4*)(p.act_shift + ncol);
+      const float slope = p.act_slope;
+      const bool elu = p.act_elu != 0;
+      // split: the pair's 8 channels live in chunk ncol/32; hi block at +0, lo block at +16 floats, 8 channels = 4 floats
+      // 16-bit mode: the activated tensor is an fp16 tensor (2 bytes per element, Cout / 2 floats per pixel); the even
+      // lane of a pair stores the pair's 8 consecutive channels (16 bytes) at channel ncol
+      const int aoff = (SPLIT && f16) ? (ncol >> 1) : SPLIT ? (ncol & ~31) + ((ncol & 31) >> 3) * 4 + (even ? 0 : 16) : ncol;
+      const int64_t astride = (SPLIT && f16) ? (Cout >> 1) : Cout;
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+        ce_f32x4 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = val[q][e] * asc[e] + ash[e];
+          u[e] = elu ? (t > 0.f ? t : expm1f(t)) : fmaxf(t, t * slope);
         }
+        ce_f32x4 o;
         if constexpr (SPLIT) {
-          if (f16 && __any(f16_sat) && p.flags && (tid & 63) == 0) or_flag_global(p.flags, VFX_FLAG_F16_SATURATED);
+          unsigned h01, h23, l01, l23;
+          if (f16) {  // 16-bit mode: fp16 (saturating) in the hi half, the lo half is never read
+            const ce_f32x2 c01 = {__builtin_fminf(__builtin_fmaxf(u[0], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[1], -65504.f), 65504.f)};
+            const ce_f32x2 c23 = {__builtin_fminf(__builtin_fmaxf(u[2], -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(u[3], -65504.f), 65504.f)};
+            h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(c01, ce_f16x2));
+            h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(c23, ce_f16x2));
+            l01 = l23 = 0u;
+            // the predicate of conv_common.h's f16_out_of_range (this header is also used without it)
+            f16_sat = f16_sat | !(__builtin_fabsf(u[0]) <= 65504.f) | !(__builtin_fabsf(u[1]) <= 65504.f) |
+                      !(__builtin_fabsf(u[2]) <= 65504.f) | !(__builtin_fabsf(u[3]) <= 65504.f);
+          } else {
+            h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[0], u[1]}, ce_bf16x2));
+            h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(ce_f32x2{u[2], u[3]}, ce_bf16x2));
+            const ce_f32x2 r01 = {u[0] - __builtin_bit_cast(float, h01 << 16), u[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+            const ce_f32x2 r23 = {u[2] - __builtin_bit_cast(float, h23 << 16), u[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+            l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, ce_bf16x2));
+            l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, ce_bf16x2));
+          }
+          // quad_perm [1,0,3,2]: swap with the neighbouring lane (the other half of the 8-channel group)
+          const unsigned s0 = even ? l01 : h01, s1 = even ? l23 : h23;
+          const unsigned g0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, false);
+          const unsigned g1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, false);
+          const ce_u32x4 w = even ? ce_u32x4{h01, h23, g0, g1} : ce_u32x4{g0, g1, l01, l23};
+          o = __builtin_bit_cast(ce_f32x4, w);
+        } else {
+          o = u;
         }
+        // 16-bit mode: the lo half (odd lanes) is never read by a consumer -- not written either
+        if (opix[q] >= 0 && !(SPLIT && f16 && !even)) *(VFX_CE_GLOBAL ce_f32x4*)(p.out_act + (int64_t)opix[q] * astride + aoff) = o;
+      }
+      if constexpr (SPLIT) {
+        if (f16 && __any(f16_sat) && p.flags && (tid & 63) == 0) or_flag_global(p.flags, VFX_FLAG_F16_SATURATED);
       }
     }
   }
