@@ -707,7 +707,7 @@ def aux_workload(name, args, device, weights):
             res["roofline"], res["step"] = roof, whole
         if not args.no_parity:
             n = 2 if name == "ssr_sr64" else 1
-            base, ref = cpu_baseline("ssr", w.clips, n, args.cpu_threads, repeats=1, dtype=torch.float64)
+            base, ref = cpu_baseline("ssr", w.clips, n, args.cpu_threads, repeats=args.cpu_repeats, dtype=torch.float64)
             res["cpu_baseline"] = base
             res["parity"] = parity_wav(got[:n], ref["wav"][:, 0])
             res["parity"]["vs"] = "oracle.pipeline.restore_ssr in FLOAT64 (CPU port of unet_v2.py:86-148)"

@@ -114,6 +114,21 @@ def test_ssr_unet_vs_reference_golden_batch_of_two(engine):
     assert rel < (1e-4 if engine.tol['name'] == 'fp32' else 1e-3), rel
 
 
+def test_restore_list_of_unequal_lengths_equals_one_call_per_clip(voicefixer):
+    """VoiceFixer.restore_list (dist.restore_sharded_lengths in a world of one): five clips of three lengths -- equal lengths run
+    as one batch, longest first -- give, clip by clip, EXACTLY what a batch-of-one `restore` of that clip gives (the reference
+    calls its handler once per file), in the order of the input list."""
+    from voicefixer_main_amd import synth
+    lens = [30000, 12345, 30000, 20001, 12345]
+    clips = [torch.from_numpy(synth.make_clips(1, L / 44100.0, seed=50 + i)[0, 0]).cuda() for i, L in enumerate(lens)]
+    assert [int(c.shape[0]) for c in clips] == lens
+    got = voicefixer.restore_list(clips)
+    assert [int(g.shape[0]) for g in got] == lens
+    for c, g in zip(clips, got):
+        one = voicefixer.restore(c[None])[0]
+        assert torch.isfinite(g).all() and torch.equal(g, one)
+
+
 def test_handler_end_to_end(voicefixer, unet_sd, voc_sd, tmp_path):
     from oracle import pipeline
     from voicefixer_main_amd import handlers, synth

@@ -377,6 +377,16 @@ class VoiceFixer(_Base):
         out = _rerun_if_saturated(self.engine, out, lambda e: e.restore_gsr(x, unify_energy=unify_energy))
         return out[:, None] if squeeze else out
 
+    def restore_list(self, wavs, unify_energy=False, max_batch=37):
+        """A test set of clips of ARBITRARY lengths (what the reference's harness iterates, one handler call per file:
+        evaluation_proc/eval.py:119-134): list of 1-D tensors -> list of restored 1-D tensors in the same order.  Clips of equal
+        length share a batched call (every clip's result is the one its own batch-of-one call gives), lengths are visited
+        longest first; with torch.distributed initialised the list is dealt over the ranks by length and gathered on rank 0
+        (dist.restore_sharded_lengths).  The 16-bit mode's re-run guarantee holds per batch."""
+        from . import dist as vdist
+        fn = vdist.checked_restore(self.engine, unify_energy=unify_energy)
+        return vdist.restore_sharded_lengths(fn, wavs, self.device, max_batch=max_batch)
+
 
 class SSR_UNet(_Base):
     """models/ssr_unet.py:56-155 / models/gsr_unet.py (identical inference surface): the
