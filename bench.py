@@ -244,15 +244,16 @@ def measure_conv_roofline(eng, step, args, traffic, ms_step=None, steps=None):
                  # product, so `frac` is bounded by 1/3 and mfma_issue_frac is the share of the MFMA pipe actually used
                  "mfma_issue_frac": round(tflops * per_product / peak, 4)}
     hbm_line = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                # a ResStack layer = x in + y out = 8 bytes per element; a convolution = its sources,
-                # residual and outputs once.  design_bytes = what the kernel's data layout moves on top (the fp16 copies of a
-                # two-form trunk: 12 bytes per element at C = 256).
+                # a ResStack layer = x in + y out (4 bytes per element on the fp16 trunk, 8 on the fp32
+                # one); a convolution = its sources, residual and outputs once.  design_bytes = what the kernel's data layout moves
+                # (round 3's two-form trunk: 12 bytes per element at C = 256; on the fp16 trunk = the algorithmic bytes).
                 "algorithmic_bytes_per_launch": round(kby / max(cnt, 1)), "design_bytes_per_launch": round(kdb / max(cnt, 1))}
     head = dict(hbm_line if hbm_bound else mfma_line)
     return dict({
         "bound": "hbm" if hbm_bound else "mfma",
         "accounting": "SURVEY.md section 8(d): algorithmic flops = 2 x MAC once; algorithmic bytes = tensors in + out once "
-                      "(ResStack layer: 8 B per element); the bound follows from that intensity vs the chip's ridge",
+                      "(ResStack layer: x in + y out = 4 B per element on the fp16 trunk, 8 B on the fp32 trunk of "
+                      "VFX_TUNE_F32_TRUNK); the bound follows from that intensity vs the chip's ridge",
         "kernel": "%s (%s)" % (dom, "1 x v_mfma_f32_32x32x16_f16 per product (fp16 operands), fp32 accumulate" if plain
                                else "3 x v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
                                if split else "v_mfma_f32_32x32x2_f32"),
