@@ -118,6 +118,11 @@ int vfx_finalize_weights(vfx_handle* h, int model);
  * arena up-front so that later calls never allocate (required before graph capture). */
 size_t vfx_workspace_bytes(vfx_handle* h, int model, int B, int T);
 int vfx_reserve(vfx_handle* h, int model, int B, int T);
+/* A call made while its stream is being captured into a hipGraph pins its plan: the graph's kernel nodes hold the plan's device
+ * parameter blocks and absolute pointers into the workspace arena, so from then on the handle refuses to grow (= move) its arena
+ * -- a larger call returns an error instead of freeing memory the graph replays into.  vfx_unpin_plans declares that every graph
+ * captured from this handle has been destroyed: plans become evictable again and the arena may grow. */
+int vfx_unpin_plans(vfx_handle* h);
 
 /*
  * STFT front-end: FDomainHelper.wav_to_spectrogram_phase (tools/pytorch/modules/

@@ -246,6 +246,32 @@ def test_graph_capture_restore_and_streaming_step(engine):
     g2.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, ref)
+    # A handle with a captured plan refuses to MOVE its arena (the graph's kernels hold absolute pointers into it): a call that
+    # needs a larger workspace fails loudly instead of freeing memory the graph still replays into -- until the caller declares the
+    # graphs destroyed (vfx_unpin_plans).  A fresh engine, so that the session-wide one keeps its arena.
+    from voicefixer_main_amd.engine import Engine
+    e2 = Engine("cuda:0", config={"precision": engine.precision})
+    e2.load_state_dict(MODEL_UNET_SPEC, synth.make_resunet_state_dict(2))
+    small = wav[:1, :22050].contiguous()
+    sps = e2.stft(small, want_mel=False, want_sp=True)["sp"]
+    e2.resunet_spec(sps, small)
+    g3 = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g3, stream=side):
+            ys = e2.resunet_spec(sps, small)
+    torch.cuda.current_stream().wait_stream(side)
+    with pytest.raises(RuntimeError, match="vfx_reserve"):
+        e2.resunet_spec(sp, chunk)                       # twice the frames: the arena would have to grow
+    g3.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(ys).all()
+    del g3
+    e2.unpin_plans()
+    assert torch.equal(e2.resunet_spec(sp, chunk), ref)  # now it may grow
+    del graph, g2
+    engine.unpin_plans()                                 # the session-wide engine may move its arena again in later tests
 
 
 def _toy_net(x):

@@ -44,6 +44,7 @@ SIGNATURES = {
     "vfx_finalize_weights": (c_int, [c_void_p, c_int]),
     "vfx_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "vfx_reserve": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "vfx_unpin_plans": (c_int, [c_void_p]),
     "vfx_stft_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vfx_stft_phase": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "vfx_mel_project": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -604,8 +604,8 @@ static char* ensure_arena(vfx_handle* h, size_t bytes) {
   // captures.
   for (auto& kv : h->plans)
     VFX_CHECK(!(kv.second->pinned && h->arena), "the workspace arena would have to grow from %zu to %zu bytes, but a hipGraph was captured from plan '%s' "
-              "and replays kernels that point into the current arena: vfx_reserve() the largest (model, B, T) BEFORE capturing "
-              "(or destroy the graph and the handle)", h->arena_bytes, bytes, kv.first.c_str());
+              "and replays kernels that point into the current arena: vfx_reserve() the largest (model, B, T) BEFORE capturing, "
+              "or destroy the graph(s) and call vfx_unpin_plans()", h->arena_bytes, bytes, kv.first.c_str());
   VFX_HIP(hipDeviceSynchronize());
   if (h->arena) VFX_HIP(hipFree(h->arena));
   h->arena = nullptr;
@@ -894,6 +894,13 @@ int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out) {
   VFX_HIP(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
   VFX_HIP(hipStreamSynchronize(s));
   *flags_out = v;
+  VFX_API_END
+}
+
+int vfx_unpin_plans(vfx_handle* h) {
+  VFX_API_BEGIN_H(h)
+  VFX_CHECK(h, "NULL handle");
+  for (auto& kv : h->plans) kv.second->pinned = false;
   VFX_API_END
 }
 

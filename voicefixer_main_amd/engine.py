@@ -128,6 +128,11 @@ class Engine:
     def reserve(self, model, B, T):
         _lib.check(self.lib.vfx_reserve(self.h, model, B, T), "vfx_reserve")
 
+    def unpin_plans(self):
+        """Every hipGraph captured from this handle has been destroyed: its plans may be evicted and the arena may grow again
+        (a handle with a captured plan refuses to move its arena: reserve() the largest shape before capturing)."""
+        _lib.check(self.lib.vfx_unpin_plans(self.h), "vfx_unpin_plans")
+
     def workspace_bytes(self, model, B, T):
         return int(self.lib.vfx_workspace_bytes(self.h, model, B, T))
 
