@@ -594,7 +594,12 @@ int choose_ksplit(const TapConvParams& p) {
   // transposed convolution, whose launches interleave their pixels)
   if (p.sh != 1 || p.sw != 1 || p.oh0 != 0 || p.ow0 != 0 || p.Hg != p.Ho || p.Wg != p.Wo) return 1;
   const int par = p.tiles_h * p.tiles_w * (p.Cout / 32);
-  int s = std::min(8, std::min(p.nstages / 3, 128 / std::max(par, 1)));
+#ifndef VFX_KSPLIT_MAX
+#define VFX_KSPLIT_MAX 8        // most slices
+#define VFX_KSPLIT_STAGES 3     // fewest stages per slice
+#define VFX_KSPLIT_PAR 128      // blocks per clip the split aims at
+#endif
+  int s = std::min(VFX_KSPLIT_MAX, std::min(p.nstages / VFX_KSPLIT_STAGES, VFX_KSPLIT_PAR / std::max(par, 1)));
   int pow2 = 1;
   while (pow2 * 2 <= s) pow2 *= 2;
   return pow2;
