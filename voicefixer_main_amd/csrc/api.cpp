@@ -490,6 +490,7 @@ static double resblock_design_bytes(const ResBlockParams& q) {
 void PlanBuilder::add_conv(TapConvParams p) {
   p.split = h->cfg.precision != 0;
   p.tuning = h->cfg.tuning;
+  p.short_clip = short_clip;
   finish_params(p);
   p.ksplit = choose_ksplit(p);
   size_t ws_off = ~size_t(0);

@@ -594,12 +594,11 @@ int choose_ksplit(const TapConvParams& p) {
   // transposed convolution, whose launches interleave their pixels)
   if (p.sh != 1 || p.sw != 1 || p.oh0 != 0 || p.ow0 != 0 || p.Hg != p.Ho || p.Wg != p.Wo) return 1;
   const int par = p.tiles_h * p.tiles_w * (p.Cout / 32);
-#ifndef VFX_KSPLIT_MAX
-#define VFX_KSPLIT_MAX 8        // most slices
-#define VFX_KSPLIT_STAGES 3     // fewest stages per slice
-#define VFX_KSPLIT_PAR 128      // blocks per clip the split aims at
-#endif
-  int s = std::min(VFX_KSPLIT_MAX, std::min(p.nstages / VFX_KSPLIT_STAGES, VFX_KSPLIT_PAR / std::max(par, 1)));
+  // at most 8 slices; a batch of ordinary clips: >= 3 stages per slice, 128 blocks per clip aimed at (round 2); a short clip
+  // (TapConvParams::short_clip: <= 128 padded frames): slices of one stage, 512 blocks per clip -- measured both ways in round 4
+  // (profiles/r04_c8_splitk_ab.txt: each rule loses 20 % on the other's workload)
+  const int min_stages = p.short_clip ? 1 : 3, aim = p.short_clip ? 512 : 128;
+  int s = std::min(8, std::min(p.nstages / min_stages, aim / std::max(par, 1)));
   int pow2 = 1;
   while (pow2 * 2 <= s) pow2 *= 2;
   return pow2;

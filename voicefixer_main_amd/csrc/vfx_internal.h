@@ -172,6 +172,11 @@ struct TapConvParams {
   // residual, raw / activated output).  The split depends on the per-clip geometry only, never on the batch size:
   // results do not depend on how clips are batched.
   int ksplit;
+  // Set by the plan (PlanBuilder::short_clip): the clip has at most 128 padded frames (the 1-s streaming chunk).  Such a clip
+  // cannot fill the chip whatever the batch is asked to be -- the deep launches are pure latency chains -- so the split aims at
+  // 512 blocks per clip with slices of one stage (round 4: 3.16 -> 2.51 ms per 1-s chunk; the same rule costs a 16 x 10 s batch
+  // +20 %, profiles/r04_c8_splitk_ab.txt).  A property of the CLIP, never of the batch: results stay batch-invariant.
+  int short_clip;
   float* ws;
   int tuning;            // vfx_config.tuning of the handle (choose_ksplit)
 };
@@ -391,6 +396,7 @@ struct PlanBuilder {
   vfx_handle* h;
   Plan* plan;
   ArenaPlanner arena;
+  int short_clip = 0;  // copied into every TapConvParams added from here on (TapConvParams::short_clip)
   // returns arena offset in BYTES
   size_t alloc_f(int64_t nfloat) { return arena.alloc((size_t)nfloat * sizeof(float)); }
   void free(size_t off) { arena.free(off); }

@@ -168,6 +168,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
   Plan* pl = pb.plan;
   vfx_handle* hh = pb.h;
   const int Tp = T + T % 2 + 4;
+  pb.short_clip = 0;  // (the ResUNets' split-K rule for short clips does not apply to the vocoder's launches)
 
   auto resolve = [pl](const RunCtx& c, const BufRef& b) -> float* {
     return b.ext ? c.ext[b.slot] : reinterpret_cast<float*>(pl->bound_base + b.off);
