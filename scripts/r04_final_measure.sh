@@ -25,6 +25,8 @@ fi
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_gsr16x10.json 2> $O/bench_gsr16x10.err; cut -c1-200 $O/bench_gsr16x10.json; tail -n 2 $O/bench_gsr16x10.err
 bash scripts/smi_sample.sh $O/smi.txt timeout 300 python bench.py --steps 20 --warmup 5 --no-aux --no-alt --cpu-baseline-clips 0 --no-parity --traffic off --no-roofline > /dev/null 2>&1
 timeout 300 python bench.py --workload sharded1024 --steps 3 --warmup 1 --no-aux > $O/bench_sharded1024.json 2> $O/bench_sharded1024.err; cut -c1-160 $O/bench_sharded1024.json
+timeout 300 python bench.py --workload ssr_sr64 --steps 3 --warmup 1 > $O/bench_ssr_sr64.json 2> $O/bench_ssr_sr64.err; cut -c1-160 $O/bench_ssr_sr64.json
+timeout 300 python bench.py --workload stream1s --steps 100 --warmup 10 > $O/bench_stream1s.json 2> $O/bench_stream1s.err; cut -c1-160 $O/bench_stream1s.json
 timeout 200 python scripts/bench_handler.py --precision=2 > $O/handler_p2.json 2> $O/handler.err; cat $O/handler_p2.json | cut -c1-300
 ( cd /tmp; export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace --stats -d "$ROOT/$O/prof" -o $tag -- \
     python "$ROOT/bench.py" --steps 5 --warmup 2 --no-alt --no-aux --cpu-baseline-clips 0 --traffic off --no-parity > "$ROOT/$O/prof.log" 2>&1; echo "prof rc=$?" )
