@@ -55,9 +55,11 @@ enum {
   VFX_TUNE_NO_PERSISTENT_C64 = 8,  /* 16-bit mode, C = 64 layers on k_resblock instead of the persistent kernel */
   VFX_TUNE_NO_PAIRS = 16,          /* 16-bit mode, C = 64 / 128: one launch per layer (no layer pairs) */
   VFX_TUNE_NO_SPLITK = 32,         /* no split-K in the deep ResUNet levels */
-  VFX_TUNE_F32_TRUNK = 64          /* 16-bit mode: the residual trunk of the fused ResStacks (C = 64 / 128 / 256) travels as fp32
+  VFX_TUNE_F32_TRUNK = 64,         /* 16-bit mode: the residual trunk of the fused ResStacks (C = 64 / 128 / 256) travels as fp32
                                       between the layers (the round-3 form: 8 - 12 bytes per element and layer) instead of
                                       fp16 (4 bytes per element and layer; the sums themselves are fp32 in registers either way) */
+  VFX_TUNE_SMALL_2D_TILES = 128    /* fused ConvBlockRes of the ResUNets at C = 32: 8 x 16 / 16 x 8 h tiles (84 outputs per 128 positions)
+                                      instead of 16 x 16 (196 per 256) */
 };
 
 typedef struct vfx_config {

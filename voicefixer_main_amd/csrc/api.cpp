@@ -813,12 +813,12 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   h->device = device;
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
   VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
-  VFX_CHECK((h->cfg.tuning & ~127) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
+  VFX_CHECK((h->cfg.tuning & ~255) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
   if (h->cfg.tuning) {  // never silent: a non-default kernel selection is announced
     static const char* names[] = {"NO_FUSED_STACKS", "NO_FUSED_WIDE", "NO_FUSED_UNET", "NO_PERSISTENT_C64", "NO_PAIRS", "NO_SPLITK",
-                                  "F32_TRUNK"};
+                                  "F32_TRUNK", "SMALL_2D_TILES"};
     std::string msg;
-    for (int b = 0; b < 7; ++b)
+    for (int b = 0; b < 8; ++b)
       if (h->cfg.tuning & (1 << b)) msg += std::string(msg.empty() ? "" : " | ") + "VFX_TUNE_" + names[b];
     fprintf(stderr, "[libvfx] handle on device %d uses non-default kernel selection: tuning = 0x%x (%s)\n", device, h->cfg.tuning,
             msg.c_str());

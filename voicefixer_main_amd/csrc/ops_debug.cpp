@@ -404,6 +404,7 @@ extern "C" int vfx_op_block2d(vfx_handle* h, const float* x, int B, int H, int W
   rp.H = H;
   rp.W = W;
   rp.C = C;
+  rp.tuning = h->cfg.tuning;
   plan_block2d(rp);
   ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
   VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));

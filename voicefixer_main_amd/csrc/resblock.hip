@@ -54,16 +54,24 @@ __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
 // G2 = true: the same machinery as a fused 2-D ConvBlockRes of the ResUNets (models/components/modules.py:223-271,
 // Cin == Cout, identity shortcut):  y = x + conv2(lrelu(bn2(conv1(lrelu(bn1(x))))))  with 3x3 convolutions.  Tile = h grid
 // of TH x W1 = 128 pixels (8 x 16 or 16 x 8), outputs = its interior, x patch = (TH + 2) x (W1 + 2) = 180 pixels.
-template <int C, int NW, bool HI, bool G2 = false>
-__global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_RB_RING32 >= 5 ? 3 : 4) : 3) : (HI ? 4 : 2))) void k_resblock(const ResBlockParams* __restrict__ pp) {
+// MT = 256 (round 4; 2-D mode at C = 32 only: one 32-channel chunk = one patch buffer): h grid of 16 x 16 pixels, 14 x 14 outputs,
+// x patch 18 x 18 = 324 pixels -- the halo costs 1.31x recomputed h positions instead of 1.52x (8 x 16 / 16 x 8: 84 outputs per
+// 128) and 1.65 instead of 2.14 patch pixels per output.  Four waves of 64 pixels (the 128-position tile: two), 48 KB of LDS:
+// three blocks per CU = the same 12 waves per CU as six blocks of the small tile.  At C = 64 the two patch buffers would be
+// 96 KB (one 8-wave block per CU instead of three 4-wave ones): not built.
+template <int C, int NW, bool HI, bool G2 = false, int MT = 128>
+__global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_RB_RING32 >= 5 ? 3 : 4) : 3) : (HI ? 4 : 2)))) void k_resblock(const ResBlockParams* __restrict__ pp) {
+  static_assert(MT == 128 || (MT == 256 && G2 && C == 32 && NW == 4 && !HI), "the 256-position tile exists for the C = 32 2-D block");
+  constexpr int PMAX = MT + MT / 2;          // patch rows per buffer (192; 384 for the 18 x 18 patch of the 16 x 16 tile)
+  constexpr int PBYTES = PMAX * CROW;        // bytes per patch buffer
   constexpr int KT = G2 ? 9 : 3;  // taps per convolution
   constexpr int WL = HI ? 2 : 4;  // weight loads per tap and wave (HI: fp16 operands, hi fragments only)
   constexpr int NTHR = NW * 64;
   constexpr int RG = NTHR / 8;               // patch rows per DMA instruction group (8 lanes per row)
-  constexpr int NG = kPatchMaxRows / RG;     // DMA instructions per wave and patch
-  static_assert(kPatchMaxRows % RG == 0, "patch rows must split into whole DMA groups");
+  constexpr int NG = PMAX / RG;     // DMA instructions per wave and patch
+  static_assert(PMAX % RG == 0, "patch rows must split into whole DMA groups");
   constexpr int NCH = C / 32;  // 32-channel chunks = waves along N
-  constexpr int WAVES_N = NCH, WAVES_M = NW / WAVES_N, WM = 4 / WAVES_M;  // (C, NW) = (64, 4): 2, 2, 2;  (128, 8): 4, 2, 2
+  constexpr int WAVES_N = NCH, WAVES_M = NW / WAVES_N, WM = (MT / 32) / WAVES_M;  // (C, NW) = (64, 4): 2, 2, 2;  (128, 8): 4, 2, 2
   // weight taps in flight.  C = 32 (2-D blocks): the timing-only build without weight refreshes (-DVFX_RB_ABL_NOWEIGHTS) runs that
   // block 25 % faster, but deeper rings do not (-DVFX_RB_RING32=4: 2.97 ms per step against 2.95 with 3; 5 at three blocks per CU:
   // 3.40): it is not the latency of a fetch but their number -- the four waves of a block (32 pixels x ALL 32 output channels each)
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
   constexpr int H_OFF = 0;            // h overlays the patch buffers (dead once conv1 is done): less LDS, more blocks per CU
   constexpr int NT1 = KT * NCH;       // taps of conv1 (chunk-major); conv2 has as many
   constexpr int LDO = C + 4;          // staged output row (floats)
-  constexpr int OTAB_OFF = CBM * LDO * 4;
+  constexpr int OTAB_OFF = MT * LDO * 4;
   // The residual: the epilogue's re-read of x finds its lines evicted from L2 (the HBM-bound C = 64 stack moves 5.0 GB per
   // layer through the fabric against 3.64 GB of tensors, a fifth of it this re-read).  Where registers allow (C = 64: 3
   // waves per SIMD, 168 VGPRs) every thread keeps the raw values it fetched for the patch (48 registers) and adds them to
@@ -194,13 +202,13 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
     unsigned f16_sat = 0;  // 16-bit mode: a value left the fp16 range and was clamped (reported per patch)
 #pragma unroll
     for (int q = 0; q < NG; ++q)
-      if (q * RG < 128 || q < nq) {
+      if (q * RG < MT || q < nq) {
         raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
         if constexpr (KEEPRES) keep[c][q] = raw[q];
       }
 #pragma unroll
     for (int q = 0; q < NG; ++q)
-      if (q * RG < 128 || q < nq) {
+      if (q * RG < MT || q < nq) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -323,8 +331,8 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
   // NBUF = 3 (four chunks: C = 128): chunks 0, 1, 2 arrive in ONE round trip, chunk 3 goes into chunk 0's buffer once conv1 is
   // done with it -- two exposed memory latencies per tile instead of four (a chunk is 0.2 us of MFMAs, a round trip 2 us)
   if constexpr (NBUF == 3) {
-    issue_patch(1, CPATCH);
-    issue_patch(2, 2 * CPATCH);
+    issue_patch(1, PBYTES);
+    issue_patch(2, 2 * PBYTES);
   }
   drain();
   transform_patch(0, 0);
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
       fetch(g + AHEAD);
       // the patch is requested right after the fetch of this chunk's LAST tap, so every counted wait
       // below is for a fetch issued before it
-      if (k == KT - 1 - AHEAD && has_dma) issue_patch(dma_chunk, (dma_chunk % NBUF) * CPATCH);
+      if (k == KT - 1 - AHEAD && has_dma) issue_patch(dma_chunk, (dma_chunk % NBUF) * PBYTES);
       if (k >= AHEAD) wait_b_dyn<NG, WL, HI>(ring(g), WL * AHEAD + ((has_dma && k >= KT - 1 - AHEAD) ? NG : 0));
       int rows[WM], kov[WM];
 #pragma unroll
@@ -351,11 +359,11 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
         if constexpr (G2) asm volatile("" : "+v"(k0));  // recompute per tap: hoisting 18 keys out of the chunk loop spills
         kov[a] = ((k0 + hW1 * (k / 3) + (k % 3 == 2 ? 1 : 0) + (k % 3 == 1 ? kpar[a] : 0)) & 7) << 4;
       }
-      mma(ring(g), lds + (c % NBUF) * CPATCH, CROW, rows, -1, kov, G2);
+      mma(ring(g), lds + (c % NBUF) * PBYTES, CROW, rows, -1, kov, G2);
       __builtin_amdgcn_sched_barrier(0);
     }
     drain();
-    if (c + 1 < NCH) transform_patch(((c + 1) % NBUF) * CPATCH, c + 1);
+    if (c + 1 < NCH) transform_patch(((c + 1) % NBUF) * PBYTES, c + 1);
   }
 
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
         const int r = arow2[a] + (G2 ? p.hoff9[k] : k - 1);
-        rows[a] = r < 0 ? 0 : (r > CBM - 1 ? CBM - 1 : r);  // clamped rows only feed outputs that are masked anyway
+        rows[a] = r < 0 ? 0 : (r > MT - 1 ? MT - 1 : r);  // clamped rows only feed outputs that are masked anyway
       }
       mma(ring(g), lds + H_OFF, HROW, rows, c, rows, false);
       __builtin_amdgcn_sched_barrier(0);
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
 
   // ---- phase 4: y = conv2 + b2 + x --------------------------------------------------------------------------
   int* otab = reinterpret_cast<int*>(lds + OTAB_OFF);
-  if (tid < CBM) {
+  if (tid < MT) {
     const int li = tid / W1, lj = tid - li * W1;
     if constexpr (G2) {  // outputs = interior of the h grid, inside the image
       const int r = i0 - 1 + li, c = j0 - 1 + lj;
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
       } else {
         m = pr - d;
       }
-      if (pr < P && m >= 0 && m < CBM) {
+      if (pr < P && m >= 0 && m < MT) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           f32x4* s4 = reinterpret_cast<f32x4*>(smem + m * LDO + c * 32 + 4 * cg);
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
     __syncthreads();
   }
   {
-    constexpr int V = C / 4, RPP = NTHR / V, NPASS = CBM / RPP;
+    constexpr int V = C / 4, RPP = NTHR / V, NPASS = MT / RPP;
     const int c4 = tid % V, r0 = tid / V;
     const f32x4 bv = G2 ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
     int opix[NPASS];
@@ -513,22 +521,22 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_R
   }
 }
 
-static size_t resblock_lds_bytes(int C) {
-  const size_t h_end = (size_t)CBM * C * 4;                       // h overlays the patch buffers
-  const size_t epi_end = (size_t)CBM * (C + 4) * 4 + CBM * 4;
-  const size_t patches = (size_t)(C == 32 ? 1 : (C == 128 ? 3 : 2)) * CPATCH;  // one chunk: one buffer; four chunks: three
+static size_t resblock_lds_bytes(int C, int MT = CBM) {
+  const size_t h_end = (size_t)MT * C * 4;                       // h overlays the patch buffers
+  const size_t epi_end = (size_t)MT * (C + 4) * 4 + MT * 4;
+  const size_t patches = (size_t)(C == 32 ? 1 : (C == 128 ? 3 : 2)) * (MT + MT / 2) * CROW;  // one chunk: one buffer; four chunks: three
   return std::max(std::max(h_end, patches), epi_end);
 }
 
-template <int C, int NW, bool HI, bool G2 = false>
+template <int C, int NW, bool HI, bool G2 = false, int MT = 128>
 static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
-  const size_t lds = resblock_lds_bytes(C);
+  const size_t lds = resblock_lds_bytes(C, MT);
   static uint64_t attr_devices = 0;  // one static per instantiation
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI, G2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI, G2, MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   }
-  hipLaunchKernelGGL((k_resblock<C, NW, HI, G2>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
+  hipLaunchKernelGGL((k_resblock<C, NW, HI, G2, MT>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
 }
 
 bool resblock_supported(int C) { return C == 64 || C == 128; }
@@ -537,7 +545,7 @@ bool resblock_supported(int C) { return C == 64 || C == 128; }
 int resblock_block_waves(const ResBlockParams& hp) {
   if (hp.rw) return hp.tile_m / 32;
   if (hp.asrc || hp.r128) return 4;
-  if (hp.geo2d) return hp.C == 32 ? 2 : 4;
+  if (hp.geo2d) return (hp.C == 32 && hp.tile_m != 256) ? 2 : 4;
   return hp.C >= 128 ? 8 : 4;
 }
 bool block2d_supported(int C) { return C == 32 || C == 64; }
@@ -546,15 +554,22 @@ bool block2d_supported(int C) { return C == 32 || C == 64; }
 // wastes fewer pixels on the image borders, outputs = its interior, x patch = (TH + 2) x (W1 + 2).
 void plan_block2d(ResBlockParams& p) {
   VFX_CHECK(block2d_supported(p.C), "block2d: C=%d is not supported", p.C);
+  // the tile that computes the fewest h positions per image: 128 positions as 8 x 16 or 16 x 8 (6 x 14 outputs); at C = 32 also
+  // 256 positions as 16 x 16 (14 x 14 outputs: k_resblock<32, 4, .., MT = 256>; VFX_TUNE_SMALL_2D_TILES keeps the 128-position ones)
   double best = -1.0;
-  for (int W1 : {16, 8}) {
-    const int TH = 128 / W1, oh = TH - 2, ow = W1 - 2;
-    const double covered = (double)((p.H + oh - 1) / oh) * oh * ((p.W + ow - 1) / ow) * ow;
-    const double util = (double)p.H * p.W / covered;
+  p.tile_m = 0;
+  struct Cand { int TH, W1; };
+  std::vector<Cand> cands = {{8, 16}, {16, 8}};
+  if (p.C == 32 && !(p.tuning & VFX_TUNE_SMALL_2D_TILES)) cands.push_back({16, 16});
+  for (const Cand& c : cands) {
+    const int oh = c.TH - 2, ow = c.W1 - 2;
+    const double positions = (double)((p.H + oh - 1) / oh) * ((p.W + ow - 1) / ow) * c.TH * c.W1;  // h positions computed
+    const double util = (double)p.H * p.W / positions;
     if (util > best) {
       best = util;
-      p.W1 = W1;
-      p.TH = TH;
+      p.W1 = c.W1;
+      p.TH = c.TH;
+      p.tile_m = c.TH * c.W1 == 256 ? 256 : 0;
     }
   }
   p.geo2d = 1;
@@ -571,7 +586,8 @@ void plan_block2d(ResBlockParams& p) {
       p.poff9[dy * 3 + dx] = dy * p.PW + dx;                 // conv1: x patch rows of the tap, relative to the h pixel's row
       p.hoff9[dy * 3 + dx] = (dy - 1) * p.W1 + (dx - 1);    // conv2: h rows
     }
-  VFX_CHECK(p.P <= kPatchMaxRows && p.TH * p.W1 == CBM, "block2d: bad tile geometry");
+  const int MT2 = p.tile_m == 256 ? 256 : CBM;
+  VFX_CHECK(p.P <= MT2 + MT2 / 2 && p.TH * p.W1 == MT2, "block2d: bad tile geometry");
   VFX_CHECK((int64_t)p.B * p.H * p.W * p.C * 4 < ((int64_t)1 << 32) - 4096, "block2d: tensor exceeds 4 GiB");
 }
 
@@ -687,7 +703,8 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
     VFX_CHECK(!hp.hionly, "block2d: split-bf16 only");
     // C = 32: two waves of 64 pixels, not four of 32 -- every wave of a block fetches ALL the weight fragments, so fewer,
     // larger waves halve that traffic (measured -12 %; the timing-only build without weight refreshes ran this block 25 % faster)
-    if (hp.C == 32) launch_rb<32, 2, false, true>((int)grid, stream, dparams);
+    if (hp.C == 32 && hp.tile_m == 256) launch_rb<32, 4, false, true, 256>((int)grid, stream, dparams);
+    else if (hp.C == 32) launch_rb<32, 2, false, true>((int)grid, stream, dparams);
     else launch_rb<64, 4, false, true>((int)grid, stream, dparams);
     VFX_HIP(hipGetLastError());
     return;
