@@ -57,11 +57,12 @@ __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
 // MT = 256 (round 4; 2-D mode at C = 32 only: one 32-channel chunk = one patch buffer): h grid of 16 x 16 pixels, 14 x 14 outputs,
 // x patch 18 x 18 = 324 pixels -- the halo costs 1.31x recomputed h positions instead of 1.52x (8 x 16 / 16 x 8: 84 outputs per
 // 128) and 1.65 instead of 2.14 patch pixels per output.  Four waves of 64 pixels (the 128-position tile: two), 48 KB of LDS:
-// three blocks per CU = the same 12 waves per CU as six blocks of the small tile.  At C = 64 the two patch buffers would be
-// 96 KB (one 8-wave block per CU instead of three 4-wave ones): not built.
+// three blocks per CU = the same 12 waves per CU as six blocks of the small tile.  Measured (profiles/r04_c13_c64_tile16x16_ab.txt):
+// mel ResUNet 13.47 -> 13.23 ms, ssr_sr64 119.4 -> 116.5 ms, stream1s 2.50 -> 2.39 ms.  At C = 64 the two patch buffers are 96 KB,
+// i.e. one 8-wave block per CU instead of three 4-wave ones: built as a variant, measured +0.5 %, deleted.
 template <int C, int NW, bool HI, bool G2 = false, int MT = 128>
-__global__ __launch_bounds__(NW * 64, MT == 256 ? (NW == 8 ? 1 : 3) : (NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_RB_RING32 >= 5 ? 3 : 4) : 3) : (HI ? 4 : 2)))) void k_resblock(const ResBlockParams* __restrict__ pp) {
-  static_assert(MT == 128 || (MT == 256 && G2 && !HI && ((C == 32 && NW == 4) || (C == 64 && NW == 8))), "the 256-position tile exists for the 2-D blocks");
+__global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_RB_RING32 >= 5 ? 3 : 4) : 3) : (HI ? 4 : 2)))) void k_resblock(const ResBlockParams* __restrict__ pp) {
+  static_assert(MT == 128 || (MT == 256 && G2 && C == 32 && NW == 4 && !HI), "the 256-position tile exists for the C = 32 2-D block");
   constexpr int PMAX = MT + MT / 2;          // patch rows per buffer (192; 384 for the 18 x 18 patch of the 16 x 16 tile)
   constexpr int PBYTES = PMAX * CROW;        // bytes per patch buffer
   constexpr int KT = G2 ? 9 : 3;  // taps per convolution
@@ -545,7 +546,7 @@ bool resblock_supported(int C) { return C == 64 || C == 128; }
 int resblock_block_waves(const ResBlockParams& hp) {
   if (hp.rw) return hp.tile_m / 32;
   if (hp.asrc || hp.r128) return 4;
-  if (hp.geo2d) return (hp.C == 32 && hp.tile_m != 256) ? 2 : ((hp.C == 64 && hp.tile_m == 256) ? 8 : 4);
+  if (hp.geo2d) return (hp.C == 32 && hp.tile_m != 256) ? 2 : 4;
   return hp.C >= 128 ? 8 : 4;
 }
 bool block2d_supported(int C) { return C == 32 || C == 64; }
@@ -560,11 +561,7 @@ void plan_block2d(ResBlockParams& p) {
   p.tile_m = 0;
   struct Cand { int TH, W1; };
   std::vector<Cand> cands = {{8, 16}, {16, 8}};
-#ifdef VFX_RB_C64_T256  // experiment (round 4): the 16 x 16 tile at C = 64 as ONE 8-wave block per CU (two 48-KB patch buffers)
-  if (!(p.tuning & VFX_TUNE_SMALL_2D_TILES)) cands.push_back({16, 16});
-#else
   if (p.C == 32 && !(p.tuning & VFX_TUNE_SMALL_2D_TILES)) cands.push_back({16, 16});
-#endif
   for (const Cand& c : cands) {
     const int oh = c.TH - 2, ow = c.W1 - 2;
     const double positions = (double)((p.H + oh - 1) / oh) * ((p.W + ow - 1) / ow) * c.TH * c.W1;  // h positions computed
@@ -708,9 +705,7 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
     // C = 32: two waves of 64 pixels, not four of 32 -- every wave of a block fetches ALL the weight fragments, so fewer,
     // larger waves halve that traffic (measured -12 %; the timing-only build without weight refreshes ran this block 25 % faster)
     if (hp.C == 32 && hp.tile_m == 256) launch_rb<32, 4, false, true, 256>((int)grid, stream, dparams);
-#ifdef VFX_RB_C64_T256
-    else if (hp.C == 64 && hp.tile_m == 256) launch_rb<64, 8, false, true, 256>((int)grid, stream, dparams);
-#endif
+
     else if (hp.C == 32) launch_rb<32, 2, false, true>((int)grid, stream, dparams);
     else launch_rb<64, 4, false, true>((int)grid, stream, dparams);
     VFX_HIP(hipGetLastError());
