@@ -479,10 +479,14 @@ static double conv_algo_bytes(const TapConvParams& q) {
 // out = 4 bytes per element and layer.
 static double resblock_algo_bytes(const ResBlockParams& q) {
   const double n = (double)q.B * (q.geo2d ? (double)q.H * q.W : (double)q.T) * q.C;
+  if (q.in1) return n * 4.0 + n / q.C * 4.0;  // one input channel in, y out
+  if (q.two_src) return n * 12.0;                  // two sources in, y out
   return n * (q.x16 ? 4.0 : 8.0) * (q.dil2 > 0 ? 2.0 : 1.0);
 }
 static double resblock_design_bytes(const ResBlockParams& q) {
   const double n = (double)q.B * (q.geo2d ? (double)q.H * q.W : (double)q.T) * q.C;
+  if (q.in1) return n * 4.0 + n / q.C * 4.0;
+  if (q.two_src) return n * 12.0;
   if (q.x16) return n * 2.0 * ((q.x || q.xa ? 1.0 : 0.0) + (q.y ? 1.0 : 0.0) + (q.ya ? 1.0 : 0.0));  // one fp16 tensor in, y and / or ya out
   return n * 8.0 + (q.asrc ? n * 2.0 : 0.0) + (q.ya ? n * 2.0 : 0.0);  // x in, y out (+ the fp16 forms: xa in, ya out)
 }
@@ -671,6 +675,7 @@ void bind_plan(vfx_handle* h, Plan& plan) {
     std::vector<ResBlockParams> rb = plan.host_rb;
     for (auto& q : rb) {
       if (q.x) q.x = rebase(q.x);
+      if (q.x2) q.x2 = rebase(q.x2);
       if (q.y) q.y = const_cast<float*>(rebase(q.y));
       if (q.xa) q.xa = rebase(q.xa);
       if (q.ya) q.ya = const_cast<float*>(rebase(q.ya));

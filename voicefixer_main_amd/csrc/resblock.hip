@@ -60,9 +60,22 @@ __device__ __forceinline__ void wait_b_dyn(BFrag& R, int n) {
 // three blocks per CU = the same 12 waves per CU as six blocks of the small tile.  Measured (profiles/r04_c13_c64_tile16x16_ab.txt):
 // mel ResUNet 13.47 -> 13.23 ms, ssr_sr64 119.4 -> 116.5 ms, stream1s 2.50 -> 2.39 ms.  At C = 64 the two patch buffers are 96 KB,
 // i.e. one 8-wave block per CU instead of three 4-wave ones: built as a variant, measured +0.5 %, deleted.
-template <int C, int NW, bool HI, bool G2 = false, int MT = 128>
+// IN1 = true (round 4; 16 x 16 tiles only): the ENTRY block of a ResUNet, encoder_block1.conv_block1 -- Cin = 1, so conv1 is nine
+// multiply-adds per (pixel, channel) and the shortcut one (modules.py:223-271 with a 1x1 shortcut): every thread computes the 32
+// channels of one h pixel from an 18 x 18 single-channel patch and writes them to LDS in operand form (phases 1 + 2 without MFMA),
+// conv2 and the epilogue are the block's own, the residual is  wsc * x + bsc  of the raw input sample.  One launch reading 4 and
+// writing 128 bytes per pixel instead of k_conv_c1 (h and the shortcut out: 256 bytes) + k_conv (both back in, y out: 384).
+// SC2 = true (round 4; 16 x 16 tiles, C = 32): the FIRST block of decoder level 1 (decoder_block6.conv_block2: x = cat(upsampled,
+// skip), 64 -> 32 channels, 1x1 shortcut with bias).  conv1 runs over the two sources as two 32-channel chunks through the ONE patch
+// buffer (a second one would leave one block per CU), conv2 is the block's own, and the shortcut is one more K segment AFTER conv2:
+// the raw centre pixels of each source come in again (L2), are split without activation and multiplied by the shortcut's fragment
+// group.  12 bytes per element through HBM instead of the 28 of the two k_conv launches (h out and back in, the sources twice).
+template <int C, int NW, bool HI, bool G2 = false, int MT = 128, bool IN1 = false, bool SC2 = false>
 __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? (C == 32 ? (VFX_RB_RING32 >= 5 ? 3 : 4) : 3) : (HI ? 4 : 2)))) void k_resblock(const ResBlockParams* __restrict__ pp) {
   static_assert(MT == 128 || (MT == 256 && G2 && C == 32 && NW == 4 && !HI), "the 256-position tile exists for the C = 32 2-D block");
+  static_assert(!IN1 || MT == 256, "the entry block runs 16 x 16 tiles");
+  static_assert(!SC2 || (MT == 256 && !IN1), "the two-source block runs 16 x 16 tiles");
+  constexpr int IN1_OFF = 40960;  // IN1: the activated 18 x 18 input patch (fp32), behind h (32 KB) and the staged output (37.9 KB)
   constexpr int PMAX = MT + MT / 2;          // patch rows per buffer (192; 384 for the 18 x 18 patch of the 16 x 16 tile)
   constexpr int PBYTES = PMAX * CROW;        // bytes per patch buffer
   constexpr int KT = G2 ? 9 : 3;  // taps per convolution
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   constexpr int NBUF = (NCH == 4 && !G2) ? 3 : 2;  // patch buffers (chunks in flight / in use)
   constexpr int HROW = C * 4;         // bytes per h row
   constexpr int H_OFF = 0;            // h overlays the patch buffers (dead once conv1 is done): less LDS, more blocks per CU
-  constexpr int NT1 = KT * NCH;       // taps of conv1 (chunk-major); conv2 has as many
+  constexpr int NT1 = SC2 ? 2 * KT : KT * NCH;  // taps of conv1 (chunk-major; SC2: two source chunks); conv2 has KT * NCH
   constexpr int LDO = C + 4;          // staged output row (floats)
   constexpr int OTAB_OFF = MT * LDO * 4;
   // The residual: the epilogue's re-read of x finds its lines evicted from L2 (the HBM-bound C = 64 stack moves 5.0 GB per
@@ -181,8 +194,8 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   // ---- x patch: LDS-DMA request and in-place transform (cf. conv.hip) -------------------------------------
   auto issue_patch = [&](int c, int dst) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + c * kKC), 0,
-        (int)(unsigned)((int64_t)p.B * (G2 ? (int64_t)Hh * Ww : (int64_t)T) * C * 4 - (int64_t)c * kKC * 4), 0x00020000);
+        const_cast<float*>(SC2 ? (c == 0 ? p.x : p.x2) : p.x + c * kKC), 0,
+        (int)(unsigned)((int64_t)p.B * (G2 ? (int64_t)Hh * Ww : (int64_t)T) * C * 4 - (SC2 ? 0 : (int64_t)c * kKC * 4)), 0x00020000);
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       const unsigned o = (okmask & (1u << q)) ? voff[q] + 16u * cg : 0xfffffff0u;
@@ -203,13 +216,13 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
     unsigned f16_sat = 0;  // 16-bit mode: a value left the fp16 range and was clamped (reported per patch)
 #pragma unroll
     for (int q = 0; q < NG; ++q)
-      if (q * RG < MT || q < nq) {
+      if (MT == 256 ? q * RG < 18 * 18 : (q * RG < MT || q < nq)) {
         raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
         if constexpr (KEEPRES) keep[c][q] = raw[q];
       }
 #pragma unroll
     for (int q = 0; q < NG; ++q)
-      if (q * RG < MT || q < nq) {
+      if (MT == 256 ? q * RG < 18 * 18 : (q * RG < MT || q < nq)) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -296,6 +309,9 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   };
   auto fetch = [&](int g) __attribute__((always_inline)) {
     const float* w = g < NT1 ? p.w1 + g * ts : (g < 2 * NT1 ? p.w2 + (g - NT1) * ts : p.w2 + (NT1 - 1) * ts);
+    if constexpr (SC2)  // conv1 of source 0, of source 1, conv2, the two shortcut groups
+      w = g < KT ? p.w1 + g * ts
+                 : (g < 2 * KT ? p.w1x2 + (g - KT) * ts : (g < 3 * KT ? p.w2 + (g - 2 * KT) * ts : (g == 3 * KT ? p.wsc : p.wsc2)));
 #ifdef VFX_RB_ABL_NOWEIGHTS  // timing-only build (wrong results): the weight ring is filled once and never refreshed
     if (g >= RING) return;
 #endif
@@ -326,6 +342,105 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   // request, which is therefore never drained early.
   // (Requesting both patches of a two-chunk block up front was measured: -3 % on the C = 64 stack -- the stack moves
   // ~5 GB per layer through the fabric at ~4.9 TB/s, it is bandwidth-, not latency-bound.)
+  if constexpr (IN1) {
+    // conv2's first taps are on their way while conv1 is computed
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) fetch(NT1 + g);
+    float* pa = reinterpret_cast<float*>(lds + IN1_OFF);
+    const float s1 = p.in1_scale, t1 = p.in1_shift;
+    for (int e = tid; e < 18 * 18; e += NTHR) {  // patch pixel (pi, pj) = image pixel (i0 - 2 + pi, j0 - 2 + pj)
+      const int pi = e / 18, pj = e - pi * 18;
+      const int r = i0 - 2 + pi, c = j0 - 2 + pj;
+      float v = 0.f;  // zero padding AFTER bn1 + LeakyReLU
+      if (((unsigned)r < (unsigned)Hh) & ((unsigned)c < (unsigned)Ww)) {
+        const float t = *(const VFX_GLOBAL float*)(p.x + ((int64_t)img * Hh + r) * Ww + c) * s1 + t1;
+        v = fmaxf(t, t * slope);
+      }
+      pa[e] = v;
+    }
+    __syncthreads();
+    {
+      const int m = tid, li = m >> 4, lj = m & 15;  // h pixel (li, lj) = image pixel (i0 - 1 + li, j0 - 1 + lj)
+      const bool ok = ((unsigned)(i0 - 1 + li) < (unsigned)Hh) & ((unsigned)(j0 - 1 + lj) < (unsigned)Ww);
+      float a9[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a9[k] = pa[(li + k / 3) * 18 + lj + k % 3];
+      char* rowp = lds + H_OFF + m * HROW;
+      const int key = (m >> 1) & 7;
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {  // 8 channels = one 16-byte piece of hi and one of lo halves
+        f32x4 u[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const f32x4 w = *(const VFX_GLOBAL f32x4*)(p.w1 + k * 32 + 8 * pc + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = fmaf(a9[k], w[e], s[e]);
+          }
+          const f32x4 hsc = *(const VFX_GLOBAL f32x4*)(p.sc2 + 8 * pc + 4 * hh);
+          const f32x4 hsh = *(const VFX_GLOBAL f32x4*)(p.sh2 + 8 * pc + 4 * hh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = s[e] * hsc[e] + hsh[e];
+            u[hh][e] = ok ? fmaxf(t, t * slope) : 0.f;
+          }
+        }
+        u32x4 hi, lo;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u[hh][0], u[hh][1]}, bf16x2));
+          const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{u[hh][2], u[hh][3]}, bf16x2));
+          const f32x2 r01 = {u[hh][0] - __builtin_bit_cast(float, h01 << 16), u[hh][1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+          const f32x2 r23 = {u[hh][2] - __builtin_bit_cast(float, h23 << 16), u[hh][3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+          hi[2 * hh] = h01;
+          hi[2 * hh + 1] = h23;
+          lo[2 * hh] = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
+          lo[2 * hh + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
+        }
+        *reinterpret_cast<u32x4*>(rowp + ((pc ^ key) << 4)) = hi;
+        *reinterpret_cast<u32x4*>(rowp + (((pc + 4) ^ key) << 4)) = lo;
+      }
+    }
+    drain();
+    __syncthreads();  // h is complete
+  } else {
+  if constexpr (SC2) {
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) fetch(g);
+    issue_patch(0, 0);
+    drain();
+    transform_patch(0, 0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      __syncthreads();  // the patch of source c is visible
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int g = KT * c + k;
+        fetch(g + AHEAD);
+        if (k >= AHEAD) wait_b_dyn<NG, WL, HI>(ring(g), WL * AHEAD);  // the first AHEAD taps of a chunk landed with the drain before it
+        int rows[WM], kov[WM];
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+          rows[a] = arow1[a] + p.poff9[k];
+          int k0 = kq0[a];
+          asm volatile("" : "+v"(k0));
+          kov[a] = ((k0 + hW1 * (k / 3) + (k % 3 == 2 ? 1 : 0) + (k % 3 == 1 ? kpar[a] : 0)) & 7) << 4;
+        }
+        mma(ring(g), lds, CROW, rows, -1, kov, true);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      drain();
+      if (c == 0) {
+        __syncthreads();  // every wave is done with source 0's patch: source 1 goes into the same buffer
+        issue_patch(1, 0);
+        drain();
+        transform_patch(0, 1);
+      }
+    }
+    __syncthreads();  // every wave is done reading the patch buffer that h overlays
+  } else {
 #pragma unroll
   for (int g = 0; g < AHEAD; ++g) fetch(g);
   issue_patch(0, 0);
@@ -368,6 +483,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   }
 
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
+  }  // !SC2
 
   // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------
   // Lane (l31, lh) of M block a holds h pixel m = (wm*WM + a)*32 + l31 and, in registers 4j .. 4j+3, channels
@@ -408,6 +524,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   }
   if constexpr (HI) report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
   __syncthreads();  // h is complete
+  }  // !IN1
 
   // ---- phase 3: conv2 from the resident h ------------------------------------------------------------------
 #pragma unroll
@@ -428,6 +545,55 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
     }
   drain();
   __syncthreads();  // every wave is done with h and the patch buffers
+
+  // ---- phase 3b (SC2): + shortcut(cat(x, x2)), a 1x1 convolution of the RAW sources -- one more 32-channel K segment per source ----
+  if constexpr (SC2) {
+    constexpr int NG2 = MT / RG;  // DMA instructions per wave: the tile's MT h-grid pixels, one 128-byte row each
+    unsigned voff2[NG2], ok2 = 0;
+#pragma unroll
+    for (int q = 0; q < NG2; ++q) {  // row m = lr + RG q = h pixel (m / 16, m % 16) = image pixel (i0 - 1 + li, j0 - 1 + lj)
+      const int m = lr + RG * q, li = m >> 4, lj = m & 15;
+      const int r = i0 - 1 + li, c = j0 - 1 + lj;
+      voff2[q] = (unsigned)((img * Hh + r) * Ww + c) * (unsigned)(C * 4);
+      ok2 |= (((unsigned)r < (unsigned)Hh) & ((unsigned)c < (unsigned)Ww)) ? (1u << q) : 0u;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(sidx == 0 ? p.x : p.x2), 0, (int)(unsigned)((int64_t)p.B * Hh * Ww * C * 4), 0x00020000);
+#pragma unroll
+      for (int q = 0; q < NG2; ++q) {
+        const unsigned o = (ok2 & (1u << q)) ? voff2[q] + 16u * cg : 0xfffffff0u;
+        VFX_LDS void* l = (VFX_LDS void*)(lds + (RG * q + 8 * wave_u) * CROW);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)o, 0, 0, 0);
+      }
+      drain();  // this wave's rows are its own threads' rows
+      {
+        char* row0 = lds + lr * CROW;
+        f32x4 raw[NG2];
+#pragma unroll
+        for (int q = 0; q < NG2; ++q) raw[q] = *reinterpret_cast<const f32x4*>(row0 + RG * q * CROW + 16 * cg);
+#pragma unroll
+        for (int q = 0; q < NG2; ++q) {  // hi/lo split of the raw values, row-linear swizzle key (rows lr + 32 q share it)
+          const f32x4 v = raw[q];
+          const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+          const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          const f32x2 r01 = {v[0] - __builtin_bit_cast(float, h01 << 16), v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+          const f32x2 r23 = {v[2] - __builtin_bit_cast(float, h23 << 16), v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+          const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
+          const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
+          char* rowp = row0 + RG * q * CROW;
+          const int half = 8 * (cg & 1);
+          *reinterpret_cast<uint2*>(rowp + (((cg >> 1) ^ key_l) << 4) + half) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(rowp + ((((cg >> 1) + 4) ^ key_l) << 4) + half) = make_uint2(l01, l23);
+        }
+      }
+      __syncthreads();  // the source's centre rows are in operand form
+      mma(ring(NT1 + KT + sidx), lds, CROW, arow2, -1, arow2, false);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // every wave is done with them (the next source / the staged output goes over them)
+    }
+  }
 
   // ---- phase 4: y = conv2 + b2 + x --------------------------------------------------------------------------
   int* otab = reinterpret_cast<int*>(lds + OTAB_OFF);
@@ -479,7 +645,10 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   {
     constexpr int V = C / 4, RPP = NTHR / V, NPASS = MT / RPP;
     const int c4 = tid % V, r0 = tid / V;
-    const f32x4 bv = G2 ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4);
+    const f32x4 bv = (IN1 || SC2) ? *(const VFX_GLOBAL f32x4*)(p.bsc + 4 * c4)
+                         : (G2 ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * c4));
+    f32x4 wsv = {0.f, 0.f, 0.f, 0.f};  // entry block: the 1x1 shortcut of the single input channel
+    if constexpr (IN1) wsv = *(const VFX_GLOBAL f32x4*)(p.wsc + 4 * c4);
     int opix[NPASS];
     f32x4 val[NPASS], res[NPASS];
 #pragma unroll
@@ -488,9 +657,17 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
       val[q] = *reinterpret_cast<const f32x4*>(smem + (r0 + q * RPP) * LDO + 4 * c4) + bv;
     }
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q)
-      res[q] = KEEPRES ? f32x4{0.f, 0.f, 0.f, 0.f}  // already added in LDS
-                       : *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * C + 4 * c4);
+    for (int q = 0; q < NPASS; ++q) {
+      if constexpr (IN1) {
+        const float xv = *(const VFX_GLOBAL float*)(p.x + (opix[q] < 0 ? 0 : opix[q]));
+        res[q] = f32x4{xv * wsv[0], xv * wsv[1], xv * wsv[2], xv * wsv[3]};
+      } else if constexpr (SC2) {
+        res[q] = f32x4{0.f, 0.f, 0.f, 0.f};  // the shortcut is in the accumulators
+      } else {
+        res[q] = KEEPRES ? f32x4{0.f, 0.f, 0.f, 0.f}  // already added in LDS
+                         : *(const VFX_GLOBAL f32x4*)(p.x + (int64_t)(opix[q] < 0 ? 0 : opix[q]) * C + 4 * c4);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) val[q] += res[q];
 #pragma unroll
@@ -529,15 +706,15 @@ static size_t resblock_lds_bytes(int C, int MT = CBM) {
   return std::max(std::max(h_end, patches), epi_end);
 }
 
-template <int C, int NW, bool HI, bool G2 = false, int MT = 128>
+template <int C, int NW, bool HI, bool G2 = false, int MT = 128, bool IN1 = false, bool SC2 = false>
 static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
   const size_t lds = resblock_lds_bytes(C, MT);
   static uint64_t attr_devices = 0;  // one static per instantiation
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI, G2, MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI, G2, MT, IN1, SC2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   }
-  hipLaunchKernelGGL((k_resblock<C, NW, HI, G2, MT>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
+  hipLaunchKernelGGL((k_resblock<C, NW, HI, G2, MT, IN1, SC2>), dim3(grid), dim3(NW * 64), lds, stream, dparams);
 }
 
 bool resblock_supported(int C) { return C == 64 || C == 128; }
@@ -562,6 +739,10 @@ void plan_block2d(ResBlockParams& p) {
   struct Cand { int TH, W1; };
   std::vector<Cand> cands = {{8, 16}, {16, 8}};
   if (p.C == 32 && !(p.tuning & VFX_TUNE_SMALL_2D_TILES)) cands.push_back({16, 16});
+  if (p.in1 || p.two_src) {  // the entry block (Cin = 1) and the two-source block exist on 16 x 16 tiles only
+    VFX_CHECK(p.C == 32 && !(p.tuning & VFX_TUNE_SMALL_2D_TILES), "block2d: the entry / two-source block runs C = 32 on 16 x 16 tiles");
+    cands = {{16, 16}};
+  }
   for (const Cand& c : cands) {
     const int oh = c.TH - 2, ow = c.W1 - 2;
     const double positions = (double)((p.H + oh - 1) / oh) * ((p.W + ow - 1) / ow) * c.TH * c.W1;  // h positions computed
@@ -590,6 +771,7 @@ void plan_block2d(ResBlockParams& p) {
   const int MT2 = p.tile_m == 256 ? 256 : CBM;
   VFX_CHECK(p.P <= MT2 + MT2 / 2 && p.TH * p.W1 == MT2, "block2d: bad tile geometry");
   VFX_CHECK((int64_t)p.B * p.H * p.W * p.C * 4 < ((int64_t)1 << 32) - 4096, "block2d: tensor exceeds 4 GiB");
+  VFX_CHECK(!(p.in1 || p.two_src) || p.tile_m == 256, "block2d: entry / two-source block tile");
 }
 
 // Fills the tile geometry of a fused ResStack layer (B, T, C, dil must be set).
@@ -704,8 +886,9 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
     VFX_CHECK(!hp.hionly, "block2d: split-bf16 only");
     // C = 32: two waves of 64 pixels, not four of 32 -- every wave of a block fetches ALL the weight fragments, so fewer,
     // larger waves halve that traffic (measured -12 %; the timing-only build without weight refreshes ran this block 25 % faster)
-    if (hp.C == 32 && hp.tile_m == 256) launch_rb<32, 4, false, true, 256>((int)grid, stream, dparams);
-
+    if (hp.in1) launch_rb<32, 4, false, true, 256, true>((int)grid, stream, dparams);
+    else if (hp.two_src) launch_rb<32, 4, false, true, 256, false, true>((int)grid, stream, dparams);
+    else if (hp.C == 32 && hp.tile_m == 256) launch_rb<32, 4, false, true, 256>((int)grid, stream, dparams);
     else if (hp.C == 32) launch_rb<32, 2, false, true>((int)grid, stream, dparams);
     else launch_rb<64, 4, false, true>((int)grid, stream, dparams);
     VFX_HIP(hipGetLastError());
@@ -722,6 +905,8 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
 }
 
 double resblock_flops(const ResBlockParams& hp) {
+  if (hp.in1) return 2.0 * (double)hp.B * hp.T * hp.C * 9.0 * (1.0 + hp.C);  // conv1 has one input channel
+  if (hp.two_src) return 2.0 * (double)hp.B * hp.T * hp.C * (9.0 * 3.0 * hp.C + 2.0 * hp.C);  // conv1 over 2 C, conv2, the 1x1 shortcut
   return (hp.dil2 > 0 ? 2.0 : 1.0) * 2.0 * 2.0 * (double)hp.B * hp.T * hp.C * ((hp.geo2d ? 9.0 : 3.0) * hp.C);  // pairs: two layers
 }
 

@@ -233,6 +233,36 @@ struct TrunkBuilder {
       pb.add_resblock(rp);
       return y;
     }
+    // The two-source block with a 1x1 shortcut at C = 32 (decoder_block6.conv_block2): one launch too (resblock.hip, SC2)
+#ifndef VFX_ABL_NO_SC2
+    if (fuse2d && srcs && nsrc == 2 && w.shortcut && w.cout == 32 && srcs[0].C == 32 && srcs[1].C == 32 &&
+        pb.h->cfg.precision != 0 && !(pb.h->cfg.tuning & VFX_TUNE_SMALL_2D_TILES)) {
+      Act4 y = make(g.H, g.W, w.cout);
+      ResBlockParams rp{};
+      rp.geo2d = 1;
+      rp.two_src = 1;
+      rp.x = rel_ptr(srcs[0].off);
+      rp.x2 = rel_ptr(srcs[1].off);
+      rp.y = const_cast<float*>(rel_ptr(y.off));
+      rp.w1 = w.w1[0];
+      rp.w1x2 = w.w1[1];
+      rp.w2 = w.w2;
+      rp.wsc = w.wsc[0];
+      rp.wsc2 = w.wsc[1];
+      rp.bsc = w.bsc;
+      rp.sc1 = w.bn1_scale;
+      rp.sh1 = w.bn1_shift;
+      rp.sc2 = w.bn2_scale;
+      rp.sh2 = w.bn2_shift;
+      rp.slope = kSlope;
+      rp.B = B;
+      rp.H = g.H;
+      rp.W = g.W;
+      rp.C = w.cout;
+      pb.add_resblock(rp);
+      return y;
+    }
+#endif
     Act4 hbuf;
     if (pre_h) {
       hbuf = *pre_h;
@@ -409,7 +439,38 @@ struct TrunkBuilder {
     const UNetWeights* wp = &Wt;
     const int Bc = B;
     Act4 skips[6];
-    // encoder_block1.conv_block1 (Cin = 1)
+    // encoder_block1.conv_block1 (Cin = 1): one launch of the fused block's entry form (resblock.hip, IN1), or -- fp32 mode,
+    // VFX_TUNE_NO_FUSED_UNET / VFX_TUNE_SMALL_2D_TILES -- k_conv_c1 (conv1 and the shortcut) + k_conv (conv2)
+    Act4 y;
+    const int tun = pb.h->cfg.tuning;
+#ifdef VFX_ABL_NO_IN1  // measurement builds (scripts/build_variant.sh)
+    const bool entry_fused = false;
+#else
+    const bool entry_fused = !(tun & (VFX_TUNE_NO_FUSED_UNET | VFX_TUNE_SMALL_2D_TILES)) && pb.h->cfg.precision != 0;
+#endif
+    if (entry_fused) {
+      y = make(Tpad, W0, 32);
+      const ConvBlockW& w = Wt.enc[0][0];
+      ResBlockParams rp{};
+      rp.geo2d = 1;
+      rp.in1 = 1;
+      rp.x = rel_ptr(x_off);
+      rp.y = const_cast<float*>(rel_ptr(y.off));
+      rp.w1 = Wt.c1_w;
+      rp.w2 = w.w2;
+      rp.in1_scale = Wt.c1_scale;
+      rp.in1_shift = Wt.c1_shift;
+      rp.wsc = Wt.c1_wsc;
+      rp.bsc = Wt.c1_bsc;
+      rp.sc2 = w.bn2_scale;
+      rp.sh2 = w.bn2_shift;
+      rp.slope = kSlope;
+      rp.B = B;
+      rp.H = Tpad;
+      rp.W = W0;
+      rp.C = 32;
+      pb.add_resblock(rp);
+    } else {
     Act4 h1 = make(Tpad, W0, 32), sc1 = make(Tpad, W0, 32);
     {
       const size_t ho = h1.off, so = sc1.off;
@@ -419,9 +480,10 @@ struct TrunkBuilder {
                        reinterpret_cast<float*>(pl->bound_base + so), c.stream);
       });
     }
-    Act4 y = conv_block(Wt.enc[0][0], nullptr, 0, &h1, &sc1);
+    y = conv_block(Wt.enc[0][0], nullptr, 0, &h1, &sc1);
     pb.free(h1.off);
     pb.free(sc1.off);
+    }
     for (int l = 0; l < 6; ++l) {
       for (int j = (l == 0 ? 1 : 0); j < 4; ++j) {
         Act4 y2 = conv_block(Wt.enc[l][j], &y, 1);

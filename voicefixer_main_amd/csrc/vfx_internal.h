@@ -231,6 +231,18 @@ struct ResBlockParams {
   const float* sh1;
   const float* sc2;  // bn2 scale / shift [C]: prologue of conv2, applied to h
   const float* sh2;
+  // entry block (k_resblock<.., IN1>): x is the single-channel input plane (B, H, W), w1 the [tap][32] conv1 weights, bn1 the
+  // scalar affine below, wsc / bsc the 1x1 shortcut (weight and bias per output channel); sc1 / sh1 are unused
+  int in1;
+  float in1_scale, in1_shift;
+  const float* wsc;
+  const float* bsc;
+  // two-source block (k_resblock<.., SC2>; decoder level 1): the input is cat(x, x2) (C channels each), w1 / w1x2 the conv1 weights
+  // of the two sources, sc1 / sh1 hold 2 C channels, wsc / wsc2 the fragment-packed 1x1 shortcut of each source, bsc its bias
+  int two_src;
+  const float* x2;
+  const float* w1x2;
+  const float* wsc2;
   int poff9[9];      // conv1: patch row offset of tap (dy, dx)
   int hoff9[9];      // conv2: h row offset of tap (dy, dx)
   // set by plan_resblock: multiply-shift reciprocals, n / d = (n * inv) >> 20 (exact for n < 512, d <= 320), and the tile ->
