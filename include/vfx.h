@@ -51,7 +51,8 @@ enum {
 enum {
   VFX_TUNE_NO_FUSED_STACKS = 1,    /* vocoder ResStack layers (C = 64, 128) as two tap-convolution launches per layer */
   VFX_TUNE_NO_FUSED_WIDE = 2,      /* ... the C = 256 layers of the 16-bit mode as two launches per layer (two-form trunk) */
-  VFX_TUNE_NO_FUSED_UNET = 4,      /* identity-shortcut ConvBlockRes of the ResUNets (C = 32, 64) as two launches */
+  VFX_TUNE_NO_FUSED_UNET = 4,      /* ConvBlockRes of the ResUNets as two launches each (fused: the identity-shortcut blocks at
+                                      C = 32, 64, the entry block and the two-source block of the full-resolution level) */
   VFX_TUNE_NO_PERSISTENT_C64 = 8,  /* 16-bit mode, C = 64 layers on k_resblock instead of the persistent kernel */
   VFX_TUNE_NO_PAIRS = 16,          /* 16-bit mode, C = 64 / 128: one launch per layer (no layer pairs) */
   VFX_TUNE_NO_SPLITK = 32,         /* no split-K in the deep ResUNet levels */
@@ -59,7 +60,8 @@ enum {
                                       between the layers (the round-3 form: 8 - 12 bytes per element and layer) instead of
                                       fp16 (4 bytes per element and layer; the sums themselves are fp32 in registers either way) */
   VFX_TUNE_SMALL_2D_TILES = 128    /* fused ConvBlockRes of the ResUNets at C = 32: 8 x 16 / 16 x 8 h tiles (84 outputs per 128 positions)
-                                      instead of 16 x 16 (196 per 256) */
+                                      instead of 16 x 16 (196 per 256); the entry block (Cin = 1) and the two-source block of that
+                                      level, which exist on 16 x 16 tiles only, as two launches each */
 };
 
 typedef struct vfx_config {

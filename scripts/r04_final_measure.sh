@@ -7,7 +7,6 @@ tag=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/$tag
 mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; tail -n 3 $O/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -n 3 $O/smoke.log
 # same-box A/B: the round-3 HEAD (its own tree and library under _ab_r03/) and this tree, alternating, identical flags
 if [ -d _ab_r03 ]; then
@@ -35,4 +34,8 @@ bash scripts/pmc_passes.sh $O/pmc --precision 2
 python scripts/pmc_report.py $O/pmc 150 > $O/pmc_report.txt 2>&1; head -n 45 $O/pmc_report.txt
 rm -rf $O/pmc/*/*.db $O/pmc/*/*/*.db $O/prof   # the databases are large; the reports stay
 grep -c . $O/smi.txt; grep "GPU use (%): 100" $O/smi.txt | tail -n 3 | cut -c1-400
+# the GPU suite LAST (the measurements above are what a short budget must not lose); VFX_FINAL_TESTS=0 skips it
+if [ "${VFX_FINAL_TESTS:-1}" != 0 ]; then
+  timeout ${VFX_FINAL_TESTS_TIMEOUT:-1500} python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; tail -n 3 $O/gpu_tests.log
+fi
 ls $O
