@@ -468,7 +468,7 @@ static double conv_algo_bytes(const TapConvParams& q) {
   }
   if (q.residual) b += out_px * q.Cout * 4.0;
   if (q.residual_act) b += out_px * q.Cout * 2.0;
-  if (q.out) b += out_px * q.Cout * 4.0;
+  if (q.out) b += out_px * (q.out_cmul ? q.out_cmul : q.Cout) * 4.0;
   if (q.out_act) b += out_px * q.Cout * (q.hionly ? 2.0 : 4.0);
   return b;
 }
@@ -534,7 +534,7 @@ void PlanBuilder::add_conv(TapConvParams p) {
       const TapConvParams& q = pl->host_params[idx];
       int K = 0;
       for (int s2 = 0; s2 < q.nseg; ++s2) K += q.seg[s2].ntaps * q.seg[s2].C;
-      const int64_t n = (int64_t)q.B * q.out_img_stride * q.Cout;
+      const int64_t n = (int64_t)q.B * q.out_img_stride * (q.out_cmul ? q.out_cmul : q.Cout);
       debug_scan(pl, "conv out", idx, q.out, n, q.M, q.Cout, K, c.stream);
       debug_scan(pl, "conv out_act", idx, q.out_act, n, q.M, q.Cout, K, c.stream);
     }
@@ -547,6 +547,9 @@ void PlanBuilder::add_conv_phased(TapConvParams p, const std::vector<TapSeg>& ph
   p.nphase = (int)phases.size();
   p.cout_phase = p.Cout / p.nphase;
   VFX_CHECK(p.cout_phase % 32 == 0, "phased conv: %d couts per phase", p.cout_phase);
+  VFX_CHECK(!p.out_cmul || (p.out_cmul == p.cout_phase && p.nphase == 2 && p.sw == 2 && p.ow0 == 0 && !p.residual && !p.residual_act &&
+                            !p.out_act && p.out && !p.bias),
+            "phased conv: bad odd-width launch");
   const size_t idx = plan->host_params.size();
   plan->phase_segs[idx] = phases;
   add_conv(p);

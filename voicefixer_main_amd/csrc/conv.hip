@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     if (li < TH && i < p.Hg && j < p.Wg) {
       const int oh = i * p.sh + p.oh0, ow = j * p.sw + p.ow0;
       const int o = oh * p.Wo + ow;
-      if (oh < p.Ho && ow < p.Wo && o < p.out_limit) idx = img * p.out_img_stride + o;
+      // (out_cmul: phase r of an odd-width phased launch writes true column ow + r)
+      if (oh < p.Ho && ow + (p.out_cmul ? phase : 0) < p.Wo && o < p.out_limit) idx = img * p.out_img_stride + o;
     }
     otab[tid] = idx;
   }

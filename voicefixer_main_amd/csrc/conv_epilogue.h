@@ -115,7 +115,7 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
     if (p.out) {
 #pragma unroll
       for (int q = 0; q < NPASS; ++q)
-        if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out + (int64_t)opix[q] * Cout + ncol) = val[q];
+        if (opix[q] >= 0) *(VFX_CE_GLOBAL ce_f32x4*)(p.out + (int64_t)opix[q] * (p.out_cmul ? p.out_cmul : Cout) + ncol) = val[q];
     }
     if (p.out_act) {
       bool f16_sat = false;  // 16-bit mode: an activation left the fp16 range and was clamped (VFX_FLAG_F16_SATURATED)

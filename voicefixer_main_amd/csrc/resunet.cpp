@@ -401,6 +401,47 @@ struct TrunkBuilder {
       }
       return y;
     }
+#ifndef VFX_ABL_NO_ODD_PHASED
+    if (!prune_w && x.H >= 2 && x.W >= 2 && !(pb.h->cfg.tuning & VFX_TUNE_NO_FUSED_UNET)) {
+      // An odd output width (2 W + 1: the mel ResUNet) has no such view, but the same two launches: the output is addressed in
+      // units of C channels at the TRUE pixel index (TapConvParams::out_cmul), column class 1 one column short.
+      for (int a = 0; a < 2; ++a) {
+        TapConvParams p{};
+        p.B = B;
+        p.Hi = x.H;
+        p.Wi = x.W;
+        p.Ho = y.H;
+        p.Wo = y.W;
+        p.Cout = 2 * D.cout;
+        p.out_cmul = D.cout;
+        p.sh = 2;
+        p.sw = 2;
+        p.oh0 = a;
+        p.ow0 = 0;
+        p.Hg = (y.H - a + 1) / 2;
+        p.Wg = x.W + 1;  // column class 0 has W + 1 columns, class 1 W
+        p.out = const_cast<float*>(rel_ptr(y.off));
+        p.act_slope = 1.f;
+        p.nseg = 1;
+        std::vector<TapSeg> phases(2);
+        for (int b = 0; b < 2; ++b) {
+          TapSeg& S = phases[b];
+          S = TapSeg{};
+          S.src = rel_ptr(x.off);
+          S.C = x.C;
+          S.scale = D.bn_scale;
+          S.shift = D.bn_shift;
+          S.act = ACT_LEAKY;
+          S.slope = 0.f;  // ReLU
+          S.wt = D.wT[a * 2 + b];
+          parity_taps(S, a, b);
+        }
+        p.seg[0] = phases[0];
+        pb.add_conv_phased(p, phases);
+      }
+      return y;
+    }
+#endif
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b) {
         TapConvParams p{};

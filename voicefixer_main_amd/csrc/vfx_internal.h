@@ -145,6 +145,12 @@ struct TapConvParams {
   // weight tensor.  With the output viewed as (B, T, nphase * cout_phase) this IS ConvTranspose1d's (B, T * nphase,
   // cout_phase): the input patch is fetched from HBM once for all phases.  nphase = 0 / 1: ordinary launch.
   int nphase, cout_phase;
+  // Phased launch onto an ODD output width (round 4: the mel ResUNet's upsamplers, output width 2 W + 1): the two column classes
+  // of one output row class cannot be viewed as channel halves of a (B, H, W', 2 C) tensor -- rows of 2 W + 1 pixels do not split
+  // into pairs -- so the output is addressed in units of out_cmul = C channels: pixel index (oh * Wo + 2 j) of the TRUE tensor,
+  // phase r at channel offset r * C, i.e. at true column 2 j + r; phase 1 has one column fewer (masked: ow + r < Wo).
+  // 0 = ordinary addressing (pixel index * Cout).  No residual, activated output or split-K with it.
+  int out_cmul;
   double flops_override;  // algorithmic flops when they are not 2 * M * Cout * K (phased launches)
   const float* bias;     // [Cout] or nullptr
   const float* residual; // (B, Ho, Wo, Cout) or nullptr, added in the epilogue
