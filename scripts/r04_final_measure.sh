@@ -30,6 +30,10 @@ timeout 200 python scripts/bench_handler.py --precision=2 > $O/handler_p2.json 2
 ( cd /tmp; export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace --stats -d "$ROOT/$O/prof" -o $tag -- \
     python "$ROOT/bench.py" --steps 5 --warmup 2 --no-alt --no-aux --cpu-baseline-clips 0 --traffic off --no-parity > "$ROOT/$O/prof.log" 2>&1; echo "prof rc=$?" )
 python scripts/prof_steps.py $(ls $O/prof/*/*_results.db $O/prof/*_results.db 2>/dev/null | head -1) --csv $O/kernel_stats.csv > $O/kernel_stats.txt 2>&1; head -n 16 $O/kernel_stats.txt
+( cd /tmp; export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace --stats -d "$ROOT/$O/prof_ssr" -o ${tag}_ssr -- \
+    python "$ROOT/bench.py" --workload ssr_sr64 --steps 3 --warmup 1 --no-alt --no-aux --cpu-baseline-clips 0 --traffic off --no-parity --no-roofline > "$ROOT/$O/prof_ssr.log" 2>&1; echo "prof ssr rc=$?" )
+python scripts/prof_steps.py $(ls $O/prof_ssr/*/*_results.db $O/prof_ssr/*_results.db 2>/dev/null | head -1) --csv $O/kernel_stats_ssr.csv > $O/kernel_stats_ssr.txt 2>&1; head -n 12 $O/kernel_stats_ssr.txt
+rm -rf $O/prof_ssr
 bash scripts/pmc_passes.sh $O/pmc --precision 2
 python scripts/pmc_report.py $O/pmc 150 > $O/pmc_report.txt 2>&1; head -n 45 $O/pmc_report.txt
 rm -rf $O/pmc/*/*.db $O/pmc/*/*/*.db $O/prof   # the databases are large; the reports stay
