@@ -455,6 +455,46 @@ def test_committed_bench_line_follows_the_contract():
     assert max(r03) - min(r03) < 0.01 * min(r03) and max(r04) - min(r04) < 0.01 * min(r04)     # same-box repeatability: < 1 %
 
 
+@pytest.mark.parametrize("C,kind,tuning", [(32, 0, 0), (32, 0, 128), (64, 0, 0), (32, 1, 0), (32, 2, 0)])
+def test_block2d_tiles_cover_every_pixel_once(C, kind, tuning):
+    """Tile geometry of the fused 2-D ConvBlockRes (plan_block2d, host-only entry point) -- identity block, entry block (Cin = 1)
+    and two-source block -- over image sizes of the shipped shapes and awkward ones: the outputs the kernel's mask lets through
+    (restated from resblock.hip: the interior of the h grid, inside the image) hit every pixel exactly once, the patch fits its
+    buffer, and the choice among the tiles is the one that computes the fewest h positions."""
+    import ctypes
+    from voicefixer_main_amd import _lib
+    lib = _lib.load_test()
+    out = (ctypes.c_int * 8)()
+    for H, W in [(1016, 127), (1024, 128), (192, 1024), (128, 127), (7, 5), (1, 1), (14, 14), (15, 29), (508, 63), (3, 200)]:
+        assert lib.vfx_plan_block2d_geometry(C, H, W, kind, tuning, out) == 0, (H, W)
+        TH, W1, TWo, tiles_h, tiles_w, PW, P, tile_m = list(out)
+        MT = 256 if tile_m == 256 else 128
+        assert TH * W1 == MT and TWo == W1 - 2 and PW == W1 + 2 and P == (TH + 2) * PW and P <= MT + MT // 2
+        if kind != 0:
+            assert (TH, W1) == (16, 16)                      # the entry / two-source kernels exist on 16 x 16 tiles only
+        if C == 64 or tuning & 128:
+            assert MT == 128                                 # 16 x 16 tiles: C = 32 without VFX_TUNE_SMALL_2D_TILES
+        cands = [(8, 16), (16, 8)] + ([(16, 16)] if (C == 32 and not tuning & 128) else [])
+        if kind == 0:
+            cost = {c: -(-H // (c[0] - 2)) * -(-W // (c[1] - 2)) * c[0] * c[1] for c in cands}
+            assert cost[(TH, W1)] == min(cost.values()), (H, W, cost)
+        count = np.zeros((H, W), np.int32)
+        for ti in range(tiles_h):
+            for tj in range(tiles_w):
+                i0, j0 = ti * (TH - 2), tj * TWo
+                for li in range(1, TH - 1):
+                    for lj in range(1, W1 - 1):
+                        r, c = i0 - 1 + li, j0 - 1 + lj
+                        if r < H and c < W:
+                            count[r, c] += 1
+                # the patch pixel of conv1's last tap of the last h pixel, and the two-source block's centre row, stay inside
+                assert (TH - 1 + 2) * PW + (W1 - 1 + 2) < P and (TH - 1) * W1 + W1 - 1 < MT
+        assert (count == 1).all(), (H, W, TH, W1)
+    # the kernels that exist on 16 x 16 tiles only are refused under VFX_TUNE_SMALL_2D_TILES (the builder keeps the two-launch form)
+    if kind != 0:
+        assert lib.vfx_plan_block2d_geometry(C, 64, 64, kind, 128, out) == 1
+
+
 @pytest.mark.parametrize("C,precision,tuning", [(64, 2, 0), (64, 1, 0), (128, 2, 0), (256, 2, 0), (256, 2, 64), (64, 2, 8)])
 def test_resblock_tiles_cover_every_position_once(C, precision, tuning):
     """Tile geometry of the fused ResStack kernels (plan_resblock, host-only entry point): over the vocoder's dilations, the

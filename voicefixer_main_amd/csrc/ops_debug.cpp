@@ -321,6 +321,27 @@ extern "C" int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2,
   return 0;
 }
 
+extern "C" int vfx_plan_block2d_geometry(int C, int H, int W, int kind, int tuning, int* out) {
+  try {
+    VFX_CHECK(out && H > 0 && W > 0 && kind >= 0 && kind <= 2, "bad argument");
+    ResBlockParams rp{};
+    rp.B = 1;
+    rp.H = H;
+    rp.W = W;
+    rp.C = C;
+    rp.geo2d = 1;
+    rp.in1 = kind == 1;
+    rp.two_src = kind == 2;
+    rp.tuning = tuning;
+    plan_block2d(rp);
+    const int v[8] = {rp.TH, rp.W1, rp.TWo, rp.tiles_h, rp.tiles_w, rp.PW, rp.P, rp.tile_m};
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+  } catch (const vfx::Error&) {
+    return 1;
+  }
+  return 0;
+}
+
 // Two consecutive ResStack layers (dilations dil, dil2) of the 16-bit mode at C = 64 as ONE launch (resblock_rw.hip, PAIR): the
 // first layer's output never leaves the CU.  Weights / biases in PyTorch layout on the HOST: wa1, ba1, wa2, ba2 = first layer,
 // wb1 .. bb2 = second layer.  Fails (returns 1) where the plan would not pair the layers.
