@@ -28,7 +28,8 @@ int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, int Cin, con
                 const float* shift, int act, float slope, const float* bias,
                 const float* residual, float* y, void* stream);
 /* ConvTranspose (stride s, PyTorch layout (Cin, Cout, kh, kw) on the HOST):
- *   2-D: kh=kw=3, s=2, padding 0, output pruned to (2H, 2W+1) or (2H, 2W) when prune_w;
+ *   2-D: kh=kw=3, s=2, padding 0, output pruned to (2H, 2W+1) or (2H, 2W) when prune_w; without a bias and for H, W >= 2 it runs
+ *        the ResUNet plan's form (two phased launches, one per output row class), else four parity launches;
  *   1-D: kh=1, kw=2s, padding s/2+s%2, output_padding s%2, output (B,1,W*s,Cout). */
 int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H, int W, int Cin,
                           const float* weight, int Cout, int kh, int kw, int stride, int prune_w,

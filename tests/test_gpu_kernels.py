@@ -170,8 +170,12 @@ def test_f32_trunk_layers(C):
     assert eng.take_flags() == 0
 
 
-@pytest.mark.parametrize("prune_w,H,W", [(False, 5, 1), (False, 10, 3), (True, 4, 16)])
+@pytest.mark.parametrize("prune_w,H,W", [(False, 5, 1), (False, 10, 3), (True, 4, 16), (False, 6, 7), (False, 3, 30), (False, 17, 63),
+                                        (True, 9, 5), (True, 2, 2)])
 def test_conv_transpose2d(engine, prune_w, H, W):
+    """The ResUNets' upsampler.  W >= 2 and H >= 2 run the product's form -- the two column classes of a row class as the phases of
+    ONE launch (even output width: channel-half view; odd width 2 W + 1: `TapConvParams::out_cmul`, the second class one column
+    short) -- W = 1 the four parity launches."""
     B, Cin, Cout = 2, 64, 32
     x = _rand((B, Cin, H, W), 21)
     w = _rand((Cin, Cout, 3, 3), 22, 0.1)

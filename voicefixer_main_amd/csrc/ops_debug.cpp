@@ -43,6 +43,32 @@ void run_one(vfx_handle* h, TapConvParams& p, DeviceBlob& blob, hipStream_t s) {
   launch_conv(p, d, s);
   if (p.ksplit > 1) launch_splitk_reduce(p, s);
 }
+
+// A phased launch (TapConvParams::nphase: the column classes of a transposed convolution's row class as ONE launch), set up the way
+// PlanBuilder::add_conv_phased / bind_plan do it: p.seg[0] = the union window, one stage table per phase.
+void run_phased(vfx_handle* h, TapConvParams& p, const std::vector<TapSeg>& phases, DeviceBlob& blob, hipStream_t s) {
+  p.split = h->cfg.precision != 0;
+  p.hionly = h->cfg.precision == 2;
+  p.flags = h->d_flags;
+  p.tuning = h->cfg.tuning;
+  p.nphase = (int)phases.size();
+  p.cout_phase = p.Cout / p.nphase;
+  finish_params(p);
+  VFX_CHECK(!p.per_tap, "phased conv: the union of the phases' taps does not fit one patch");
+  std::vector<ConvStage> st((size_t)p.nstages * p.nphase);
+  for (int r = 0; r < p.nphase; ++r) {
+    TapConvParams q = p;
+    q.seg[0] = phases[r];
+    build_stages(q, h->d_ones, h->d_zeros, st.data() + (size_t)r * p.nstages);
+  }
+  ConvStage* ds = static_cast<ConvStage*>(blob.alloc(st.size() * sizeof(ConvStage)));
+  VFX_HIP(hipMemcpy(ds, st.data(), st.size() * sizeof(ConvStage), hipMemcpyHostToDevice));
+  p.stages = ds;
+  p.ksplit = 0;
+  TapConvParams* d = static_cast<TapConvParams*>(blob.alloc(sizeof(TapConvParams)));
+  VFX_HIP(hipMemcpy(d, &p, sizeof(p), hipMemcpyHostToDevice));
+  launch_conv(p, d, s);
+}
 }  // namespace
 
 extern "C" int vfx_op_conv(vfx_handle* h, const float* x, int B, int H, int W, int Cin, const float* weight, int Cout,
@@ -447,7 +473,52 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scratch sc;
     const float* dbias = bias ? sc.blob.upload(bias, Cout) : nullptr;
-    if (kh == 3 && kw == 3 && stride == 2) {
+    if (kh == 3 && kw == 3 && stride == 2 && !bias && H >= 2 && W >= 2 && Cout % 32 == 0 && !(h->cfg.tuning & VFX_TUNE_NO_FUSED_UNET)) {
+      // the product's form (resunet.cpp, TrunkBuilder::upsample): the two column classes of a row class as the PHASES of one
+      // launch -- even output width: the output viewed as (B, 2H, W, 2 Cout); odd width: addressed in units of Cout (out_cmul)
+      const int Ho = 2 * H, Wo = prune_w ? 2 * W : 2 * W + 1;
+      for (int a = 0; a < 2; ++a) {
+        TapConvParams p{};
+        p.B = B;
+        p.Hi = H;
+        p.Wi = W;
+        p.Ho = Ho;
+        p.Cout = 2 * Cout;
+        p.sh = 2;
+        p.oh0 = a;
+        p.ow0 = 0;
+        p.Hg = (Ho - a + 1) / 2;
+        if (prune_w) {
+          p.Wo = W;
+          p.sw = 1;
+          p.Wg = W;
+        } else {
+          p.Wo = Wo;
+          p.sw = 2;
+          p.Wg = W + 1;
+          p.out_cmul = Cout;
+        }
+        p.out = y;
+        p.nseg = 1;
+        std::vector<TapSeg> phases(2);
+        for (int b = 0; b < 2; ++b) {
+          TapSeg& S = phases[b];
+          S = TapSeg{};
+          std::vector<std::pair<int, int>> taps;
+          for (int r = a; r < 3; r += 2)
+            for (int c = b; c < 3; c += 2) {
+              S.dh[taps.size()] = -(r / 2);
+              S.dw[taps.size()] = -(c / 2);
+              taps.push_back({r, c});
+            }
+          S.ntaps = (int)taps.size();
+          fill_seg(S, x, Cin, scale, shift, act, slope, sc.blob);
+          S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 3, 3, taps, h->cfg.precision == 2 ? 2 : (h->cfg.precision != 0)));
+        }
+        p.seg[0] = phases[0];
+        run_phased(h, p, phases, sc.blob, s);
+      }
+    } else if (kh == 3 && kw == 3 && stride == 2) {
       const int Ho = 2 * H, Wo = prune_w ? 2 * W : 2 * W + 1;
       for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) {
