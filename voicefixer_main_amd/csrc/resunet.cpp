@@ -360,7 +360,7 @@ struct TrunkBuilder {
         }
     };
     // (x.H, x.W >= 2: plan_conv then always finds a tile whose all-taps window fits one patch, which a phased launch needs;
-    // an odd output width -- the mel ResUNet prunes the time axis only -- has no such view: four launches)
+    // an odd output width -- the mel ResUNet prunes the time axis only -- has no such view: addressed in units of C instead, below)
     if (prune_w && x.H >= 2 && x.W >= 2 && !(pb.h->cfg.tuning & VFX_TUNE_NO_FUSED_UNET)) {
       // An even output width makes (B, 2H, 2W, C) a (B, 2H, W, 2C) tensor whose channel halves are the two column parities:
       // the column classes of one row class are the PHASES of one launch (own taps, own weight tensor, one patch) -- two
