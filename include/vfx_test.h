@@ -49,6 +49,9 @@ int vfx_op_resblock(vfx_handle* h, const float* x, int B, int T, int C, const fl
 int vfx_plan_resblock_geometry(int C, int T, int dil, int dil2, int precision, int* out);
 /* ... for a handle configured with vfx_config.tuning = `tuning` (the function above is tuning = 0). */
 int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2, int precision, int tuning, int* out);
+/* Host-only: tile and patch geometry plan_conv gives a tap convolution over an (Hg, Wg) output grid with `ntaps` taps at offsets
+ * (dh[t], dw[t]).  out[6] = TH, TW, PW, P, per_tap, tiles_h * tiles_w. */
+int vfx_plan_conv_geometry(int Hg, int Wg, int ntaps, const int* dh, const int* dw, int* out);
 /* Host-only: the tile geometry of a fused 2-D ConvBlockRes of the ResUNets (plan_block2d) over (H, W) images of C channels;
  * kind 0 = identity block, 1 = entry block (Cin = 1), 2 = two-source block.  out[8] = TH, W1, TWo, tiles_h, tiles_w, PW, P,
  * tile_m (0 = 128 positions).  Returns 1 where the plan refuses (e.g. kind != 0 under VFX_TUNE_SMALL_2D_TILES). */

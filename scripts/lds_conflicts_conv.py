@@ -54,6 +54,28 @@ def tile_cost(TH, TW, key, piece=0, halo=1):
     return tot / n, worst
 
 
+def window_cost(TH, TW, PW, taps, key):
+    """The same model for an arbitrary tap window: taps = [(dpi, dpj)] patch offsets of the taps relative to the tile pixel, PW the
+    patch width (plan_conv: TW + window width, made even where the window is odd)."""
+    tot = n = worst = 0
+    for a in range((TH * TW + 31) // 32):
+        for dpi, dpj in taps:
+            for g in GROUPS:
+                addrs = []
+                for l in g:
+                    ml = a * 32 + l
+                    li, lj = ml // TW, ml % TW
+                    if li >= TH:
+                        li, lj = 0, 0
+                    pi, pj = li + dpi, lj + dpj
+                    addrs.append((pi * PW + pj) * 8 + key(pi, pj, PW, TW))
+                c = group_cost(addrs)
+                tot += c
+                n += 1
+                worst = max(worst, c)
+    return tot / n, worst
+
+
 def main():
     shapes = [("level 0/1 (8 x 16)", 8, 16), ("levels 2-4 (16 x 8)", 16, 8), ("level 5 (24 x 4)", 24, 4),
               ("bottleneck (8 x 2)", 8, 2), ("32 x 4", 32, 4), ("4 x 32", 4, 32)]
@@ -62,6 +84,13 @@ def main():
         a1, w1 = tile_cost(TH, TW, key_1d)
         a2, w2 = tile_cost(TH, TW, key_2d)
         print("%-24s   avg %.2f worst %d   avg %.2f worst %d" % (name, a1, w1, a2, w2))
+    # the column / row classes of a transposed 3x3 convolution (taps at 0 and -1: a window one wider than the tile)
+    taps = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    print("\n%-24s %18s %18s" % ("upsampler window, 2-D key", "PW = TW + 1 (odd)", "PW = TW + 2 (even)"))
+    for name, TH, TW in shapes:
+        ao, wo = window_cost(TH, TW, TW + 1, taps, key_2d)
+        ae, we = window_cost(TH, TW, TW + 2, taps, key_2d)
+        print("%-24s   avg %.2f worst %d   avg %.2f worst %d" % (name, ao, wo, ae, we))
 
 
 if __name__ == "__main__":

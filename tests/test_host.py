@@ -652,6 +652,40 @@ def test_fragment_reads_of_2d_tiles_are_conflict_free_with_the_2d_key():
     assert m.tile_cost(1, 128, m.key_2d) == (1.0, 1)  # a 1-D patch: the 2-D key is the row-linear one
 
 
+def test_upsampler_patches_get_an_even_width():
+    """The parity classes of the ResUNets' transposed convolutions read a window ONE wider than the tile (taps 0 / -1): with an odd
+    patch width the 2-D swizzle key's premise fails and the model shows 1.5 LDS cycles per lane group (PMC in round 4: 34-37 %
+    conflict cycles in those launches).  plan_conv (host-only entry point) must hand such launches an even patch width wherever
+    the tile has more than one row, and the modelled fragment reads must then be conflict-free; 3x3 windows are unchanged."""
+    import ctypes
+    from voicefixer_main_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import lds_conflicts_conv as m
+    lib = _lib.load_test()
+    out = (ctypes.c_int * 6)()
+
+    def plan(Hg, Wg, taps):
+        dh = (ctypes.c_int * len(taps))(*[t[0] for t in taps])
+        dw = (ctypes.c_int * len(taps))(*[t[1] for t in taps])
+        assert lib.vfx_plan_conv_geometry(Hg, Wg, len(taps), dh, dw, out) == 0
+        return list(out)
+
+    union = [(0, 0), (0, -1), (-1, 0), (-1, -1)]           # what a phased upsampler launch stages (resunet.cpp, upsample)
+    for Hg, Wg in [(512, 64), (512, 63), (256, 32), (128, 16), (64, 8), (32, 4), (16, 2), (8, 2), (96, 512), (3, 30), (17, 64)]:
+        for taps in (union, [(0, 0), (0, -1)]):             # (the classes without a horizontal tap have a window as wide as the tile)
+            TH, TW, PW, P, per_tap, _ = plan(Hg, Wg, taps)
+            assert per_tap == 0 and P <= 192
+            wide = max(t[1] for t in taps) - min(t[1] for t in taps)
+            tall = max(t[0] for t in taps) - min(t[0] for t in taps)
+            if TH > 1 and (TH + tall) * (TW + wide + (TW + wide) % 2) <= 192:   # (a 32 x 4 tile has no room for the extra column)
+                assert PW % 2 == 0 and PW - TW in (wide, wide + 1), (Hg, Wg, taps, TW, PW)
+                offs = [(t[0] - min(u[0] for u in taps), t[1] - min(u[1] for u in taps)) for t in taps]
+                assert m.window_cost(TH, TW, PW, offs, m.key_2d) == (1.0, 1), (Hg, Wg, taps, TH, TW, PW)
+    TH, TW, PW, P, per_tap, _ = plan(512, 127, [(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)])
+    assert PW == TW + 2 and P == (TH + 2) * PW                      # 3x3: even already
+    assert m.window_cost(8, 16, 17, [(0, 0), (0, 1), (1, 0), (1, 1)], m.key_2d)[0] == 1.5   # what the odd width cost
+
+
 def test_tile_split_reciprocal_is_exact_including_one_tile_per_clip():
     """conv_common.h's div_recip(n, r) with the host's r = ceil(2^32 / d) (plan_resblock) -- restated here -- equals n // d for
     every tile count the plan admits (n * d < 2^32), including d = 1 (one tile per clip), where r = 2^32 does not fit 32 bits:

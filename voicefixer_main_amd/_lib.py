@@ -76,6 +76,7 @@ TEST_SIGNATURES = {
     "vfx_plan_resblock_geometry": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vfx_plan_resblock_geometry_tuned": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vfx_plan_block2d_geometry": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vfx_plan_conv_geometry": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vfx_op_resblock_pair": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "vfx_op_block2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

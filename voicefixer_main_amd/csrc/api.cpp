@@ -293,7 +293,15 @@ static void plan_conv(TapConvParams& p) {
   p.tiles_h = (p.Hg + TH - 1) / TH;
   p.tiles_w = (p.Wg + TW - 1) / TW;
   if (window) {
-    const int64_t PH = TH + (int64_t)(dh_hi - dh_lo), PW = TW + (int64_t)(dw_hi - dw_lo);
+    const int64_t PH = TH + (int64_t)(dh_hi - dh_lo);
+    int64_t PW = TW + (int64_t)(dw_hi - dw_lo);
+    // An ODD patch width (the parity classes of a transposed 3x3 convolution: taps 0 / -1, window TW + 1) breaks what the 2-D
+    // swizzle key rests on -- "the bank half of LDS row pi * PW + pj is pj & 1" (conv.hip) -- and every second fragment read of
+    // those launches is a 2-way bank conflict (scripts/lds_conflicts_conv.py: 1.5 LDS cycles per lane group; PMC: 34-37 % conflict
+    // cycles in the upsampler launches, review item 1d).  One unused column makes it even where it fits.
+#ifndef VFX_ABL_ODD_PATCH_WIDTH  // (measurement builds keep the odd width)
+    if (PH > 1 && (PW & 1) && PH * (PW + 1) <= kPatchMaxRows) PW += 1;
+#endif
     p.per_tap = 0;
     p.PW = (int)PW;
     p.P = (int)(PH * PW);

@@ -347,6 +347,34 @@ extern "C" int vfx_plan_resblock_geometry_tuned(int C, int T, int dil, int dil2,
   return 0;
 }
 
+extern "C" int vfx_plan_conv_geometry(int Hg, int Wg, int ntaps, const int* dh, const int* dw, int* out) {
+  try {
+    VFX_CHECK(out && dh && dw && Hg > 0 && Wg > 0 && ntaps >= 1 && ntaps <= kMaxTaps, "bad argument");
+    static float dummy;
+    TapConvParams p{};
+    p.B = 1;
+    p.Hi = p.Hg = p.Ho = Hg;
+    p.Wi = p.Wg = p.Wo = Wg;
+    p.sh = p.sw = 1;
+    p.Cout = 32;
+    p.split = 1;
+    p.out = &dummy;  // never dereferenced: host-side planning only
+    p.nseg = 1;
+    p.seg[0].C = 32;
+    p.seg[0].ntaps = ntaps;
+    for (int t = 0; t < ntaps; ++t) {
+      p.seg[0].dh[t] = dh[t];
+      p.seg[0].dw[t] = dw[t];
+    }
+    finish_params(p);
+    const int v[6] = {p.TH, p.TW, p.PW, p.P, p.per_tap, p.tiles_h * p.tiles_w};
+    for (int i = 0; i < 6; ++i) out[i] = v[i];
+  } catch (const vfx::Error&) {
+    return 1;
+  }
+  return 0;
+}
+
 extern "C" int vfx_plan_block2d_geometry(int C, int H, int W, int kind, int tuning, int* out) {
   try {
     VFX_CHECK(out && H > 0 && W > 0 && kind >= 0 && kind <= 2, "bad argument");
