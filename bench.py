@@ -152,6 +152,14 @@ def cpu_model():
     return "unknown"
 
 
+def sample_indices(B, n):
+    """The clips of a batch of B that the CPU oracle runs on: the first ceil(n/2) and the LAST floor(n/2) -- so that the
+    parity of the benched batch covers both ends of it (the clips in between are covered HIP-vs-HIP, `batch_tail_equal`)."""
+    n = max(0, min(n, B))
+    head = (n + 1) // 2
+    return list(range(head)) + list(range(B - (n - head), B))
+
+
 def cpu_baseline(kind, clips, n_clips, threads, repeats=3, dtype=None):
     """the oracle (a port of the reference algorithm) on the box's host cores, after one warm-up
     call, MEDIAN of `repeats` timed calls on a bounded sample of the benched clips; thread count and CPU model stated.
@@ -161,7 +169,7 @@ def cpu_baseline(kind, clips, n_clips, threads, repeats=3, dtype=None):
     as the PARITY reference (two fp32 evaluations of that trunk agree to ~60 dB only); it is then timed once."""
     from oracle import pipeline
     from voicefixer_main_amd import synth
-    wav = clips[:n_clips]
+    wav = clips[sample_indices(clips.shape[0], n_clips)]
     threads = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(threads)
     times = []
@@ -190,8 +198,8 @@ def cpu_baseline(kind, clips, n_clips, threads, repeats=3, dtype=None):
             "seconds": round(dt, 2), "timed_calls": [round(t, 2) for t in times], "statistic": "median",
             "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
             "sample": "%s (torch-CPU fp32 + numpy port of the reference algorithm) on %d clip(s) x %.0f s of the same "
-                      "synthetic clips as one batch, same seeded weights, after a warm-up call"
-                      % (name, wav.shape[0], wav.shape[-1] / 44100.0)}, ref
+                      "synthetic clips (batch indices %s) as one batch, same seeded weights, after a warm-up call"
+                      % (name, wav.shape[0], wav.shape[-1] / 44100.0, sample_indices(clips.shape[0], n_clips))}, ref
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -710,7 +718,9 @@ def aux_workload(name, args, device, weights):
             n = 2 if name == "ssr_sr64" else 1
             base, ref = cpu_baseline("ssr", w.clips, n, args.cpu_threads, repeats=args.cpu_repeats, dtype=torch.float64)
             res["cpu_baseline"] = base
-            res["parity"] = parity_wav(got[:n], ref["wav"][:, 0])
+            idx = sample_indices(w.B, n)
+            res["parity"] = parity_wav(got[idx], ref["wav"][:, 0])
+            res["parity"]["batch_indices"] = idx
             res["parity"]["vs"] = "oracle.pipeline.restore_ssr in FLOAT64 (CPU port of unet_v2.py:86-148)"
         del w
         torch.cuda.empty_cache()
@@ -836,12 +846,23 @@ def main():
                 res["cpu_baseline"], ref = {"error": repr(e)}, None
             if ref is not None and not args.no_parity:
                 n = args.cpu_baseline_clips
+                idx = sample_indices(B, n)
                 if wl == "gsr16x10":
-                    res["parity"] = parity_gsr(out_p[:n], logmel_p[:n], ref)
+                    res["parity"] = parity_gsr(out_p[idx], logmel_p[idx], ref)
+                    res["parity"]["batch_indices"] = idx
+                    # the clips the oracle did not see, HIP against HIP: every pair of rows (2i, 2i+1) of the benched batch,
+                    # restored as its own batch of two, must equal its rows of the batch's output bit for bit (a clip's
+                    # result does not depend on the batch it is in: per-clip split-K rule, no cross-clip reduction anywhere)
+                    bad = [i for i in range(0, B - 1, 2)
+                           if not torch.equal(eng.restore_gsr(w.wav[i:i + 2].contiguous()), out_p[i:i + 2])]
+                    res["parity"]["batch_rows_equal_as_pairs"] = not bad
+                    if bad:
+                        failed = "restore(wav[i:i+2]) differs from rows i, i+1 of restore(wav[0:B]) for i in %s" % bad
                     if res["parity"]["logmel_l1"] > LOGMEL_L1_BAR:
                         failed = "log-mel L1 %.3g exceeds the %.0e bar" % (res["parity"]["logmel_l1"], LOGMEL_L1_BAR)
                 elif wl in ("ssr_sr64", "stream1s"):
-                    res["parity"] = parity_wav(w.holder[0][:n], ref["wav"][:, 0])
+                    res["parity"] = parity_wav(w.holder[0][idx], ref["wav"][:, 0])
+                    res["parity"]["batch_indices"] = idx
                     res["parity"]["vs"] = "oracle.pipeline.restore_ssr in FLOAT64 (CPU port of unet_v2.py:86-148)"
         if gsr and wl == "gsr16x10" and args.precision == 2 and not args.no_alt:
             # Same workload, same process, same box, minutes apart:
@@ -870,8 +891,8 @@ def main():
                     r.update({k: v for k, v in step_stats([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)], None).items()
                               if k.startswith("ms_per_step")})
                     if "parity" in res:
-                        n = args.cpu_baseline_clips
-                        o1, l1 = alt.restore_gsr(wav[:n], want_logmel=True)
+                        sel = wav[sample_indices(B, args.cpu_baseline_clips)].contiguous()
+                        o1, l1 = alt.restore_gsr(sel, want_logmel=True)
                         r["parity"] = parity_gsr(o1, l1, ref)
                     fl = alt.take_flags()
                     r["f16_saturated"] = bool(fl & 2)

@@ -101,6 +101,47 @@ class TorchStftHelper(torch.nn.Module):
         return torch.istft(spec, 2048, 441, 2048, self.win, center=True, length=length)
 
 
+BANDPASS_CASES = {"d_butter": (500, 4000, 5, "butter"), "d_cheby1": (300.7, 3400.2, 6, "cheby1"), "d_ellip": (1000, 8000, 4, "ellip"),
+                  "d_bessel": (200, 2000, 3, "bessel"), "d_substr": (400, 5000, 5, "utt"), "d_clamped": (400, 5000, 13, "cheby1")}
+
+
+def simulate_golden():
+    """Section 7 alone: `python oracle/gen_golden.py --only simulate` rewrites tests/golden/simulate.npz and nothing else."""
+    install_stubs()
+    # 7. degradation simulator (SURVEY.md section 8 f4; round 4): the reference's OWN tools/dsp/lowpass.py and
+    # dataloaders/augmentation/base.py on seeded inputs -- every IIR type, the resampling low-pass, the substring dispatch, the
+    # band-pass, the three noise mixers with the random draws pinned (equal bounds: tools/pytorch/random_.py returns the bound).
+    # `stft_hard` needs torchlibrosa (FDomainHelper) and is covered by the GPU test against the oracle's STFT instead.
+    install_io_stubs()
+    import tools.dsp.lowpass as ref_lp
+    import dataloaders.augmentation.base as ref_aug
+    rng = np.random.default_rng(31)
+    n = 4096
+    x = rng.normal(0.0, 0.1, n)
+    sim = {"x": x}
+    for name, (hc, order, typ) in {"butter": (4000, 5, "butter"), "cheby1": (1000, 8, "cheby1"), "ellip": (6000, 6, "ellip"),
+                                   "bessel": (2000, 4, "bessel"), "substr_b": (3000, 5, "b"), "order_clamped": (3000, 14, "butter"),
+                                   "stft": (8000, 5, "stft")}.items():
+        sim["lowpass_" + name] = np.asarray(ref_lp.lowpass(x.copy(), highcut=hc, fs=44100, order=order, _type=typ), np.float64)
+    sim["bandpass_butter"] = np.asarray(ref_lp.bandpass_filter(x.copy(), 500, 4000, 44100, 6, "butter"), np.float64)
+    sim["bandpass_cheby2"] = np.asarray(ref_lp.bandpass_filter(x.copy(), 300, 3000, 44100, 4, "cheby2"), np.float64)
+    # the dispatch wrapper (lowpass.py:189-215; round 5): every type it accepts, a substring, a clamped order, float cut-offs
+    for name, (lc, hc, order, typ) in BANDPASS_CASES.items():
+        sim["bandpass_" + name] = np.asarray(ref_lp.bandpass(x.copy(), lc, hc, 44100, order=order, _type=typ), np.float64)
+    front, noise = rng.normal(0.0, 0.2, n), rng.normal(0.0, 0.05, n)
+    hq, aug = front * 0.9 + rng.normal(0.0, 0.01, n), np.tanh(front * 3.0)
+    sim.update(front=front, noise=noise, hq=hq, aug=aug)
+    t = lambda a: torch.from_numpy(a.copy())
+    o = ref_aug.add_noise_and_scale(t(front), t(noise), snr_l=10, snr_h=10, scale_lower=0.8, scale_upper=0.8)
+    sim["mix_front"], sim["mix_noise"], sim["mix_snr_scale"] = o[0].numpy(), o[1].numpy(), np.array([float(o[2]), float(o[3])])
+    o = ref_aug.add_noise_and_scale_with_HQ(t(hq), t(front), t(noise), snr_l=5, snr_h=5, scale_lower=0.7, scale_upper=0.7)
+    sim["hq_hq"], sim["hq_front"], sim["hq_noise"], sim["hq_snr_scale"] = o[0].numpy(), o[1].numpy(), o[2].numpy(), np.array([float(o[3]), float(o[4])])
+    o = ref_aug.add_noise_and_scale_with_HQ_with_Aug(t(hq), t(front), t(aug), t(noise), snr_l=0, snr_h=0, scale_lower=0.9, scale_upper=0.9)
+    sim["aug_hq"], sim["aug_front"], sim["aug_aug"], sim["aug_noise"], sim["aug_snr_scale"] = (
+        o[0].numpy(), o[1].numpy(), o[2].numpy(), o[3].numpy(), np.array([float(o[4]), float(o[5])]))
+    np.savez_compressed(os.path.join(OUT, "simulate.npz"), **{k: np.asarray(v, np.float64) for k, v in sim.items()})
+
+
 def main():
     install_stubs()
     os.makedirs(OUT, exist_ok=True)
@@ -197,39 +238,14 @@ def main():
         out2 = spec(sp2, wav2)["wav"]
     np.savez_compressed(os.path.join(OUT, "unet_spec_b2.npz"), pcm_in=pcm, wav_out=out2.numpy()[:, 0],
                         mag_sub=mags["mag"][:, 0, ::8, ::32].numpy())
-    # 7. degradation simulator (round 4): the reference's OWN tools/dsp/lowpass.py and
-    # dataloaders/augmentation/base.py on seeded inputs -- every IIR type, the resampling low-pass, the substring dispatch, the
-    # band-pass, the three noise mixers with the random draws pinned (equal bounds: tools/pytorch/random_.py returns the bound).
-    # `stft_hard` needs torchlibrosa (FDomainHelper) and is covered by the GPU test against the oracle's STFT instead.
-    install_io_stubs()
-    import tools.dsp.lowpass as ref_lp
-    import dataloaders.augmentation.base as ref_aug
-    rng = np.random.default_rng(31)
-    n = 4096
-    x = rng.normal(0.0, 0.1, n)
-    sim = {"x": x}
-    for name, (hc, order, typ) in {"butter": (4000, 5, "butter"), "cheby1": (1000, 8, "cheby1"), "ellip": (6000, 6, "ellip"),
-                                   "bessel": (2000, 4, "bessel"), "substr_b": (3000, 5, "b"), "order_clamped": (3000, 14, "butter"),
-                                   "stft": (8000, 5, "stft")}.items():
-        sim["lowpass_" + name] = np.asarray(ref_lp.lowpass(x.copy(), highcut=hc, fs=44100, order=order, _type=typ), np.float64)
-    sim["bandpass_butter"] = np.asarray(ref_lp.bandpass_filter(x.copy(), 500, 4000, 44100, 6, "butter"), np.float64)
-    sim["bandpass_cheby2"] = np.asarray(ref_lp.bandpass_filter(x.copy(), 300, 3000, 44100, 4, "cheby2"), np.float64)
-    front, noise = rng.normal(0.0, 0.2, n), rng.normal(0.0, 0.05, n)
-    hq, aug = front * 0.9 + rng.normal(0.0, 0.01, n), np.tanh(front * 3.0)
-    sim.update(front=front, noise=noise, hq=hq, aug=aug)
-    t = lambda a: torch.from_numpy(a.copy())
-    o = ref_aug.add_noise_and_scale(t(front), t(noise), snr_l=10, snr_h=10, scale_lower=0.8, scale_upper=0.8)
-    sim["mix_front"], sim["mix_noise"], sim["mix_snr_scale"] = o[0].numpy(), o[1].numpy(), np.array([float(o[2]), float(o[3])])
-    o = ref_aug.add_noise_and_scale_with_HQ(t(hq), t(front), t(noise), snr_l=5, snr_h=5, scale_lower=0.7, scale_upper=0.7)
-    sim["hq_hq"], sim["hq_front"], sim["hq_noise"], sim["hq_snr_scale"] = o[0].numpy(), o[1].numpy(), o[2].numpy(), np.array([float(o[3]), float(o[4])])
-    o = ref_aug.add_noise_and_scale_with_HQ_with_Aug(t(hq), t(front), t(aug), t(noise), snr_l=0, snr_h=0, scale_lower=0.9, scale_upper=0.9)
-    sim["aug_hq"], sim["aug_front"], sim["aug_aug"], sim["aug_noise"], sim["aug_snr_scale"] = (
-        o[0].numpy(), o[1].numpy(), o[2].numpy(), o[3].numpy(), np.array([float(o[4]), float(o[5])]))
-    np.savez_compressed(os.path.join(OUT, "simulate.npz"), **{k: np.asarray(v, np.float64) for k, v in sim.items()})
+    simulate_golden()
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print("  %-24s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["--only", "simulate"]:
+        simulate_golden()
+    else:
+        main()

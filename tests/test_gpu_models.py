@@ -33,6 +33,11 @@ def test_resunet_negative_input_flag(engine):
     engine.resunet_mel(torch.from_numpy(mel[:, 0]))
     assert engine.take_flags() & 1
     assert engine.take_flags() == 0
+    # bin 127 never reaches the network (unet.py:78) but to_log's assert covers the whole tensor (pytorch_util.py:158)
+    mel = _mel_input(1, 64)
+    mel[0, 0, 40, 127] = -1e-3
+    engine.resunet_mel(torch.from_numpy(mel[:, 0]))
+    assert engine.take_flags() & 1
 
 
 @pytest.mark.parametrize("B,T", [(1, 21), (2, 10)])
@@ -146,8 +151,8 @@ def test_fp16_vocoder_mode(unet_sd, voc_sd):
         json.dump({k: float(v) for k, v in res.items()}, f, indent=1)
     print(res)
     assert res["restore_logmel_l1"] < 2e-4, res          # the ResUNet is still split-bf16: bar 1e-3
-    assert res["vocoder_sisdr_db"] > 50.0, res              # stated waveform bar of the 16-bit vocoder
-    assert res["restore_sisdr_db"] > 50.0, res
+    assert res["vocoder_sisdr_db"] > 52.0, res              # stated waveform bar of the 16-bit vocoder
+    assert res["restore_sisdr_db"] > 52.0, res
     assert res["restore_out_logmel_l1"] < 1e-3, res         # log-mel of the restored waveform: the north-star bar
     assert res["vocoder_sisdr_db_split"] > 60.0, res
 

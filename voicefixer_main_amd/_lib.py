@@ -108,8 +108,9 @@ def load():
             "libvfx.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the product path)" % LIB_PATH)
     try:
-        # RTLD_GLOBAL: libvfx_test.so (load_test) resolves the library's internals from THIS copy, whichever path it came from
-        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        # default RTLD_LOCAL: the product path does not put the library's internals into the process-wide namespace beside
+        # torch's and HIP's symbols (load_test promotes the already-loaded copy when the test library needs them)
+        lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 missing
         raise RuntimeError("cannot load %s: %s" % (LIB_PATH, e))
     for name, (res, args) in SIGNATURES.items():
@@ -129,6 +130,9 @@ def load_test():
     if not os.path.exists(TEST_LIB_PATH):
         raise RuntimeError("libvfx_test.so not found at %s -- build it with `make -C voicefixer_main_amd/csrc`" % TEST_LIB_PATH)
     try:
+        # tests only: promote the copy of libvfx.so that load() mapped (whichever path it came from -- VFX_LIB_PATH variant
+        # builds included) to the global scope, so that libvfx_test.so binds vfx::plan_resblock, pack_conv, ... to THAT copy
+        ctypes.CDLL(LIB_PATH, mode=os.RTLD_NOLOAD | ctypes.RTLD_GLOBAL)
         lib = ctypes.CDLL(TEST_LIB_PATH)
     except OSError as e:
         raise RuntimeError("cannot load %s: %s" % (TEST_LIB_PATH, e))

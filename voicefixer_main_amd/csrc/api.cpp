@@ -621,7 +621,7 @@ static char* ensure_arena(vfx_handle* h, size_t bytes) {
   for (auto& kv : h->plans)
     VFX_CHECK(!(kv.second->pinned && h->arena), "the workspace arena would have to grow from %zu to %zu bytes, but a hipGraph was captured from plan '%s' "
               "and replays kernels that point into the current arena: vfx_reserve() the largest (model, B, T) BEFORE capturing, "
-              "or destroy the graph(s) and call vfx_unpin_plans()", h->arena_bytes, bytes, kv.first.c_str());
+              "or destroy the graph(s) and call vfx_unpin_plans(); if this call was itself being captured, that capture has failed", h->arena_bytes, bytes, kv.first.c_str());
   VFX_HIP(hipDeviceSynchronize());
   if (h->arena) VFX_HIP(hipFree(h->arena));
   h->arena = nullptr;
@@ -1032,17 +1032,17 @@ static std::shared_ptr<Plan> get_plan(vfx_handle* h, const std::string& key,
   } else {
     plan = it->second;
   }
+  bool capturing = false;
   if (stream) {  // the legacy (NULL) stream cannot be captured
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) == hipSuccess && st == hipStreamCaptureStatusActive)
-      plan->pinned = true;
+    capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) == hipSuccess && st == hipStreamCaptureStatusActive;
   }
   plan->last_use = ++h->plan_tick;
-  const char* old = h->arena;
+  // bind first, pin afterwards: when the arena would have to grow under a capture (or under an older pinned plan)
+  // ensure_arena throws, the capture fails in the caller -- and a plan no graph was captured from must not stay pinned, it
+  // would refuse every later growth until somebody finds vfx_unpin_plans()
   bind_plan(h, *plan);
-  if (old && old != h->arena) {
-    // arena moved: every other cached plan re-binds lazily (bound_base mismatch)
-  }
+  if (capturing) plan->pinned = true;
   return plan;
 }
 

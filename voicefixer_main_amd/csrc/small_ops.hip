@@ -19,18 +19,23 @@ __global__ void k_prep_logmel(const float* __restrict__ mel, int B, int T, int T
                               int* __restrict__ flags) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)B * Tpad * 127;
-  if (idx >= total) return;
+  const bool live = idx < total;
   const int f = idx % 127;
   const int64_t r = idx / 127;
   const int i = r % Tpad;
   const int b = r / Tpad;
   float v = 0.f;
-  if (i < T) {
-    const float m = mel[((int64_t)b * T + i) * 128 + f];
-    if (m < 0.f) atomicOr(flags, VFX_FLAG_NEGATIVE_INPUT);
+  bool neg = false;
+  if (live && i < T) {
+    const float* row = mel + ((int64_t)b * T + i) * 128;
+    const float m = row[f];
+    // to_log asserts on the WHOLE tensor (pytorch_util.py:158): bin 127 is dropped from the network's input but not from
+    // the check -- the thread of bin 126 looks at it as well
+    neg = m < 0.f || (f == 126 && row[127] < 0.f);
     v = log10f(fmaxf(m, 1e-8f));
   }
-  x[idx] = v;
+  if (live) x[idx] = v;
+  if (__any(neg) && (threadIdx.x & 63) == 0) or_flag_global(flags, VFX_FLAG_NEGATIVE_INPUT);   // one global atomic per wave
 }
 
 // unet_v2.py:103-110: (B,T,1025) -> (B,Tpad,1024), zero rows beyond T, last bin dropped.

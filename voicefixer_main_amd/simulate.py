@@ -10,6 +10,7 @@ same names, argument meaning and error behaviour:
     ``stft_hard``  -> ``stft_hard_lowpass_v0``: STFT -> zero the bins above the cut-off -> ISTFT            :21-33
   (``_type in "butter"`` is a SUBSTRING test in the reference -- ``"b"``, ``"utt"`` and ``""`` all select the Butterworth
   filter; kept, since a config that relied on it must keep working);
+* ``bandpass(data, lowcut, highcut, fs, order=5, _type="butter")``     tools/dsp/lowpass.py:189-215 (IIR types, same dispatch)
 * ``bandpass_filter`` / ``align_length`` / ``limit``                       tools/dsp/lowpass.py:35-94,148-150
 * ``add_noise_and_scale`` / ``add_noise_and_scale_with_HQ`` / ``add_noise_and_scale_with_HQ_with_Aug``
                                                                            dataloaders/augmentation/base.py:33-118
@@ -132,6 +133,19 @@ def lowpass(data, highcut, fs, order=5, _type="butter", engine=None):
         return stft_hard_lowpass(data, lowpass_ratio=highcut / int(fs / 2))
     if _type in "stft_hard":
         return stft_hard_lowpass_v0(data, lowpass_ratio=highcut / int(fs / 2), engine=engine)
+    raise ValueError("Error: Unexpected filter type " + _type)
+
+
+def bandpass(data, lowcut, highcut, fs, order=5, _type="butter"):
+    """lowpass.py:189-215: the band-pass twin of `lowpass` -- same 1-D check, same substring dispatch and order clamp, IIR
+    types only (butter / cheby1 / ellip / bessel; cheby2 is commented out in the reference and raises here as well)."""
+    if len(list(data.shape)) != 1:
+        raise ValueError("Error (chebyshev_lowpass_filter): Data " + str(data.shape) +
+                         " should be type 1d time array, (samples,) , can not be (samples, 1)")
+    for name in ("butter", "cheby1", "ellip", "bessel"):
+        if _type in name:
+            return bandpass_filter(x=data, lowcut=int(lowcut), highcut=int(highcut), fs=fs,
+                                   order=limit(order, high=10, low=2), ftype=name)
     raise ValueError("Error: Unexpected filter type " + _type)
 
 
