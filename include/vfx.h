@@ -179,6 +179,18 @@ int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_ou
                     float* logmel_out, int flags, void* stream);
 
 /*
+ * vfx_restore_gsr for a batch of clips of UNEQUAL length (the reference restores one file per call, of any length:
+ * evaluation_proc/eval.py:119-134, eval_gsr_voicefixer.py:47-74).  wav, wav_out (B, Lmax); lengths[b] (HOST array) = samples of
+ * clip b, n_fft/2 < lengths[b] <= Lmax; logmel_out (B, Lmax / hop + 1, 128) optional.  Every clip gets what its own
+ * vfx_restore_gsr(B = 1, L = lengths[b]) call computes -- frames and reflect padding at its own end (fDomainHelper.py:26-28),
+ * the ResUNet's zero time padding behind its own last frame (unet.py:75-77), the vocoder stopped at its own length, its own
+ * peak normalisation and trim_center -- and zeros past its end in both outputs.  REQUIREMENT: the clips of one call share the
+ * padded frame count 64 * ceil((lengths[b] / hop + 1) / 64) of the ResUNet (the caller buckets by it; a violation is an error).
+ */
+int vfx_restore_gsr_varlen(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out,
+                           float* logmel_out, int flags, void* stream);
+
+/*
  * Long-audio chunkers: the two `LambdaOverlapAdd` classes (tools/dsp/overlapadd.py:337-480 and
  * tools/dsp/overlapadd_boxcar.py:338-513) segment a signal, run the network per chunk and stitch.  The
  * network call stays with the caller (all equal-length chunks as ONE batch); these are the two data

@@ -129,6 +129,80 @@ def test_restore_list_of_unequal_lengths_equals_one_call_per_clip(voicefixer):
         assert torch.isfinite(g).all() and torch.equal(g, one)
 
 
+VARLEN = [28500, 56000, 33333, 50017, 41000]      # T = 65, 127, 76, 114, 93 frames: one padded length (128), odd and even T
+
+
+def _varlen_batch(lens, seed=70):
+    from voicefixer_main_amd import synth
+    clips = [torch.from_numpy(synth.make_clips(1, L / 44100.0 + 0.01, seed=seed + i)[0, 0, :L].copy()).cuda() for i, L in enumerate(lens)]
+    x = torch.full((len(lens), max(lens)), 0.37, device="cuda")          # the padding is NOT silence: it must not matter
+    for j, c in enumerate(clips):
+        x[j, :lens[j]] = c
+    return clips, x
+
+
+@pytest.mark.parametrize("unify", [False, True])
+def test_restore_varlen_equals_one_call_per_clip_and_the_oracle(engine, unet_sd, voc_sd, unify):
+    """vfx_restore_gsr_varlen: five clips of five lengths as ONE padded batch give, clip by clip, what a batch-of-one
+    vfx_restore_gsr of that clip gives -- bit for bit: the tile a position falls into differs, the sums that make its value do
+    not -- and what the oracle computes for the clip on its own; past a clip's end both outputs are zero."""
+    from oracle import pipeline
+    clips, x = _varlen_batch(VARLEN)
+    out, logmel = engine.restore_gsr_varlen(x, VARLEN, unify_energy=unify, want_logmel=True)
+    assert engine.take_flags() & 3 == 0
+    tol = engine.tol
+    for j, (c, L) in enumerate(zip(clips, VARLEN)):
+        one, lm1 = engine.restore_gsr(c[None], unify_energy=unify, want_logmel=True)
+        T = L // 441 + 1
+        assert torch.equal(out[j, :L], one[0]), (j, float((out[j, :L] - one[0]).abs().max()))
+        assert torch.equal(logmel[j, :T], lm1[0]), j
+        assert float(out[j, L:].abs().max()) == 0.0 if L < x.shape[1] else True
+        assert float(logmel[j, T:].abs().max()) == 0.0 if T < logmel.shape[1] else True
+    for j in (0, 1):          # the shortest and the longest clip against the CPU oracle, each on its own
+        L = VARLEN[j]
+        ref = pipeline.restore_gsr(unet_sd, voc_sd, clips[j].cpu().numpy()[None, None], unify_energy=unify)
+        lm = logmel[j, :L // 441 + 1].cpu().numpy()
+        assert np.abs(lm - ref["logmel"][0, 0]).mean() < tol["logmel_l1"]
+        err = out[j, :L].cpu().numpy().astype(np.float64) - ref["wav"][0, 0]
+        sisdr = 10 * np.log10((ref["wav"].astype(np.float64) ** 2).sum() / ((err ** 2).sum() + 1e-30))
+        assert sisdr > tol["sisdr"], (j, sisdr)
+
+
+def test_restore_varlen_sub_batches_and_errors(engine, monkeypatch):
+    clips, x = _varlen_batch(VARLEN, seed=90)
+    want = engine.restore_gsr_varlen(x, VARLEN)
+    monkeypatch.setenv("VFX_MAX_CLIPS", "2")          # three launches of the plan: 2 + 2 + 1 clips
+    got = engine.restore_gsr_varlen(x, VARLEN)
+    monkeypatch.delenv("VFX_MAX_CLIPS")
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError, match="share 64"):            # 20000 samples = 46 frames pad to 64, the others to 128
+        engine.restore_gsr_varlen(x, [20000] + VARLEN[1:])
+    with pytest.raises(RuntimeError, match="samples"):
+        engine.restore_gsr_varlen(x, [900] + VARLEN[1:])
+    with pytest.raises(RuntimeError, match="samples"):
+        engine.restore_gsr_varlen(x, [x.shape[1] + 1] + VARLEN[1:])
+    engine.take_flags()
+
+
+def test_restore_list_buckets_by_padded_frames(voicefixer):
+    """restore_list on clips of seven lengths in two padded-frame buckets: two calls of the library instead of seven, results
+    equal to one `restore` per clip."""
+    lens = [30000, 12345, 41000, 20001, 12345, 28224, 50017]       # T = 69, 28, 93, 46, 28, 65, 114 -> padded 128, 64, 128, 64, 64, 128, 128
+    clips, _ = _varlen_batch(lens, seed=110)
+    calls = []
+    eng = voicefixer.engine
+    orig_v, orig_f = eng.restore_gsr_varlen, eng.restore_gsr
+    eng.restore_gsr_varlen = lambda x, l, **k: (calls.append(("varlen", x.shape[0])), orig_v(x, l, **k))[1]
+    eng.restore_gsr = lambda x, **k: (calls.append(("fixed", x.shape[0])), orig_f(x, **k))[1]
+    try:
+        got = voicefixer.restore_list(clips)
+    finally:
+        del eng.restore_gsr_varlen, eng.restore_gsr
+    assert sorted(calls) == [("varlen", 3), ("varlen", 4)], calls
+    for c, g in zip(clips, got):
+        assert torch.equal(g, voicefixer.restore(c[None])[0])
+
+
 def test_handler_end_to_end(voicefixer, unet_sd, voc_sd, tmp_path):
     from oracle import pipeline
     from voicefixer_main_amd import handlers, synth

@@ -504,7 +504,7 @@ void PlanBuilder::add_conv(TapConvParams p) {
   p.tuning = h->cfg.tuning;
   p.short_clip = short_clip;
   finish_params(p);
-  p.ksplit = choose_ksplit(p);
+  p.ksplit = p.lens ? 1 : choose_ksplit(p);  // (a launch with per-clip lengths skips the tiles past a clip's end: no partial sums)
   size_t ws_off = ~size_t(0);
   if (p.ksplit > 1) {  // the partial tiles live in the arena for the duration of this op
     ws_off = alloc_f((int64_t)p.ksplit * p.B * p.out_img_stride * p.Cout);
@@ -847,6 +847,8 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   }
   h->d_flags = static_cast<int*>(h->blob.alloc(sizeof(int)));
   VFX_HIP(hipMemset(h->d_flags, 0, sizeof(int)));
+  h->d_lens = static_cast<int*>(h->blob.alloc(3 * kMaxVarlenClips * sizeof(int)));
+  VFX_HIP(hipMemset(h->d_lens, 0, 3 * kMaxVarlenClips * sizeof(int)));
   *out = h.release();
   VFX_API_END
 }
@@ -1256,6 +1258,90 @@ static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, floa
   }, stream);
   debug_poison(*plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags, &h->prof};
+  plan->run(ctx);
+  VFX_API_END
+}
+
+// A batch of clips of UNEQUAL length through the same per-segment body (the reference restores one file per call, of any
+// length: evaluation_proc/eval.py:119-134, eval_gsr_voicefixer.py:47-74).  wav (B, Lmax): clip b = the first lengths[b] samples
+// of row b.  Every clip gets what its own batch-of-one call computes:
+//   * STFT: frames and the reflection at ITS end (fDomainHelper.py:26-28, center = True framing);
+//   * ResUNet: all clips of a call share the padded frame count 64 * ceil(T_b / 64) -- a REQUIREMENT of this entry point (the
+//     caller buckets by it) -- and a clip's rows past T_b are zeros like the network's own time padding (unet.py:75-77);
+//   * vocoder: every launch stops the clip at its own length (zero padding, the k7 reflections, the tail of -4 frames);
+//   * peak normalisation and trim_center per clip; wav_out (B, Lmax) and logmel_out (B, Tmax, 128) are zero past a clip's end.
+static int vfx_restore_gsr_varlen_1(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out,
+                                    float* logmel_out, int flags, void* stream);
+int vfx_restore_gsr_varlen(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out,
+                           float* logmel_out, int flags, void* stream) {
+  if (!h || B <= 0 || Lmax <= 0 || !lengths)
+    return vfx_restore_gsr_varlen_1(h, wav, B, Lmax, lengths, wav_out, logmel_out, flags, stream);
+  const int T = Lmax / h->cfg.hop + 1;
+  const int step = std::min(kMaxVarlenClips, max_clips_per_launch(h, T, true, false, true));
+  for (int b = 0; b < B; b += step) {
+    const int rc = vfx_restore_gsr_varlen_1(h, wav + (int64_t)b * Lmax, std::min(step, B - b), Lmax, lengths + b,
+                                            wav_out + (int64_t)b * Lmax, logmel_out ? logmel_out + (int64_t)b * T * 128 : nullptr,
+                                            flags, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static int vfx_restore_gsr_varlen_1(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out,
+                                    float* logmel_out, int flags, void* stream) {
+  VFX_API_BEGIN_H(h)
+  VFX_CHECK(h && wav && wav_out && lengths && B > 0 && B <= kMaxVarlenClips, "bad argument");
+  VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL] && h->voc, "vfx_restore_gsr_varlen: weights are not finalized");
+  const int hop = h->cfg.hop;
+  const int T = frames_of(h, Lmax), Tpad = (T + 63) / 64 * 64;
+  std::vector<int> host(3 * (size_t)B);
+  for (int b = 0; b < B; ++b) {
+    const int Lb = lengths[b];
+    VFX_CHECK(Lb > h->cfg.n_fft / 2 && Lb <= Lmax, "vfx_restore_gsr_varlen: clip %d has %d samples (need %d < length <= Lmax = %d)", b, Lb,
+              h->cfg.n_fft / 2, Lmax);
+    const int Tb = Lb / hop + 1;
+    VFX_CHECK((Tb + 63) / 64 * 64 == Tpad, "vfx_restore_gsr_varlen: clip %d has %d frames (padded %d) but the batch's longest row pads to %d -- "
+              "the clips of one call must share 64 * ceil(T / 64): bucket them by it", b, Tb, (Tb + 63) / 64 * 64, Tpad);
+    host[b] = Lb;
+    host[B + b] = Tb;
+    host[2 * (size_t)B + b] = Tb + Tb % 2 + 4;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // the per-clip lengths of THIS call, in stream order behind the kernels of the previous one
+  int* const d_l = h->d_lens;
+  int* const d_t = h->d_lens + kMaxVarlenClips;
+  int* const d_tp = h->d_lens + 2 * kMaxVarlenClips;
+  launch_set_lens(h->d_lens, kMaxVarlenClips, host.data(), B, s);
+  const int64_t Llong = vocoder_out_len(h->cfg, T);
+  const int unify = flags & 1;
+  auto plan = get_plan(h, key_of("restore_gsr_vl", B, T, unify), [&](PlanBuilder& pb) {
+    const int64_t nmel = (int64_t)B * T * 128;
+    const size_t o_mel = pb.alloc_f(nmel), o_log = pb.alloc_f(nmel), o_den = pb.alloc_f(nmel);
+    const size_t o_long = pb.alloc_f((int64_t)B * Llong), o_ws = pb.alloc_f(2 * B + 64), o_pk = pb.alloc_f(B + 64);
+    vfx_handle* hh = pb.h;
+    Plan* pl = pb.plan;
+    pb.lens_t = d_t;
+    pb.lens_tp = d_tp;
+    pl->ops.push_back([=](const RunCtx& c) {
+      launch_stft_mel(hh->fe, c.ext[0], B, Lmax, T, reinterpret_cast<float*>(pl->bound_base + o_mel), nullptr, nullptr,
+                      nullptr, 0, hh->cfg.hop, 1e-8f, c.stream, d_l);
+    });
+    build_unet_mel(pb, B, T, arena_buf(o_mel), arena_buf(o_log));
+    pl->ops.push_back([=](const RunCtx& c) {
+      float* lg = reinterpret_cast<float*>(pl->bound_base + o_log);
+      if (c.ext[2]) launch_copy_rows_masked(lg, c.ext[2], B, T, 128, d_t, c.stream);
+      launch_from_log(lg, reinterpret_cast<float*>(pl->bound_base + o_mel), B, T, unify,
+                      reinterpret_cast<float*>(pl->bound_base + o_ws), reinterpret_cast<float*>(pl->bound_base + o_den),
+                      c.stream, d_t);
+    });
+    const BufRef peak_buf = arena_buf(o_pk);
+    build_vocoder(pb, B, T, arena_buf(o_den), arena_buf(o_long), &peak_buf);
+    pl->ops.push_back([=](const RunCtx& c) {
+      launch_peak_trim_varlen(reinterpret_cast<float*>(pl->bound_base + o_long), B, Llong, Lmax, hh->cfg.hop, d_l, d_tp,
+                              reinterpret_cast<float*>(pl->bound_base + o_pk), c.ext[1], c.stream, c.flags);
+    });
+  }, stream);
+  debug_poison(*plan, stream);
+  RunCtx ctx{s, {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
 }

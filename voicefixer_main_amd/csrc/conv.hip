@@ -71,7 +71,7 @@ namespace vfx {
 // the 32-channel form, and every fetched byte is an operand).  HI without H64: raw fp32 sources, 32-channel stages,
 // transformed in place to fp16 in the first half of the row, two K = 16 steps per tap.
 // RA (with H64): the launch's residual is an activated fp16 tensor, inverted in the epilogue (TapConvParams::residual_act).
-template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false>
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false, bool VL = false>
 __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
   static_assert(!H64 || (HI && SPLIT), "H64 is a variant of the 16-bit mode");
   static_assert(!RA || H64, "an activated residual exists in the 16-bit mode's activated-source launches only");
@@ -118,8 +118,21 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   const int ti = mt % p.tiles_h;
   const int img = mt / p.tiles_h;
   const int i0 = ti * p.TH, j0 = tj * p.TW;
-  const int Hi = p.Hi, Wi = p.Wi, PW = p.PW, P = p.P;
-  const int in_img_stride = p.in_img_stride, in_limit = p.in_limit;
+  const int Hi = p.Hi, PW = p.PW, P = p.P;
+  const int in_img_stride = p.in_img_stride;
+  // VL: batches of clips of unequal length (TapConvParams::lens; the vocoder's 1-D launches): clip `img` ends at its own
+  // length -- positions past it read as zeros (or reflect at the clip's own end) and are not written, exactly what a
+  // batch-of-one call of that clip computes; a tile that lies wholly past the end has nothing to do.  A variant of its own:
+  // the per-clip limits are computed values that stay live through the stage loop, where the uniform ones are re-read from
+  // the parameter block -- three registers the 168-register tiles of the ResUNet launches do not have.
+  int in_limit = p.in_limit, out_limit = p.out_limit, Wi = p.Wi;
+  if constexpr (VL) {
+    const int n = ((const VFX_GLOBAL int*)p.lens)[__builtin_amdgcn_readfirstlane(img)];
+    in_limit = min(in_limit, n * p.lens_mul_in);
+    out_limit = min(out_limit, n * p.lens_mul_out);
+    if (Hi == 1) Wi = in_limit;
+    if ((i0 * p.sh + p.oh0) * p.Wo + j0 * p.sw + p.ow0 >= out_limit) return;
+  }
   const int nq = (P + 31) >> 5;  // patch row groups in use (uniform)
 
   // ---- per-thread roles ---------------------------------------------------------------------------
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       const int oh = i * p.sh + p.oh0, ow = j * p.sw + p.ow0;
       const int o = oh * p.Wo + ow;
       // (out_cmul: phase r of an odd-width phased launch writes true column ow + r)
-      if (oh < p.Ho && ow + (p.out_cmul ? phase : 0) < p.Wo && o < p.out_limit) idx = img * p.out_img_stride + o;
+      if (oh < p.Ho && ow + (p.out_cmul ? phase : 0) < p.Wo && o < out_limit) idx = img * p.out_img_stride + o;
     }
     otab[tid] = idx;
   }
@@ -491,15 +504,15 @@ static size_t conv_lds_bytes(int BN, bool hi) {
   return main_bytes + CBM * 4;
 }
 
-template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false>
+template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false, bool VL = false>
 static void launch_one(int grid, hipStream_t stream, const TapConvParams* dparams) {
   const size_t lds = conv_lds_bytes(BN, HI);
   static uint64_t attr_devices = 0;  // one static per instantiation
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64, RA>),
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64, RA, VL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64, RA>), dim3(grid), dim3(256), lds, stream, dparams);
+  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64, RA, VL>), dim3(grid), dim3(256), lds, stream, dparams);
 }
 
 #ifdef VFX_ABLATION_BUILD
@@ -522,14 +535,27 @@ static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvP
 }
 #endif
 
-template <bool ELU, bool SPLIT, bool HI = false, bool H64 = false, bool RA = false>
+template <bool ELU, bool SPLIT, bool HI = false, bool H64 = false, bool RA = false, bool VL = false>
 static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams* dparams) {
   switch (BN) {
     // H64: a tap is four K = 16 steps (as long as two taps of the 32-channel form), so one tap of look-ahead covers the
     // same time with a third less ring registers (with three groups the BN = 128 tile spills at three waves per SIMD)
-    case 128: launch_one<128, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA>(grid, stream, dparams); break;
-    case 64: launch_one<64, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA>(grid, stream, dparams); break;
-    default: launch_one<32, ELU, SPLIT, 0, 2, HI, H64, RA>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
+    case 128: launch_one<128, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA, VL>(grid, stream, dparams); break;
+    case 64: launch_one<64, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA, VL>(grid, stream, dparams); break;
+    default: launch_one<32, ELU, SPLIT, 0, 2, HI, H64, RA, VL>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
+  }
+}
+// the same with the per-clip lengths of a varlen batch (TapConvParams::lens): the VL variants exist without an ELU prologue only
+// (the vocoder applies its ELUs in the producers' epilogues)
+template <bool SPLIT, bool HI = false, bool H64 = false, bool RA = false>
+static void launch_vl(bool vl, bool elu, int BN, int grid, hipStream_t stream, const TapConvParams* dparams) {
+  if (vl) {
+    VFX_CHECK(!elu, "conv: a launch with per-clip lengths cannot have an ELU prologue");
+    launch_bn<false, SPLIT, HI, H64, RA, true>(BN, grid, stream, dparams);
+  } else if (elu) {
+    if constexpr (!H64) launch_bn<true, SPLIT, HI, H64, RA>(BN, grid, stream, dparams);
+  } else {
+    launch_bn<false, SPLIT, HI, H64, RA>(BN, grid, stream, dparams);
   }
 }
 
@@ -560,6 +586,8 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
   static const int abl = getenv("VFX_ABLATE") ? atoi(getenv("VFX_ABLATE")) : 0;
   if (abl && hp.split && !elu && BN == 128 && launch_ablated(abl, (int)grid, stream, dparams)) return;
 #endif
+  const bool vl = hp.lens != nullptr;
+  VFX_CHECK(!vl || KS == 1, "conv: a launch with per-clip lengths cannot be split along K");
   if (hp.split && hp.hionly) {
     // 16-bit mode: activated sources are fp16 tensors with 64-channel stages, raw fp32 sources keep 32-channel stages;
     // one launch has one kind (the hand-counted weight waits depend on the loads per tap)
@@ -569,19 +597,15 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
     VFX_CHECK(!hp.residual_act || n_act, "conv: an activated residual goes with activated sources");
     if (n_act) {
       VFX_CHECK(!elu, "conv: an activated source has no prologue");
-      if (hp.residual_act) launch_bn<false, true, true, true, true>(BN, (int)grid, stream, dparams);
-      else launch_bn<false, true, true, true>(BN, (int)grid, stream, dparams);
-    } else if (elu) {
-      launch_bn<true, true, true>(BN, (int)grid, stream, dparams);
+      if (hp.residual_act) launch_vl<true, true, true, true>(vl, false, BN, (int)grid, stream, dparams);
+      else launch_vl<true, true, true>(vl, false, BN, (int)grid, stream, dparams);
     } else {
-      launch_bn<false, true, true>(BN, (int)grid, stream, dparams);
+      launch_vl<true, true>(vl, elu, BN, (int)grid, stream, dparams);
     }
   } else if (hp.split) {
-    if (elu) launch_bn<true, true>(BN, (int)grid, stream, dparams);
-    else launch_bn<false, true>(BN, (int)grid, stream, dparams);
+    launch_vl<true>(vl, elu, BN, (int)grid, stream, dparams);
   } else {
-    if (elu) launch_bn<true, false>(BN, (int)grid, stream, dparams);
-    else launch_bn<false, false>(BN, (int)grid, stream, dparams);
+    launch_vl<false>(vl, elu, BN, (int)grid, stream, dparams);
   }
   VFX_HIP(hipGetLastError());
 }

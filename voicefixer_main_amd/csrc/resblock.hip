@@ -124,6 +124,10 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   const int base_x = base_h - d;                                // position of x patch pixel (0, 0)
   const int Hh = p.H, Ww = p.W;      // 2-D mode: image extent
   const int i0 = ti * (TH - 2);      // 2-D mode: first output row of the tile
+  // 1-D layers, batches of clips of unequal length (ResBlockParams::lens): this clip's sequence ends at Tb <= T -- positions past
+  // it read as zeros, h is zero there, nothing is stored there; a tile wholly past the end has nothing to do
+  const int Tb = (!G2 && p.lens) ? min(T, ((const VFX_GLOBAL int*)p.lens)[__builtin_amdgcn_readfirstlane(img)] * p.lens_mul) : T;
+  if (!G2 && base_h + 1 >= Tb) return;
   const float slope = p.slope;
 
   const int lr = tid >> 3, cg = tid & 7;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
       okmask |= ok ? (1u << q) : 0u;
     } else {
       const int pos = base_x + pi * rowstride + pj;
-      const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
+      const bool ok = (prow < P) & ((unsigned)pos < (unsigned)Tb);
       voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 4);
       okmask |= ok ? (1u << q) : 0u;
     }
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
       hval[a] = (li < TH) & ((unsigned)(i0 - 1 + li) < (unsigned)Hh) & ((unsigned)(j0 - 1 + lj) < (unsigned)Ww);
     } else {
       const int pos = base_h + li * rowstride + lj;
-      hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
+      hval[a] = (li < TH) & ((unsigned)pos < (unsigned)Tb);
     }
   }
   const unsigned nb_off = (unsigned)(wn * 1024 + lane * 4) * 4u;
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
       otab[tid] = ok ? (img * Hh + r) * Ww + c : -1;
     } else {
       const int pos = base_h + li * rowstride + lj;
-      const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) &
+      const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) &
                       (!p.fold | (j0 + lj - 1 < d));
       otab[tid] = ok ? img * T + pos : -1;
     }

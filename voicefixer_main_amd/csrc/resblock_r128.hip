@@ -84,6 +84,10 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   // position of h pixel (0, 0); a pair's tile starts 1 + d2 further left (the second layer's halo)
   const int base_h = PAIR ? j0 - 2 - d2 : (p.fold ? ti * TH * d + j0 - 1 : j0 - 1);
   const int base_x = base_h - d;                                // position of patch pixel (0, 0)
+  // batches of clips of unequal length (ResBlockParams::lens): this clip's sequence ends at Tb <= T -- positions past it read as
+  // zeros, h (and a pair's intermediate tensor) is zero there, nothing is stored there; a tile wholly past the end has nothing to do
+  const int Tb = p.lens ? min(T, ((const VFX_GLOBAL int*)p.lens)[__builtin_amdgcn_readfirstlane(img)] * p.lens_mul) : T;
+  if ((PAIR ? j0 : base_h + 1) >= Tb) return;
   const float slope = p.slope;
   // m / W1 and prow / PW as multiply-shift (rows < 512, divisors <= 320: exact; cf. resblock_rw.hip): an integer division is ~25 VALU
   // instructions, a tile has 25 of them per thread
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     const int li = (int)(((unsigned)ml * inv_w1) >> 20), lj = ml - li * W1;
     arow1[a] = li < TH ? li * PW + lj : 0;
     const int pos = base_h + li * rowstride + lj;
-    hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
+    hval[a] = (li < TH) & ((unsigned)pos < (unsigned)Tb);
   }
   // weights: (32-channel chunk, tap) blocks of C / 32 cout blocks x 1024 floats; this wave's cout blocks are 2 wn, 2 wn + 1
   const unsigned nb_off = (unsigned)(2 * wn * 1024 + lane * 4) * 4u;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       prow[j] = j < KEEP ? rt + 8 * j + off : (hh < off ? hh : hh + MT);
       const int pi = (int)(((unsigned)prow[j] * inv_pw) >> 20), pj = prow[j] - pi * PW;
       const int pos = base_x + pi * rowstride + pj;
-      const bool ok = (prow[j] < P) & ((unsigned)pos < (unsigned)T);
+      const bool ok = (prow[j] < P) & ((unsigned)pos < (unsigned)Tb);
       const unsigned o = ok ? (unsigned)(img * T + pos) * (unsigned)(C * EB) + lane_off : 0xfffffff0u;
       if constexpr (X16) raw[j] = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)o, 0, 0);
       else raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 #pragma unroll
       for (int q = 0; q < NPASS; ++q) {
         const int m = r0 + q * RPP;
-        const bool ok = (m >= 1) & (m <= MT - 2) & ((unsigned)(base_h + m) < (unsigned)T);
+        const bool ok = (m >= 1) & (m <= MT - 2) & ((unsigned)(base_h + m) < (unsigned)Tb);
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(keep[q][e], keep[q][e] * slope) : 0.f;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
       const int m = wm * 64 + a * 32 + l31o;
-      hval2[a] = (m >= 1 + d2) & (m <= MT - 2 - d2) & ((unsigned)(base_h + m) < (unsigned)T);
+      hval2[a] = (m >= 1 + d2) & (m <= MT - 2 - d2) & ((unsigned)(base_h + m) < (unsigned)Tb);
     }
     // (cleared here, not when they were staged: 64 live zeros beside the residual and the ring do not fit the register file)
 #pragma unroll
@@ -438,8 +442,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       const int m = r0o + q * RPP;  // h pixel of the staged row
       const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
       const int pos = base_h + li * rowstride + lj;
-      const bool ok = PAIR ? ((m >= 2 + d2) & (m <= MT - 3 - d2) & ((unsigned)pos < (unsigned)T))
-                           : ((li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d)));
+      const bool ok = PAIR ? ((m >= 2 + d2) & (m <= MT - 3 - d2) & ((unsigned)pos < (unsigned)Tb))
+                           : ((li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) & (!p.fold | (j0 + lj - 1 < d)));
       const f32x4 val = *reinterpret_cast<const f32x4*>(smem + m * LDO + 4 * c4) + bv + keep[q];  // + the residual: this thread's own rows
       const unsigned off = (unsigned)(img * T + pos) * (unsigned)(C * 4) + 16u * c4;
       if constexpr (X16) {

@@ -162,19 +162,22 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     int img, j0, base_h;
     tile_geom(t, img, j0, base_h);
     const int base_x = base_h - d;
+    // the end of THAT tile's clip (ResBlockParams::lens; on the fp16 trunk only -- the fp32-trunk variants of VFX_TUNE_F32_TRUNK have
+    // no register left for it and the plan refuses the combination)
+    const int Tn = (X16 && p.lens) ? min(T, ((const VFX_GLOBAL int*)p.lens)[__builtin_amdgcn_readfirstlane(img)] * p.lens_mul) : T;
     // (element offsets; X16: fp16 elements)
     const char* xi = reinterpret_cast<const char*>(p.x) + ((int64_t)img * T * C + 4 * cg) * (X16 ? 2 : 4);
 #pragma unroll
     for (int q = 0; q < NCQ; ++q) {
       const int rel = rel_of(crow(q)), pos = base_x + rel;
       PC[q] = ld_t{};
-      if (rel >= 0 && (unsigned)pos < (unsigned)T) PC[q] = *(const VFX_GLOBAL ld_t*)(xi + (int64_t)pos * C * (X16 ? 2 : 4));
+      if (rel >= 0 && (unsigned)pos < (unsigned)Tn) PC[q] = *(const VFX_GLOBAL ld_t*)(xi + (int64_t)pos * C * (X16 ? 2 : 4));
     }
 #pragma unroll
     for (int q = 0; q < NHQ; ++q) {
       const int rel = rel_of(hrow(q)), pos = base_x + rel;
       PH[q] = ld_t{};
-      if (rel >= 0 && (unsigned)pos < (unsigned)T) PH[q] = *(const VFX_GLOBAL ld_t*)(xi + (int64_t)pos * C * (X16 ? 2 : 4));
+      if (rel >= 0 && (unsigned)pos < (unsigned)Tn) PH[q] = *(const VFX_GLOBAL ld_t*)(xi + (int64_t)pos * C * (X16 ? 2 : 4));
     }
   };
   // raw row -> LeakyReLU -> fp16 -> this thread's 8 bytes of the patch row: piece cg >> 1 (8 channels) at slot piece ^ key
@@ -191,6 +194,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     *reinterpret_cast<uint2*>(patch + pr * ROWB + (((cg >> 1) ^ ((pr >> 1) & 7)) << 4) + 8 * (cg & 1)) = make_uint2(v.x, v.y);
   };
 
+  // batches of clips of unequal length (ResBlockParams::lens): the end of the CURRENT tile's clip, set per tile -- positions past it
+  // read as zeros, h (and a pair's intermediate tensor) is zero there, nothing is stored there
+  int Tb = T;
   f32x16 acc[WM];
 #pragma unroll
   for (int a = 0; a < WM; ++a)
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
         const int m = (wm * WM + a) * 32 + l31_v;
-        const bool hval = (unsigned)(base_h + (SECOND ? m : hrel_of(m))) < (unsigned)T;
+        const bool hval = (unsigned)(base_h + (SECOND ? m : hrel_of(m))) < (unsigned)Tb;
         char* rowp = hbuf + m * ROWB + 8 * lh;
         const int key = (m >> 1) & 7;
 #pragma unroll
@@ -308,6 +314,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     asm volatile("" : "+v"(lr_v), "+v"(l31_v));
     int img, j0, base_h;
     tile_geom(t, img, j0, base_h);
+    if (X16 && p.lens) {
+      Tb = min(T, ((const VFX_GLOBAL int*)p.lens)[__builtin_amdgcn_readfirstlane(img)] * p.lens_mul);
+      if ((PAIR ? j0 : base_h + 1) >= Tb) {  // the tile lies wholly past the end of its clip: nothing to compute or store
+        if (t + 1 < t_end) request(t + 1);
+        continue;
+      }
+    }
     int arow1[WM];  // patch row of this lane's h pixels
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         for (int qq = 0; qq < NCQ / 2; ++qq) {
           const int q = half * (NCQ / 2) + qq;
           const int m = lr_v + RQ * q;
-          const bool ok = (m >= 1) & (m <= MT - 2) & ((unsigned)(base_h + m) < (unsigned)T);
+          const bool ok = (m >= 1) & (m <= MT - 2) & ((unsigned)(base_h + m) < (unsigned)Tb);
           const f32x4 b2a = *reinterpret_cast<const f32x4*>(b1s + C + 4 * cg);
           const f32x4 val = (*reinterpret_cast<const f32x4*>(smem + (m - half * (MT / 2)) * LDO + 4 * cg) + K[q]) + b2a;
           K[q] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -393,11 +406,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
           bool ok;
           if constexpr (PAIR) {
             pos = base_h + m;
-            ok = (m >= 2 + d2) & (m <= MT - 3 - d2) & ((unsigned)pos < (unsigned)T);
+            ok = (m >= 2 + d2) & (m <= MT - 3 - d2) & ((unsigned)pos < (unsigned)Tb);
           } else {
             const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
             pos = base_h + li * rowstride + lj;
-            ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
+            ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) & (!p.fold | (j0 + lj - 1 < d));
           }
           const f32x4 val = (*reinterpret_cast<const f32x4*>(smem + (m - half * (MT / NHALF)) * LDO + 4 * cg) + K[q]) + b2v;
           if constexpr (X16) {
@@ -464,6 +477,8 @@ static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t
 
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   VFX_CHECK(hp.rw && hp.hionly && hp.C == 64 && !hp.geo2d && !hp.asrc, "resblock_rw: needs the 16-bit mode and C = 64");
+  VFX_CHECK(!hp.lens || hp.x16, "resblock_rw: a batch of clips of unequal length needs the fp16 trunk of the 16-bit mode (not with "
+            "VFX_TUNE_F32_TRUNK, and 0 < voc_res_slope <= 1); use precision 1 otherwise");
   const int64_t ntiles = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
   VFX_CHECK(ntiles > 0 && ntiles < ((int64_t)1 << 30), "resblock_rw: bad tile count");
   VFX_CHECK(hp.x && (hp.y || (hp.x16 && hp.ya)), "resblock_rw: no input / no output");

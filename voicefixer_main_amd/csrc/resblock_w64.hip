@@ -79,6 +79,10 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   const int j0 = tj * p.TWo;
   const int base_h = p.fold ? ti * TH * d + j0 - 1 : j0 - 1;  // position of h pixel (0, 0)
   const int base_x = base_h - d;                                // position of patch pixel (0, 0)
+  // batches of clips of unequal length (ResBlockParams::lens): this clip's sequence ends at Tb <= T -- positions past it read as
+  // zeros, h is zero there, nothing is stored there; a tile wholly past the end has nothing to do
+  const int Tb = p.lens ? min(T, ((const VFX_GLOBAL int*)p.lens)[__builtin_amdgcn_readfirstlane(img)] * p.lens_mul) : T;
+  if (base_h + 1 >= Tb) return;
   const float slope = p.slope;
   // m / W1 and prow / PW as multiply-shift (rows < 512, divisors <= 320: exact; cf. resblock_rw.hip): an integer division is ~25 VALU
   // instructions, a tile has 25 of them per thread
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
       const int prow = lr + RG * q;
       const int pi = (int)(((unsigned)prow * inv_pw) >> 20), pj = prow - pi * PW;
       const int pos = base_x + pi * rowstride + pj;
-      const bool ok = (prow < P) & ((unsigned)pos < (unsigned)T);
+      const bool ok = (prow < P) & ((unsigned)pos < (unsigned)Tb);
       voff[q] = (unsigned)(img * T + pos) * (unsigned)(C * 2);
       okmask |= ok ? (1u << q) : 0u;
     }
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
     const int li = (int)(((unsigned)ml * inv_w1) >> 20), lj = ml - li * W1;
     arow1[a] = li < TH ? li * PW + lj : 0;
     const int pos = base_h + li * rowstride + lj;
-    hval[a] = (li < TH) & ((unsigned)pos < (unsigned)T);
+    hval[a] = (li < TH) & ((unsigned)pos < (unsigned)Tb);
   }
   // weights: (64-channel chunk, tap) blocks of C / 32 cout blocks x 1024 floats; this wave's cout blocks are 2 w, 2 w + 1
   const unsigned nb_off = (unsigned)(2 * wave_u * 1024 + lane * 4) * 4u;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
       const int m = r0 + (sp * SUB + q) * RPP;  // h pixel of the staged row
       const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
       const int pos = base_h + li * rowstride + lj;
-      const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)T) & (!p.fold | (j0 + lj - 1 < d));
+      const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) & (!p.fold | (j0 + lj - 1 < d));
       ooff[sp][q] = ok ? (unsigned)(img * T + pos) * (unsigned)(C * EB) : kOob;
     }
   // The residual runs THREE sub-passes (12 loads, 48 registers) ahead: the first three are requested here, before the staging

@@ -574,10 +574,14 @@ void build_unet_mel(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef log
   const int Tpad = (T + 63) / 64 * 64, W0 = 127;
   pb.short_clip = Tpad <= 128 ? 1 : 0;  // split-K rule of the deep levels (TapConvParams::short_clip)
   Plan* pl = pb.plan;
+  // a varlen batch (PlanBuilder::lens_t): every clip has its own frame count inside the SAME padded length -- the rows past it
+  // are zeros like the network's own time padding (unet.py:75-77), so the trunk computes for each clip what its batch-of-one
+  // call computes; no kernel of the trunk needs to know
+  const int* lens_t = pb.lens_t;
   const size_t x_off = pb.alloc_f((int64_t)B * Tpad * W0);
   pl->ops.push_back([=](const RunCtx& c) {
     launch_prep_logmel(resolve(pl, c, mel_linear), B, T, Tpad, reinterpret_cast<float*>(pl->bound_base + x_off), c.flags,
-                       c.stream);
+                       c.stream, lens_t);
   });
   TrunkBuilder tb{pb, Wt, B};
   Act4 y = tb.run(x_off, Tpad, W0, /*both=*/false);

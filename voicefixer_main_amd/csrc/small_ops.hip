@@ -15,8 +15,10 @@ static inline unsigned nblocks(int64_t n, int per) { return (unsigned)((n + per 
 // ---------------------------------------------------------------------------------------------
 // Generator.forward's to_log (models/gsr_voicefixer.py:87; pytorch_util.py:157-159) fused with
 // the time padding and last-bin drop of unet.py:75-78:  (B,T,128) -> (B,Tpad,127).
+// lens_t != nullptr (batches of clips of unequal length): clip b has lens_t[b] <= T frames in its T rows of `mel`; the rows past
+// them are the network's zero time padding, like the rows T .. Tpad
 __global__ void k_prep_logmel(const float* __restrict__ mel, int B, int T, int Tpad, float* __restrict__ x,
-                              int* __restrict__ flags) {
+                              int* __restrict__ flags, const int* __restrict__ lens_t) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)B * Tpad * 127;
   const bool live = idx < total;
@@ -26,7 +28,7 @@ __global__ void k_prep_logmel(const float* __restrict__ mel, int B, int T, int T
   const int b = r / Tpad;
   float v = 0.f;
   bool neg = false;
-  if (live && i < T) {
+  if (live && i < (lens_t ? min(T, lens_t[b]) : T)) {
     const float* row = mel + ((int64_t)b * T + i) * 128;
     const float m = row[f];
     // to_log asserts on the WHOLE tensor (pytorch_util.py:158): bin 127 is dropped from the network's input but not from
@@ -50,8 +52,8 @@ __global__ void k_prep_spec(const float* __restrict__ sp, int B, int T, int Tpad
   x[idx] = i < T ? sp[((int64_t)b * T + i) * 1025 + f] : 0.f;
 }
 
-void launch_prep_logmel(const float* mel, int B, int T, int Tpad, float* x, int* flags, hipStream_t s) {
-  hipLaunchKernelGGL(k_prep_logmel, dim3(nblocks((int64_t)B * Tpad * 127, 256)), dim3(256), 0, s, mel, B, T, Tpad, x, flags);
+void launch_prep_logmel(const float* mel, int B, int T, int Tpad, float* x, int* flags, hipStream_t s, const int* lens_t) {
+  hipLaunchKernelGGL(k_prep_logmel, dim3(nblocks((int64_t)B * Tpad * 127, 256)), dim3(256), 0, s, mel, B, T, Tpad, x, flags, lens_t);
   VFX_HIP(hipGetLastError());
 }
 void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s) {
@@ -196,8 +198,11 @@ void launch_final_1x1(const float* y, int B, int Tpad, int W, const float* w32, 
 // Vocoder input normalisation (voicefixer.Vocoder.__call__, see oracle/vocoder.py):
 //   (B,T,128) linear mel -> (B,Tp,128) conditioning in [-R, R], frames >= T filled with -R.
 // ---------------------------------------------------------------------------------------------
+// lens_t != nullptr (batches of clips of unequal length): clip b has lens_t[b] <= T frames; its tail of -R frames follows THEM
+// (rows past its own T_b + T_b % 2 + 4 are never read: the vocoder's launches stop at the clip's length)
 __global__ void k_voc_prep(const float* __restrict__ mel, int T, int Tp, const float* __restrict__ inv_w,
-                           float amp_floor, float min_db, float range, int64_t total, float* __restrict__ cond) {
+                           float amp_floor, float min_db, float range, int64_t total, float* __restrict__ cond,
+                           const int* __restrict__ lens_t) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int f = idx & 127;
@@ -205,7 +210,7 @@ __global__ void k_voc_prep(const float* __restrict__ mel, int T, int Tp, const f
   const int t = r % Tp;
   const int64_t b = r / Tp;
   float v = -range;
-  if (t < T) {
+  if (t < (lens_t ? min(T, lens_t[b]) : T)) {
     const float m = fabsf(mel[(b * T + t) * 128 + f] * inv_w[f]);
     float s = 20.f * log10f(fmaxf(m, amp_floor)) - 20.f;
     s = (s - min_db) / (-min_db) * (2.f * range) - range;
@@ -215,10 +220,10 @@ __global__ void k_voc_prep(const float* __restrict__ mel, int T, int Tp, const f
 }
 
 void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_weight, float amp_floor, float min_db,
-                     float range, float* cond, hipStream_t s) {
+                     float range, float* cond, hipStream_t s, const int* lens_t) {
   const int64_t total = (int64_t)B * Tp * 128;
   hipLaunchKernelGGL(k_voc_prep, dim3(nblocks(total, 256)), dim3(256), 0, s, mel, T, Tp, inv_weight, amp_floor, min_db,
-                     range, total, cond);
+                     range, total, cond, lens_t);
   VFX_HIP(hipGetLastError());
 }
 
@@ -234,13 +239,18 @@ void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_we
 template <int CPL, bool X16>  // channels per lane = C / 8 (4, 8 or 16); X16: x is the fp16 trunk of the 16-bit mode
 __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, int T, const float* __restrict__ w /*[7][C]*/,
                                                     float bias, float slope, float* __restrict__ wav,
-                                                    unsigned* __restrict__ peak /*[B] or null*/) {
+                                                    unsigned* __restrict__ peak /*[B] or null*/,
+                                                    const int* __restrict__ lens /*[B] vocoder frames per clip, or null*/, int hop) {
   constexpr int C = 8 * CPL;
   const int b = blockIdx.y;
+  // batches of clips of unequal length: clip b ends (reflects, stops writing, stops counting for the peak) at its own length;
+  // Ts stays the stride between clips
+  const int Ts = T;
+  if (lens) T = min(T, lens[b] * hop);
   const int grp = threadIdx.x >> 3, g = threadIdx.x & 7;
   const int t0 = (blockIdx.x * 32 + grp) * 8;  // first output sample of the group
-  const float* xb = x + (int64_t)b * T * C + g * CPL;
-  const _Float16* xh = reinterpret_cast<const _Float16*>(x) + (int64_t)b * T * C + g * CPL;
+  const float* xb = x + (int64_t)b * Ts * C + g * CPL;
+  const _Float16* xh = reinterpret_cast<const _Float16*>(x) + (int64_t)b * Ts * C + g * CPL;
   float wk[7][CPL];
 #pragma unroll
   for (int k = 0; k < 7; ++k)
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, 
   float m = 0.f;
   if (t < T) {
     const float y = tanhf(mine + bias);
-    wav[(int64_t)b * T + t] = y;
+    wav[(int64_t)b * Ts + t] = y;
     m = fabsf(y);
   }
   if (peak) {
@@ -313,16 +323,16 @@ __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, 
 }
 
 void launch_voc_final(const float* x, int x_f16, int B, int T, int C, const float* w, float bias, float slope, float* wav,
-                      unsigned* peak, hipStream_t s) {
+                      unsigned* peak, hipStream_t s, const int* lens, int hop) {
   const dim3 grid((T + 255) / 256, B);
   if (peak) VFX_HIP(hipMemsetAsync(peak, 0, sizeof(unsigned) * B, s));
   switch (C * 2 + (x_f16 ? 1 : 0)) {
-    case 64: hipLaunchKernelGGL((k_voc_final<4, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
-    case 65: hipLaunchKernelGGL((k_voc_final<4, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
-    case 128: hipLaunchKernelGGL((k_voc_final<8, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
-    case 129: hipLaunchKernelGGL((k_voc_final<8, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
-    case 256: hipLaunchKernelGGL((k_voc_final<16, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
-    case 257: hipLaunchKernelGGL((k_voc_final<16, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak); break;
+    case 64: hipLaunchKernelGGL((k_voc_final<4, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak, lens, hop); break;
+    case 65: hipLaunchKernelGGL((k_voc_final<4, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak, lens, hop); break;
+    case 128: hipLaunchKernelGGL((k_voc_final<8, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak, lens, hop); break;
+    case 129: hipLaunchKernelGGL((k_voc_final<8, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak, lens, hop); break;
+    case 256: hipLaunchKernelGGL((k_voc_final<16, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak, lens, hop); break;
+    case 257: hipLaunchKernelGGL((k_voc_final<16, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak, lens, hop); break;
     default: VFX_CHECK(false, "vocoder tail: %d channels are not supported (32, 64 or 128)", C);
   }
   VFX_HIP(hipGetLastError());
@@ -334,8 +344,9 @@ void launch_voc_final(const float* x, int x_f16, int B, int T, int C, const floa
 // from_log (pytorch_util.py:161-163): 10 ** min(x, 5).  With `sums` != null also accumulates the
 // per-clip energy of mel bins 5..24 of the estimate and of the input (amp_to_original_f,
 // tools/utils.py:50-55): sums[2b] += est, sums[2b+1] += target.
+// lens_t != nullptr (batches of clips of unequal length): only the lens_t[b] frames clip b really has count for its energies
 __global__ void k_from_log(const float* __restrict__ logmel, const float* __restrict__ mel_in, int T, int64_t total,
-                           float* __restrict__ sums, float* __restrict__ mel_out) {
+                           float* __restrict__ sums, float* __restrict__ mel_out, const int* __restrict__ lens_t) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float e = 0.f, g = 0.f;
   int64_t b = 0;
@@ -344,7 +355,8 @@ __global__ void k_from_log(const float* __restrict__ logmel, const float* __rest
     mel_out[idx] = v;
     const int f = idx & 127;
     b = (idx >> 7) / T;
-    if (sums && f >= 5 && f < 25) {
+    const int t = (int)((idx >> 7) - b * T);
+    if (sums && f >= 5 && f < 25 && (!lens_t || t < lens_t[b])) {
       e = v;
       g = mel_in[idx];
     }
@@ -367,11 +379,11 @@ __global__ void k_scale_by_ratio(float* __restrict__ mel, int T, int64_t total, 
 }
 
 void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int unify, float* sums, float* mel_out,
-                     hipStream_t s) {
+                     hipStream_t s, const int* lens_t) {
   const int64_t total = (int64_t)B * T * 128;
   if (unify) VFX_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 2 * B, s));
   hipLaunchKernelGGL(k_from_log, dim3(nblocks(total, 256)), dim3(256), 0, s, logmel, mel_in, T, total,
-                     unify ? sums : nullptr, mel_out);
+                     unify ? sums : nullptr, mel_out, lens_t);
   if (unify) hipLaunchKernelGGL(k_scale_by_ratio, dim3(nblocks(total, 256)), dim3(256), 0, s, mel_out, T, total, sums);
   VFX_HIP(hipGetLastError());
 }
@@ -397,6 +409,71 @@ __global__ void k_trim_scale(const float* __restrict__ x, int64_t Llong, int L, 
   if (n == 0 && p > 1.0f && flags) or_flag_global(flags, VFX_FLAG_PEAK_NORMALISED);
   const float v = x[(int64_t)b * Llong + off + n];
   out[(int64_t)b * L + n] = p > 1.0f ? v / p : v;
+}
+
+// The same for a batch of clips of unequal length: clip b was restored from lens_l[b] samples through lens_tp[b] vocoder frames,
+// so its vocoder output has lens_tp[b] * hop samples and trim_center takes its own centre; the rest of its row of L is zero.
+__global__ void k_trim_scale_varlen(const float* __restrict__ x, int64_t Llong, int L, int hop, const int* __restrict__ lens_l,
+                                    const int* __restrict__ lens_tp, const unsigned* __restrict__ peak,
+                                    float* __restrict__ out, int* __restrict__ flags) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= L) return;
+  const float p = __uint_as_float(peak[b]);
+  if (n == 0 && p > 1.0f && flags) or_flag_global(flags, VFX_FLAG_PEAK_NORMALISED);
+  const int Lb = lens_l[b];
+  const int off = (int)(((int64_t)lens_tp[b] * hop - Lb) / 2);
+  float v = 0.f;
+  if (n < Lb) {
+    v = x[(int64_t)b * Llong + off + n];
+    v = p > 1.0f ? v / p : v;
+  }
+  out[(int64_t)b * L + n] = v;
+}
+
+// The per-clip lengths of a varlen call travel as KERNEL ARGUMENTS (64 clips per launch): in stream order behind the previous
+// call's kernels, no host synchronisation, no pageable-memory copy (and legal inside a stream capture).
+struct LensChunk {
+  int v[3][64];
+};
+__global__ void k_set_lens(int* __restrict__ d_lens, int cap, int first, int n, LensChunk c) {
+  const int i = threadIdx.x;
+  if (i < n)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d_lens[r * cap + first + i] = c.v[r][i];
+}
+void launch_set_lens(int* d_lens, int cap, const int* host /*[3][B]*/, int B, hipStream_t s) {
+  for (int first = 0; first < B; first += 64) {
+    LensChunk c{};
+    const int n = std::min(64, B - first);
+    for (int r = 0; r < 3; ++r)
+      for (int i = 0; i < n; ++i) c.v[r][i] = host[(size_t)r * B + first + i];
+    hipLaunchKernelGGL(k_set_lens, dim3(1), dim3(64), 0, s, d_lens, cap, first, n, c);
+  }
+  VFX_HIP(hipGetLastError());
+}
+
+// rows (b, t < lens_t[b]) of src (B, T, F) -> dst; the other rows of dst are zero (the log-mel estimate of a varlen batch)
+__global__ void k_copy_rows_masked(const float* __restrict__ src, float* __restrict__ dst, int T, int F, int64_t total,
+                                   const int* __restrict__ lens_t) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t r = idx / F;
+  const int64_t b = r / T;
+  const int t = (int)(r - b * T);
+  dst[idx] = t < lens_t[b] ? src[idx] : 0.f;
+}
+void launch_copy_rows_masked(const float* src, float* dst, int B, int T, int F, const int* lens_t, hipStream_t s) {
+  const int64_t total = (int64_t)B * T * F;
+  hipLaunchKernelGGL(k_copy_rows_masked, dim3(nblocks(total, 256)), dim3(256), 0, s, src, dst, T, F, total, lens_t);
+  VFX_HIP(hipGetLastError());
+}
+
+void launch_peak_trim_varlen(const float* wav_long, int B, int64_t Llong, int L, int hop, const int* lens_l, const int* lens_tp,
+                             const float* peak, float* out, hipStream_t s, int* flags) {
+  hipLaunchKernelGGL(k_trim_scale_varlen, dim3((L + 255) / 256, B), dim3(256), 0, s, wav_long, Llong, L, hop, lens_l, lens_tp,
+                     reinterpret_cast<const unsigned*>(peak), out, flags);
+  VFX_HIP(hipGetLastError());
 }
 
 __global__ void k_or_flags(int* flags, int bits) { or_flag_global(flags, bits); }  // (no FLAT atomics anywhere: conv_common.h)

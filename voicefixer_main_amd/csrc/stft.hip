@@ -194,7 +194,8 @@ __global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_stft_mel(const float* __
                                                                  const int* __restrict__ fb_off, float* __restrict__ mel,
                                                                  float* __restrict__ sp, float* __restrict__ cosp,
                                                                  float* __restrict__ sinp, int log10_mel, int hop, float eps,
-                                                                 int F, int groups, int total_groups, int fb_lds) {
+                                                                 int F, int groups, int total_groups, int fb_lds,
+                                                                 const int* __restrict__ lens) {
   __shared__ float2 twl[NC];
   __shared__ float2 wl[NC];  // the window, as pairs (w[2n], w[2n+1])
   __shared__ float fbl[kMelNnzMax];  // the non-zeros of the mel filterbank (band-major): the band sums read them once per frame
@@ -212,8 +213,32 @@ __global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_stft_mel(const float* __
   const int gw = blockIdx.x * STFT_WAVES + wave;  // this wave's group of F consecutive frames of one clip
   if (gw >= total_groups) return;
   const int b = gw / groups, g = gw - b * groups;
-  const int t_begin = g * F, t_end = min(T, t_begin + F);
-  const float* x = wav + (int64_t)b * L;
+  // `lens` (batches of clips of unequal length, vfx_restore_gsr_varlen): clip b holds lens[b] <= L samples in its row of L --
+  // its frames, and the reflection at its end, are those of a clip of that length; the rows of the outputs past its
+  // last frame are written as zeros (finite input for whatever reads the padded batch)
+  const int Lrow = L;
+  int Tc = T;  // frames of this clip (T stays the row stride of the outputs)
+  if (lens) {
+    L = lens[__builtin_amdgcn_readfirstlane(b)];
+    Tc = min(T, L / hop + 1);
+    const int t0 = g * F, t1 = min(T, t0 + F);
+    for (int t = max(t0, Tc); t < t1; ++t) {
+      const int64_t row = (int64_t)b * T + t;
+      if (mel) {
+        mel[row * NMEL + lane] = log10_mel ? -8.f : 0.f;
+        mel[row * NMEL + 64 + lane] = log10_mel ? -8.f : 0.f;
+      }
+      if constexpr (SPEC)
+        for (int k = lane; k < NBINS; k += 64) {
+          if (sp) sp[row * NBINS + k] = 0.f;
+          if (cosp) cosp[row * NBINS + k] = 0.f;
+          if (sinp) sinp[row * NBINS + k] = 0.f;
+        }
+    }
+    if (t0 >= Tc) return;
+  }
+  const int t_begin = g * F, t_end = min(Tc, t_begin + F);
+  const float* x = wav + (int64_t)b * Lrow;
   float2* zw = zbuf[wave];
   float* ms = reinterpret_cast<float*>(zw);  // the magnitudes of the frame, over the FFT buffer once it is consumed
 
@@ -445,7 +470,7 @@ static int frames_per_group(int64_t frames) {
 }
 
 void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, int T, float* mel, float* sp,
-                     float* cosp, float* sinp, int log10_mel, int hop, float eps, hipStream_t stream) {
+                     float* cosp, float* sinp, int log10_mel, int hop, float eps, hipStream_t stream, const int* lens) {
   const int F = frames_per_group((int64_t)B * T);
   const int groups = (T + F - 1) / F;
   const int total = B * groups;
@@ -453,7 +478,7 @@ void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, in
   hipLaunchKernelGGL(kernel, dim3((total + STFT_WAVES - 1) / STFT_WAVES), dim3(STFT_WAVES * 64), 0, stream, wav, L, T, t.window,
                      reinterpret_cast<const float2*>(t.twiddle), reinterpret_cast<const float2*>(t.rtwiddle),
                      t.fb_val, t.fb_start, t.fb_off, mel, sp, cosp, sinp, log10_mel, hop, eps, F, groups, total,
-                     t.fb_nnz <= kMelNnzMax ? 1 : 0);
+                     t.fb_nnz <= kMelNnzMax ? 1 : 0, lens);
   VFX_HIP(hipGetLastError());
 }
 

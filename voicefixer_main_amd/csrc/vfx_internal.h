@@ -73,6 +73,7 @@ constexpr int kMaxSegs = 3;
 constexpr int kKC = 32;             // input channels per K step
 constexpr int kIdentityLen = 4096;  // length of the identity scale/shift tables
 constexpr int kPatchMaxRows = 192;
+constexpr int kMaxVarlenClips = 1024;  // clips per launch of a varlen batch (vfx_handle::d_lens)
 constexpr size_t kMaxCachedPlans = 8;  // per handle: a plan owns host + device parameter blocks (the eval handler's last
                                         // segment has a new length for every file)  // patch pixels per stage (6 row groups of 32)
 
@@ -185,6 +186,12 @@ struct TapConvParams {
   int short_clip;
   float* ws;
   int tuning;            // vfx_config.tuning of the handle (choose_ksplit)
+  // Batches of clips of unequal length (vfx_restore_gsr_varlen; 1-D launches of the vocoder): lens[b] = length of clip b in
+  // vocoder frames (T_b + T_b % 2 + 4), a device array owned by the handle and refilled by every call; the clip's input /
+  // output sequence ends at lens[b] * lens_mul_in / lens_mul_out positions (the launch's own units: a phased upsampler
+  // addresses its output in INPUT positions).  NULL = every clip has the full length (all other launches).  No split-K with it.
+  const int* lens;
+  int lens_mul_in, lens_mul_out;
 };
 
 // One fused TFGAN ResStack layer (resblock.hip): y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2.
@@ -258,6 +265,10 @@ struct ResBlockParams {
   unsigned long long inv_tiles_w, inv_tiles_per_img;
   int patch_rows;    // set by plan_resblock: rows of a patch buffer when they are not tile_m + 64 (resblock_w64.hip: 160)
   int tuning;        // vfx_config.tuning of the handle: which kernel family runs the layer (plan_resblock)
+  // Batches of clips of unequal length (cf. TapConvParams::lens): clip b's sequence ends at lens[b] * lens_mul positions; T stays
+  // the stride between clips.  NULL = T for every clip.  1-D layers only.
+  const int* lens;
+  int lens_mul;
   // Timing builds only (-DVFX_TIMING, scripts/phase_timing.py): [tile][wave][16] s_memtime stamps of the 4-wave kernels' phases
   unsigned long long* timing;
 };
@@ -311,13 +322,16 @@ struct FrontEndTables {
   float* voc_inv_weight = nullptr;  // [128] 1 / mel band weight
 };
 
+// lens != nullptr (device, [B]): clip b holds lens[b] <= L samples in its row of L (batches of clips of unequal length)
 void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, int T, float* mel, float* sp,
-                     float* cosp, float* sinp, int log10_mel, int hop, float eps, hipStream_t stream);
+                     float* cosp, float* sinp, int log10_mel, int hop, float eps, hipStream_t stream,
+                     const int* lens = nullptr);
 void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, float* mel, hipStream_t stream);
 void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop, float* wav,
                   hipStream_t stream);
 
-void launch_prep_logmel(const float* mel_linear, int B, int T, int Tpad, float* x, int* flags, hipStream_t s);
+void launch_prep_logmel(const float* mel_linear, int B, int T, int Tpad, float* x, int* flags, hipStream_t s,
+                        const int* lens_t = nullptr);  // lens_t: frames per clip of a varlen batch (device, [B])
 void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s);
 void launch_conv_c1(const float* x, int B, int H, int W, const float* w9x32, float scale, float shift, float slope,
                     const float* wsc32, const float* bsc32, float* h, float* sc, hipStream_t s);
@@ -325,11 +339,17 @@ void launch_avgpool2(const float* x, int B, int H, int W, int C, float* y, hipSt
 void launch_final_1x1(const float* y, int B, int Tpad, int W, const float* w32, float bias, int mode, int T,
                       const float* aux0, const float* aux1, float* out0, float* out1, hipStream_t s);
 void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_weight, float amp_floor, float min_db,
-                     float range, float* cond, hipStream_t s);
+                     float range, float* cond, hipStream_t s, const int* lens_t = nullptr);
+// x_f16: x is an fp16 tensor (the fp16 trunk of the 16-bit mode); lens: vocoder frames per clip of a varlen batch, hop samples each
 void launch_voc_final(const float* x, int x_f16, int B, int T, int C, const float* w, float bias, float slope, float* wav,
-                      unsigned* peak, hipStream_t s);  // x_f16: x is an fp16 tensor (the fp16 trunk of the 16-bit mode)
+                      unsigned* peak, hipStream_t s, const int* lens = nullptr, int hop = 1);
+// d_lens[r * cap + b] = host[r * B + b], r < 3 (samples, frames, vocoder frames per clip): as kernel arguments, in stream order
+void launch_set_lens(int* d_lens, int cap, const int* host, int B, hipStream_t s);
+void launch_copy_rows_masked(const float* src, float* dst, int B, int T, int F, const int* lens_t, hipStream_t s);
+void launch_peak_trim_varlen(const float* wav_long, int B, int64_t Llong, int L, int hop, const int* lens_l, const int* lens_tp,
+                             const float* peak, float* out, hipStream_t s, int* flags);
 void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int unify, float* sums, float* mel_out,
-                     hipStream_t s);
+                     hipStream_t s, const int* lens_t = nullptr);
 void launch_peak_trim(const float* wav_long, int B, int64_t Llong, int L, float* ws, bool have_peak, float* out,
                       hipStream_t s, int* flags = nullptr);  // flags: VFX_FLAG_PEAK_NORMALISED when a clip was divided by its peak
 void launch_spectral_metrics(const float* est, const float* tgt, int B, int T, int F, double* ws, float* out, hipStream_t s);
@@ -415,6 +435,10 @@ struct PlanBuilder {
   Plan* plan;
   ArenaPlanner arena;
   int short_clip = 0;  // copied into every TapConvParams added from here on (TapConvParams::short_clip)
+  // Batches of clips of unequal length (vfx_restore_gsr_varlen): device arrays [B] of the handle, refilled by every call --
+  // frames per clip (T_b = L_b / hop + 1) and vocoder frames per clip (T_b + T_b % 2 + 4).  NULL: every clip has the plan's T.
+  const int* lens_t = nullptr;
+  const int* lens_tp = nullptr;
   // returns arena offset in BYTES
   size_t alloc_f(int64_t nfloat) { return arena.alloc((size_t)nfloat * sizeof(float)); }
   void free(size_t off) { arena.free(off); }
@@ -503,6 +527,7 @@ struct vfx_handle {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   int* d_flags = nullptr;
+  int* d_lens = nullptr;     // [3][kMaxVarlenClips]: samples / frames / vocoder frames per clip of the varlen call in flight
   float* d_ones = nullptr;   // identity prologue tables (kIdentityLen floats)
   float* d_zeros = nullptr;
   vfx::ConvProfile prof;

@@ -168,6 +168,12 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
   Plan* pl = pb.plan;
   vfx_handle* hh = pb.h;
   const int Tp = T + T % 2 + 4;
+  // A varlen batch (PlanBuilder::lens_t / lens_tp): clip b has lens_t[b] <= T frames, i.e. lens_tp[b] <= Tp vocoder frames (its
+  // OWN tail of -R frames included).  Every launch below carries lens_tp and the number of positions per vocoder frame at its
+  // rate: a clip's sequence ends there (zero padding / reflection / nothing stored), as in its batch-of-one call.
+  const int* lens_t = pb.lens_t;
+  const int* lens_tp = pb.lens_tp;
+  int rate = 1;  // positions per vocoder frame of the current stage
   pb.short_clip = 0;  // (the ResUNets' split-K rule for short clips does not apply to the vocoder's launches)
 
   auto resolve = [pl](const RunCtx& c, const BufRef& b) -> float* {
@@ -179,7 +185,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     const size_t xo = x;
     pl->ops.push_back([=](const RunCtx& c) {
       launch_voc_prep(resolve(c, mel_linear), B, T, Tp, hh->fe.voc_inv_weight, cfg.voc_amp_floor, cfg.voc_min_db,
-                      cfg.voc_norm_range, reinterpret_cast<float*>(pl->bound_base + xo), c.stream);
+                      cfg.voc_norm_range, reinterpret_cast<float*>(pl->bound_base + xo), c.stream, lens_t);
       // 16-bit mode on weights that do not fit fp16 operands: every call says so (never silently wrong)
       if (hh->voc && hh->voc->needs_strict) launch_or_flags(c.flags, VFX_FLAG_F16_SATURATED, c.stream);
     });
@@ -228,6 +234,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
       p.act_slope = next_slope;
       p.act_elu = next_act == ACT_ELU;
     }
+    p.lens = lens_tp;
+    p.lens_mul_in = p.lens_mul_out = rate;
     p.nseg = 1;
     TapSeg& S = p.seg[0];
     S.src = rel_ptr(src);
@@ -290,6 +298,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
       p.sh = p.sw = 1;
       p.bias = up.bias;
       p.act_slope = 1.f;
+      p.lens = lens_tp;  // (the phased launch addresses its output in INPUT positions: (B, Tlen, s * cout))
+      p.lens_mul_in = p.lens_mul_out = rate;
       if (t16 && fuse) {
         p.out_act = const_cast<float*>(rel_ptr(y.raw));  // fp16(y): LeakyReLU with slope 1
       } else {
@@ -332,6 +342,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     free_forms(cur);
     cur = y;
     Tlen = Tout;
+    rate *= s;
     int dil = 1;
     const size_t nlayers = W->res[st].size();
     for (size_t li = 0; li < nlayers; ++li) {
@@ -351,6 +362,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.dil = dil;
         rp.hionly = cfg.precision == 2;
         rp.tuning = cfg.tuning;
+        rp.lens = lens_tp;
+        rp.lens_mul = rate;
         VFX_CHECK(layer.first.mode == layer.second.mode &&
                       layer.first.mode == fused_layer_mode(cfg, up.cout),
                   "vocoder plan: the weights of a fused %d-channel layer are packed for another kernel", up.cout);
@@ -395,6 +408,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.asrc = 1;
         rp.x16 = t16 ? 1 : 0;  // the activated tensor is the only form of the trunk: no x, no y
         rp.tuning = cfg.tuning;
+        rp.lens = lens_tp;
+        rp.lens_mul = rate;
         rp.x = t16 ? nullptr : rel_ptr(cur.raw);
         rp.xa = rel_ptr(cur.act);
         rp.y = t16 ? nullptr : const_cast<float*>(rel_ptr(y2.raw));
@@ -444,7 +459,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     pl->ops.push_back([=](const RunCtx& c) {
       launch_voc_final(reinterpret_cast<const float*>(pl->bound_base + xo), tail_f16, B, Tl, W->final_c, W->final_w, W->final_b,
                        cfg.voc_up_slope, resolve(c, wav_out), want_peak ? reinterpret_cast<unsigned*>(resolve(c, pk)) : nullptr,
-                       c.stream);
+                       c.stream, lens_tp, rate);
     });
   }
   free_forms(cur);

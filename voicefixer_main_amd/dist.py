@@ -111,10 +111,17 @@ def broadcast_state_dict(sd, device, src=0):
 
 
 def checked_restore(engine, **kw):
-    """engine_fn for restore_sharded / sharded_step that keeps the 16-bit mode's guarantee on every rank: a batch whose
-    vocoder activations left the fp16 range (VFX_FLAG_F16_SATURATED) is re-run on the split-bf16 twin, a negative
-    mel (to_log's assert) raises (Engine.restore_gsr_checked; one device sync per call)."""
-    return lambda x: engine.restore_gsr_checked(x, **kw)
+    """engine_fn for restore_sharded / sharded_step / restore_sharded_lengths that keeps the 16-bit mode's guarantee on every
+    rank: a batch whose vocoder activations left the fp16 range (VFX_FLAG_F16_SATURATED) is re-run on the split-bf16 twin, a
+    negative mel (to_log's assert) raises (Engine.restore_gsr_checked; one device sync per call).  Called with `lengths` it
+    restores a padded batch of clips of unequal length (Engine.restore_gsr_varlen_checked); `fn.bucket_key(L)` tells
+    restore_sharded_lengths which clips may share such a call (the ResUNet's padded frame count)."""
+    def fn(x, lengths=None):
+        if lengths is None or len(set(int(v) for v in lengths)) == 1 and int(lengths[0]) == x.shape[-1]:
+            return engine.restore_gsr_checked(x, **kw)
+        return engine.restore_gsr_varlen_checked(x, lengths, **kw)
+    fn.bucket_key = engine.padded_frames
+    return fn
 
 
 def restore_sharded(engine_fn, full, n, length, device, src=0):
@@ -146,8 +153,9 @@ def sharded_step(engine_fn, full, n, length, device, src=0, sync=None):
 
 def deal_by_length(lengths, world):
     """"clip list sorted by length, dealt round-robin".  -> owner[i] = rank that restores clip i.
-    Longest first, so the ranks' total audio differs by at most one clip of the shortest kind; ties keep the file order (the
-    deal is a pure function of the lengths: every rank computes the same one)."""
+    Longest first: rank r never holds less audio than rank r + 1, and two ranks differ by at most the LONGEST clip (each
+    round of the deal hands rank 0 a clip at least as long as everybody else's); ties keep the file order (the deal is a pure
+    function of the lengths: every rank computes the same one)."""
     order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
     owner = [0] * len(lengths)
     for pos, i in enumerate(order):
@@ -163,12 +171,14 @@ def restore_sharded_lengths(engine_fn, clips, device, src=0, max_batch=37, dtype
     * dealt by length (deal_by_length): the per-rank work is balanced without knowing the speed of anything;
     * every rank receives its clips as ONE flat buffer (one message per peer and direction, all of rank `src`'s links driven
       concurrently by the grouped isend / irecv) -- the lengths travel first, as one small object;
-    * within a rank, clips of EQUAL length run as one batch (engine_fn: (B, L) -> (B, L); at most `max_batch` clips per call:
-      the kernels address a tensor with 32-bit byte offsets, 37 clips of 10 s).  Equal length, not equal padded frame count:
-      padding a clip to a neighbour's length would replace the reflection at its end (fDomainHelper.py:26-28, center / reflect)
-      and the ResUNet's own zero padding of the frame axis (unet.py:75-77) by other samples, i.e. change its last frames --
-      batched this way every clip's result is the one a batch-of-one call gives (the kernels' results do not depend on the
-      batch a clip is in, tests/test_gpu_models.py);
+    * within a rank, clips that share `engine_fn.bucket_key(length)` run as one PADDED batch with their lengths
+      (engine_fn(x (B, Lmax), lengths) -> (B, Lmax); `checked_restore`: the key is the ResUNet's padded frame count, the call
+      vfx_restore_gsr_varlen, round 5) -- every clip's result is still the one its own batch-of-one call gives: the reflection
+      at ITS end (fDomainHelper.py:26-28), the ResUNet's zero padding behind ITS last frame (unet.py:75-77), the vocoder stopped
+      at ITS length (tests/test_gpu_surface.py).  An engine_fn without `bucket_key` gets clips of EQUAL length only
+      ((B, L) -> (B, L), rounds 1-4).  At most `max_batch` clips per call;
+    * an exception on one rank (to_log's assert, a twin that cannot be created) is raised on EVERY rank after the restore phase
+      instead of leaving the others waiting in the gather;
     * a world of one is the length-bucketing helper for a single GPU (no process group needed)."""
     world, rank = world_rank()
     meta = [None]
@@ -200,22 +210,40 @@ def restore_sharded_lengths(engine_fn, clips, device, src=0, max_batch=37, dtype
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-    # ---- restore: equal lengths as one batch
+    # ---- restore: one padded batch per bucket (equal lengths when the engine function cannot take a length vector)
     pieces, off = {}, 0
     for i in mine:
         pieces[i] = flat[off:off + lengths[i]]
         off += lengths[i]
-    by_len = {}
+    key_of = getattr(engine_fn, "bucket_key", None)
+    buckets = {}
     for i in mine:
-        by_len.setdefault(lengths[i], []).append(i)
-    done = {}
-    for L in sorted(by_len, reverse=True):
-        idx = by_len[L]
-        for a in range(0, len(idx), max_batch):
-            chunk = idx[a:a + max_batch]
-            out = engine_fn(torch.stack([pieces[i] for i in chunk]))
-            for j, i in enumerate(chunk):
-                done[i] = out[j]
+        buckets.setdefault(key_of(lengths[i]) if key_of else lengths[i], []).append(i)
+    done, failure = {}, None
+    try:
+        for k in sorted(buckets, reverse=True):
+            idx = sorted(buckets[k], key=lambda i: (-lengths[i], i))
+            for a in range(0, len(idx), max_batch):
+                chunk = idx[a:a + max_batch]
+                lens = [lengths[i] for i in chunk]
+                if min(lens) == max(lens):
+                    out = engine_fn(torch.stack([pieces[i] for i in chunk]))
+                else:
+                    x = torch.zeros((len(chunk), max(lens)), device=device, dtype=dtype)
+                    for j, i in enumerate(chunk):
+                        x[j, :lengths[i]] = pieces[i]
+                    out = engine_fn(x, lens)
+                for j, i in enumerate(chunk):
+                    done[i] = out[j, :lengths[i]]
+    except Exception as e:       # raised below, on every rank: nobody may be left waiting in the gather
+        failure = e
+    if world > 1:
+        bad = torch.tensor([1 if failure is not None else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) and failure is None:
+            raise RuntimeError("restore_sharded_lengths: the restore failed on another rank")
+    if failure is not None:
+        raise failure
     back = torch.cat([done[i].reshape(-1) for i in mine]) if mine else torch.empty(0, device=device, dtype=dtype)
     # ---- gather
     if rank == src:

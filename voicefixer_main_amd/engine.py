@@ -261,6 +261,28 @@ class Engine:
                                             self._stream()), "vfx_restore_gsr")
         return (out, logmel) if want_logmel else out
 
+    def padded_frames(self, L):
+        """The ResUNet's padded frame count of a clip of L samples (unet.py:75-77): 64 * ceil(T / 64) -- the bucket key of
+        restore_gsr_varlen."""
+        return -(-self.frames(L) // 64) * 64
+
+    def restore_gsr_varlen(self, wav, lengths, unify_energy=False, want_logmel=False, out=None):
+        """The handler() segment body for a batch of clips of UNEQUAL length: wav (B, Lmax), clip b = wav[b, :lengths[b]]
+        -> restored (B, Lmax), zero past a clip's end.  Every clip gets what its own restore_gsr(wav[b:b+1, :lengths[b]])
+        computes (vfx_restore_gsr_varlen); the clips of one call must share `padded_frames(length)`."""
+        wav = _dev_f32(wav, self.device)
+        B, L = wav.shape
+        lengths = [int(v) for v in lengths]
+        if len(lengths) != B:
+            raise ValueError("restore_gsr_varlen: %d lengths for %d clips" % (len(lengths), B))
+        arr = (ctypes.c_int * B)(*lengths)
+        if out is None:
+            out = torch.empty_like(wav)
+        logmel = torch.empty((B, self.frames(L), N_MELS), device=self.device, dtype=torch.float32) if want_logmel else None
+        _lib.check(self.lib.vfx_restore_gsr_varlen(self.h, _ptr(wav), B, L, arr, _ptr(out), _ptr(logmel),
+                                                   int(bool(unify_energy)), self._stream()), "vfx_restore_gsr_varlen")
+        return (out, logmel) if want_logmel else out
+
     def check_negative_input(self):
         """`to_log`'s assert alone (pytorch_util.py:158): reads and clears ONLY the negative-input bit -- a saturation bit a
         deferred vocoder check still has to see stays raised."""
@@ -293,6 +315,12 @@ class Engine:
         """restore_gsr + check_flags: never silently wrong in the 16-bit mode, whoever the caller is (models, dist, bench)."""
         res = self.restore_gsr(wav, unify_energy=unify_energy, out=out)
         again = self.check_flags(lambda e: e.restore_gsr(wav, unify_energy=unify_energy, out=out))
+        return res if again is None else again
+
+    def restore_gsr_varlen_checked(self, wav, lengths, unify_energy=False, out=None):
+        """restore_gsr_varlen + check_flags (cf. restore_gsr_checked)."""
+        res = self.restore_gsr_varlen(wav, lengths, unify_energy=unify_energy, out=out)
+        again = self.check_flags(lambda e: e.restore_gsr_varlen(wav, lengths, unify_energy=unify_energy, out=out))
         return res if again is None else again
 
     def vocoder_checked(self, mel_linear):

@@ -379,9 +379,10 @@ class VoiceFixer(_Base):
 
     def restore_list(self, wavs, unify_energy=False, max_batch=37):
         """A test set of clips of ARBITRARY lengths (what the reference's harness iterates, one handler call per file:
-        evaluation_proc/eval.py:119-134): list of 1-D tensors -> list of restored 1-D tensors in the same order.  Clips of equal
-        length share a batched call (every clip's result is the one its own batch-of-one call gives), lengths are visited
-        longest first; with torch.distributed initialised the list is dealt over the ranks by length and gathered on rank 0
+        evaluation_proc/eval.py:119-134): list of 1-D tensors -> list of restored 1-D tensors in the same order.  Clips whose
+        frame counts pad to the same multiple of 64 share ONE call of the library as a padded batch with their lengths
+        (vfx_restore_gsr_varlen: every clip's result is the one its own batch-of-one call gives), buckets are visited longest
+        first; with torch.distributed initialised the list is dealt over the ranks by length and gathered on rank 0
         (dist.restore_sharded_lengths).  The 16-bit mode's re-run guarantee holds per batch."""
         from . import dist as vdist
         fn = vdist.checked_restore(self.engine, unify_energy=unify_energy)
