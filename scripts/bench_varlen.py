@@ -62,6 +62,20 @@ def main():
     dt1, one = timed(lambda: [m.restore(c[None])[0] for c in clips])
     res["per_clip_s"], res["per_clip_audio_s_per_s"] = round(dt1, 4), round(total / dt1, 1)
     res["varlen_equals_per_clip"] = bool(all(torch.equal(a, b) for a, b in zip(got, one)))
+    if not res["varlen_equals_per_clip"]:      # diagnostics: which clips, where, how much; is either path repeatable?
+        again_v, again_1 = m.restore_list(clips), [m.restore(c[None])[0] for c in clips]
+        res["varlen_repeatable"] = bool(all(torch.equal(a, b) for a, b in zip(got, again_v)))
+        res["per_clip_repeatable"] = bool(all(torch.equal(a, b) for a, b in zip(one, again_1)))
+        bad = []
+        for i, (a, b) in enumerate(zip(got, one)):
+            if not torch.equal(a, b):
+                d = (a - b).abs()
+                nz = torch.nonzero(d > 0)
+                bad.append({"clip": i, "samples": lens[i], "frames": lens[i] // 441 + 1, "padded": eng.padded_frames(lens[i]),
+                            "max_abs_diff": float(d.max()), "first_diff_at": int(nz[0]), "last_diff_at": int(nz[-1]),
+                            "n_diff": int(nz.shape[0]), "peak": float(b.abs().max())})
+        res["mismatches"] = bad[:12]
+        res["n_mismatch"] = len(bad)
     L_eq = int(round(total / 16 * 44100))
     eq = torch.from_numpy(synth.make_clips(16, L_eq / 44100.0, seed=78)[:, 0, :L_eq].copy()).to(dev)
     dt2, _ = timed(lambda: m.restore(eq))

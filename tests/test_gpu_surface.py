@@ -145,7 +145,8 @@ def _varlen_batch(lens, seed=70):
 def test_restore_varlen_equals_one_call_per_clip_and_the_oracle(engine, unet_sd, voc_sd, unify):
     """vfx_restore_gsr_varlen: five clips of five lengths as ONE padded batch give, clip by clip, what a batch-of-one
     vfx_restore_gsr of that clip gives -- bit for bit: the tile a position falls into differs, the sums that make its value do
-    not -- and what the oracle computes for the clip on its own; past a clip's end both outputs are zero."""
+    not (with unify_energy: to the last bits of a float atomicAdd sum) -- and what the oracle computes for the clip on its own;
+    past a clip's end both outputs are zero."""
     from oracle import pipeline
     clips, x = _varlen_batch(VARLEN)
     out, logmel = engine.restore_gsr_varlen(x, VARLEN, unify_energy=unify, want_logmel=True)
@@ -154,7 +155,12 @@ def test_restore_varlen_equals_one_call_per_clip_and_the_oracle(engine, unet_sd,
     for j, (c, L) in enumerate(zip(clips, VARLEN)):
         one, lm1 = engine.restore_gsr(c[None], unify_energy=unify, want_logmel=True)
         T = L // 441 + 1
-        assert torch.equal(out[j, :L], one[0]), (j, float((out[j, :L] - one[0]).abs().max()))
+        if unify:    # the energies of amp_to_original_f are float atomicAdd sums: their order, hence the last bits of the scale,
+            #          differ from launch to launch -- also between two identical calls of either entry point
+            #          (the 16-bit vocoder turns a last-bit change of its input into fp16 rounding steps: its own waveform bar)
+            assert float((out[j, :L] - one[0]).abs().max()) < max(2e-5, tol["voc_max"]), j
+        else:
+            assert torch.equal(out[j, :L], one[0]), (j, float((out[j, :L] - one[0]).abs().max()))
         assert torch.equal(logmel[j, :T], lm1[0]), j
         assert float(out[j, L:].abs().max()) == 0.0 if L < x.shape[1] else True
         assert float(logmel[j, T:].abs().max()) == 0.0 if T < logmel.shape[1] else True
@@ -166,6 +172,21 @@ def test_restore_varlen_equals_one_call_per_clip_and_the_oracle(engine, unet_sd,
         err = out[j, :L].cpu().numpy().astype(np.float64) - ref["wav"][0, 0]
         sisdr = 10 * np.log10((ref["wav"].astype(np.float64) ** 2).sum() / ((err ** 2).sum() + 1e-30))
         assert sisdr > tol["sisdr"], (j, sisdr)
+
+
+def test_restore_two_lengths_with_one_frame_count(engine, unet_sd, voc_sd):
+    """Two clips whose lengths differ but whose frame counts agree (L // 441 + 1 = 30), one after the other on ONE handle: each
+    is restored with its OWN length (rounds 1-4 cached the fused plan by frame count: the second call ran with the first
+    one's sample count -- wrong reflection point, wrong trim)."""
+    from oracle import pipeline
+    from voicefixer_main_amd import synth
+    for L in (13000, 12800, 13100):
+        wav = synth.make_clips(1, L / 44100.0 + 0.01, seed=31)[..., :L]
+        ref = pipeline.restore_gsr(unet_sd, voc_sd, wav)["wav"][:, 0]
+        out = engine.restore_gsr(torch.from_numpy(wav[:, 0])).cpu().numpy().astype(np.float64)
+        err = out - ref
+        sisdr = 10 * np.log10((ref.astype(np.float64) ** 2).sum() / ((err ** 2).sum() + 1e-30))
+        assert sisdr > engine.tol["sisdr"], (L, sisdr)
 
 
 def test_restore_varlen_sub_batches_and_errors(engine, monkeypatch):

@@ -504,7 +504,7 @@ void PlanBuilder::add_conv(TapConvParams p) {
   p.tuning = h->cfg.tuning;
   p.short_clip = short_clip;
   finish_params(p);
-  p.ksplit = p.lens ? 1 : choose_ksplit(p);  // (a launch with per-clip lengths skips the tiles past a clip's end: no partial sums)
+  p.ksplit = (p.lens || no_splitk) ? 1 : choose_ksplit(p);  // (a launch with per-clip lengths skips the tiles past a clip's end)
   size_t ws_off = ~size_t(0);
   if (p.ksplit > 1) {  // the partial tiles live in the arena for the duration of this op
     ws_off = alloc_f((int64_t)p.ksplit * p.B * p.out_img_stride * p.Cout);
@@ -1230,7 +1230,10 @@ static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, floa
   const int T = frames_of(h, L);
   const int64_t Llong = vocoder_out_len(h->cfg, T);
   const int unify = flags & 1;
-  auto plan = get_plan(h, key_of("restore_gsr", B, T, unify), [&](PlanBuilder& pb) {
+  // keyed on L, not on T: the plan's launches hold the sample count (STFT row stride and reflection point, trim_center) -- two
+  // clips with the same frame count and different lengths must not share it (rounds 1-4 keyed on T: the second of two such
+  // clips on one handle was framed and trimmed with the first one's length; found by the varlen comparison of round 5)
+  auto plan = get_plan(h, key_of("restore_gsr", B, L, unify), [&](PlanBuilder& pb) {
     const int64_t nmel = (int64_t)B * T * 128;
     const size_t o_mel = pb.alloc_f(nmel), o_log = pb.alloc_f(nmel), o_den = pb.alloc_f(nmel);
     const size_t o_long = pb.alloc_f((int64_t)B * Llong), o_ws = pb.alloc_f(2 * B + 64), o_pk = pb.alloc_f(B + 64);
@@ -1313,7 +1316,7 @@ static int vfx_restore_gsr_varlen_1(vfx_handle* h, const float* wav, int B, int 
   launch_set_lens(h->d_lens, kMaxVarlenClips, host.data(), B, s);
   const int64_t Llong = vocoder_out_len(h->cfg, T);
   const int unify = flags & 1;
-  auto plan = get_plan(h, key_of("restore_gsr_vl", B, T, unify), [&](PlanBuilder& pb) {
+  auto plan = get_plan(h, key_of("restore_gsr_vl", B, Lmax, unify), [&](PlanBuilder& pb) {  // (Lmax: the row stride, cf. vfx_restore_gsr)
     const int64_t nmel = (int64_t)B * T * 128;
     const size_t o_mel = pb.alloc_f(nmel), o_log = pb.alloc_f(nmel), o_den = pb.alloc_f(nmel);
     const size_t o_long = pb.alloc_f((int64_t)B * Llong), o_ws = pb.alloc_f(2 * B + 64), o_pk = pb.alloc_f(B + 64);

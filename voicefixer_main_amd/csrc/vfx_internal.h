@@ -439,6 +439,10 @@ struct PlanBuilder {
   // frames per clip (T_b = L_b / hop + 1) and vocoder frames per clip (T_b + T_b % 2 + 4).  NULL: every clip has the plan's T.
   const int* lens_t = nullptr;
   const int* lens_tp = nullptr;
+  // set by build_vocoder: its launches never split K (split-K is the deep ResUNet levels' tool; a vocoder launch of a short clip
+  // would otherwise sum in another order than the same clip inside a varlen batch, whose launches cannot split -- with this
+  // every arithmetic mode gives a clip the same bits in both entry points)
+  bool no_splitk = false;
   // returns arena offset in BYTES
   size_t alloc_f(int64_t nfloat) { return arena.alloc((size_t)nfloat * sizeof(float)); }
   void free(size_t off) { arena.free(off); }

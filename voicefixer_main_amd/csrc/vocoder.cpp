@@ -174,6 +174,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
   const int* lens_t = pb.lens_t;
   const int* lens_tp = pb.lens_tp;
   int rate = 1;  // positions per vocoder frame of the current stage
+  pb.no_splitk = true;  // (PlanBuilder::no_splitk; reset at the end)
   pb.short_clip = 0;  // (the ResUNets' split-K rule for short clips does not apply to the vocoder's launches)
 
   auto resolve = [pl](const RunCtx& c, const BufRef& b) -> float* {
@@ -463,6 +464,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     });
   }
   free_forms(cur);
+  pb.no_splitk = false;
 }
 
 }  // namespace vfx
