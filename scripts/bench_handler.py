@@ -43,6 +43,18 @@ def main():
         dt = time.perf_counter() - t0
         res["handler_%s_s" % tag] = round(dt, 4)
         res["handler_%s_audio_s_per_s" % tag] = round(seconds / dt, 1)
+    if "--profile" in sys.argv:      # where the host's part of the handler goes (cumulative seconds per function, one call)
+        import cProfile
+        import io
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        handlers.handler(src, dst, None, ckpt=None, device=dev, needrefresh=False, meta={"unify_energy": False})
+        torch.cuda.synchronize()
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(18)
+        sys.stderr.write(buf.getvalue())
     # the same three segments through the fused entry point, resident in HBM (no file I/O)
     x = torch.from_numpy(wav).to(dev)
     segs = [x[i * 2646000:(i + 1) * 2646000][None] for i in range(3)]

@@ -286,6 +286,37 @@ back = vdist.restore_sharded_lengths(eng, clips, dev)
 assert calls == ([(1, 9)] if rank == 0 else [])
 if rank == 0:
     assert torch.equal(back[0], clips[0] * 2.0 + 1.0)
+# round 5: an engine function that takes a length vector (checked_restore: fn(x, lengths), fn.bucket_key) gets ONE padded batch
+# per bucket -- 6 clips of 6 lengths, bucket = length // 50: rank 0 holds 120, 101, 45 -> calls (2, 120) + lengths, (1, 45)
+calls.clear()
+def eng_v(x, lengths=None):
+    calls.append((tuple(x.shape), None if lengths is None else tuple(lengths)))
+    y = x * 2.0
+    if lengths is not None:
+        for j, n in enumerate(lengths):
+            assert float(x[j, n:].abs().sum()) == 0.0            # the padding of a padded batch is zeros
+    return y
+eng_v.bucket_key = lambda n: n // 50
+lens = [120, 110, 101, 47, 40, 45]
+clips = [torch.arange(L, dtype=torch.float32) + 1.0 + 1000.0 * i for i, L in enumerate(lens)] if rank == 0 else None
+back = vdist.restore_sharded_lengths(eng_v, clips, dev)
+want_calls = [((2, 120), (120, 101)), ((1, 45), None)] if rank == 0 else [((1, 110), None), ((2, 47), (47, 40))]
+assert calls == want_calls, (rank, calls)
+if rank == 0:
+    assert [int(b.shape[0]) for b in back] == lens and all(torch.equal(b, c * 2.0) for b, c in zip(back, clips))
+# an exception on ONE rank (to_log's assert, a twin that cannot be created) is raised on EVERY rank instead of leaving the
+# others waiting in the gather
+def eng_bad(x, lengths=None):
+    if rank == 1:
+        raise AssertionError("to_log: input has negative values")
+    return x
+try:
+    vdist.restore_sharded_lengths(eng_bad, clips, dev)
+    raise SystemExit("rank %%d: no exception" %% rank)
+except AssertionError as e:
+    assert rank == 1 and "negative" in str(e)
+except RuntimeError as e:
+    assert rank == 0 and "another rank" in str(e)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

@@ -274,6 +274,27 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
 
   // ---- phase 1: conv1 (its last tap fetches the first tap of conv2) -------------------------------------------------------------
   conv(prep1, 0, NT1, true);
+  // X16 (round 5): the residual never comes from memory a second time.  The tile's centre rows of xa are still in the patch
+  // buffers: this wave takes ITS 64 couts x 128 positions (chunk `wave` of the centre tap's rows) in accumulator layout -- lane =
+  // pixel, 4 consecutive channels per 8-byte read, 64 registers of packed fp16 -- before the barrier that hands the buffers over
+  // to h; phase 2 turns them into x = min(xa, xa / slope) as the INITIAL value of conv2's accumulators.  (Rounds 3-4 re-read the
+  // centre rows from L2 in the epilogue: 0.95-1.03 GB read per launch for a 0.40 GB tensor, 12 loads in flight beside the staged
+  // tile, profiles/r04_pmc.txt.)
+  u32x2 rres[2][WM][4];
+  if constexpr (X16) {
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      int r = arow1[a];
+      asm volatile("" : "+v"(r));
+      const int row = r + poff1;
+      const char* rowp = lds + wave_u * PBYTES + row * CROW + 8 * lh;
+      const int key = swz_key(row);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rres[cb][a][j] = *reinterpret_cast<const u32x2*>(rowp + (((cb * 4 + j) << 4) ^ key));
+    }
+  }
   VFX_TS(5);
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
   VFX_TS(6);
@@ -284,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   {
     unsigned sat16 = 0;
     const f16x2 slope2 = {(_Float16)slope, (_Float16)slope};
+    const float inv_slope = 1.f / slope;    // X16: the residual x = min(xa, xa / slope)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       f32x4 b1v[4];
@@ -299,8 +321,14 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
           // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
           const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[cb][a][4 * j] + b1v[j][0], acc[cb][a][4 * j + 1] + b1v[j][1], hval[a], sat16), slope2);
           const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[cb][a][4 * j + 2] + b1v[j][2], acc[cb][a][4 * j + 3] + b1v[j][3], hval[a], sat16), slope2);
+          if constexpr (X16) {  // conv2 accumulates on top of the residual x = min(xa, xa / slope)
+            const f32x4 v = f16x4_widen(rres[cb][a][j]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[cb][a][4 * j + e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[cb][a][4 * j + e] = fminf(v[e], v[e] * inv_slope);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[cb][a][4 * j + e] = 0.f;
+          }
           *reinterpret_cast<uint2*>(rowp + (((cb * 4 + j) ^ key) << 4)) = make_uint2(h01, h23);  // LeakyReLU(0) = 0: masked stays 0
         }
       }
@@ -335,7 +363,6 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(p.ya, 0, p.ya ? (int)(ybytes / 2) : 0, 0x00020000);
   constexpr unsigned kOob = 0xC0000000u;  // beyond every descriptor (the launch checks the tensors are < 2 GiB), + 1 KB does not wrap
   constexpr unsigned EB = X16 ? 2u : 4u;  // bytes per element of the tensors `ooff` addresses
-  const float inv_slope = 1.f / slope;    // X16: the residual x = min(xa, xa / slope)
   unsigned ooff[NSUB][SUB];  // byte offset of the row's first channel in y (fp32; ya: half of it) -- X16: in xa / ya (fp16)
 #pragma unroll
   for (int sp = 0; sp < NSUB; ++sp)
@@ -369,19 +396,15 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
     }
   };
   // the residual of row q of the register set: X16: x = min(xa, xa / slope) of the fp16 operand form (a masked row loads zeros)
+  // (X16: the residual is already inside the accumulators -- see phase 2 -- and nothing is requested here)
   auto res_f32 = [&](const res_t& r) __attribute__((always_inline)) -> f32x4 {
-    if constexpr (X16) {
-      const f32x4 v = f16x4_widen(r);
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = fminf(v[e], v[e] * inv_slope);
-      return o;
-    } else {
-      return __builtin_bit_cast(f32x4, r);
-    }
+    if constexpr (X16) return f32x4{0.f, 0.f, 0.f, 0.f};
+    else return __builtin_bit_cast(f32x4, r);
   };
+  if constexpr (!X16) {
 #pragma unroll
-  for (int i = 0; i < NRB; ++i) request_res(i);
+    for (int i = 0; i < NRB; ++i) request_res(i);
+  }
   __syncthreads();  // every wave is done with h
   VFX_TS(10);
   unsigned ya_sat = 0;
@@ -409,7 +432,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
       for (int q = 0; q < SUB; ++q)
         val[q] = *reinterpret_cast<const f32x4*>(smem + (r0 + (sp * SUB + q) * RPP) * LDO + 4 * c4) + bv +
                  res_f32(res[(pass * NSUB + sp) % NRB][q]);
-      if (pass * NSUB + sp + NRB < NEP * NSUB) request_res(pass * NSUB + sp + NRB);  // into the registers just consumed
+      if constexpr (!X16)
+        if (pass * NSUB + sp + NRB < NEP * NSUB) request_res(pass * NSUB + sp + NRB);  // into the registers just consumed
       if constexpr (!X16) {
 #pragma unroll
         for (int q = 0; q < SUB; ++q)

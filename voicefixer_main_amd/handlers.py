@@ -20,6 +20,7 @@ from .models import from_log, tensor2numpy, to_log
 EPS = 1e-12        # evaluation_proc/metrics.py:16
 EPS_UNIFY = 1e-8   # evaluation_proc/utils.py:8 (energy_unify)
 SEG_SECONDS = 60
+MAX_SEGMENT_BATCH = 4   # full segments of one file per call when no per-segment metrics are asked for (4 x 60 s: 3 GB of workspace)
 
 
 # ----------------------------------------------------------------------------------------
@@ -154,8 +155,10 @@ def refresh_model(ckpt, cls):
 
 
 def _pre(model, segment, device):
+    """`pre` of the handlers (eval_gsr_voicefixer.py:19-25): segment (n,) -> sp, mel, x (1, 1, n); a stack of equal-length
+    segments (k, n) -> the same for a batch of k."""
     x = segment if isinstance(segment, torch.Tensor) else torch.tensor(segment)
-    x = x[None, None, ...].to(device)
+    x = (x[None, None, ...] if x.dim() == 1 else x[:, None, :]).to(device)
     sp, _, _ = model.f_helper.wav_to_spectrogram_phase(x)
     mel_orig = model.mel(sp.permute(0, 1, 3, 2)).permute(0, 1, 3, 2)
     return sp, mel_orig, x
@@ -267,9 +270,10 @@ def _warn_peaks(peaks, input):
 
 def _peak_normalise(out):
     """`if max|out| > 1: out = out / max|out|` (eval_gsr_voicefixer.py:68-70) without the host round trip of the compare:
-    the same values bit for bit (x / p where p > 1, x otherwise); the peak is kept for the warning."""
-    peak = torch.max(torch.abs(out))
-    return torch.where(peak > 1.0, out / peak, out), peak
+    the same values bit for bit (x / p where p > 1, x otherwise); the peak is kept for the warning.  out (k, 1, n): every
+    segment of a batch has its own peak (the reference handles one segment per call)."""
+    peak = torch.amax(torch.abs(out), dim=(1, 2), keepdim=True)
+    return torch.where(peak > 1.0, out / peak, out), peak.max()
 
 
 def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=False, meta={}):
@@ -298,34 +302,46 @@ def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=Fals
         done = False
         try:
             while break_point < len(reader) + seg_length:
-                segment = reader.read(seg_length)
+                # Without a target there are no per-segment metrics, and a segment's result does not depend on the batch it is
+                # in (the kernels' sums are per clip): the FULL segments of the file go through the same calls up to
+                # MAX_SEGMENT_BATCH at a time -- the same bytes in the file, fewer and larger launches (round 5).  With a
+                # target the loop stays the reference's: one segment per iteration, its metrics replace the previous ones.
+                k = 1
+                if tgt is None:
+                    k = max(1, min(MAX_SEGMENT_BATCH, (len(reader) - (break_point - seg_length)) // seg_length))
+                segment = reader.read(k * seg_length)
                 if segment.shape[0] == 0:      # the header promised more frames than the file holds
                     break
-                _, mel_noisy, seg_t = _pre(model, torch.from_numpy(segment).pin_memory().to(device, non_blocking=True), device)
-                out_model = model(mel_noisy, check=False)
-                denoised_mel = from_log(out_model["mel"])
-                if unify:
-                    denoised_mel, mel_noisy = amp_to_original_f(mel_sp_est=denoised_mel, mel_sp_target=mel_noisy)
-                if tgt is not None:
-                    # like the reference (eval_gsr_voicefixer.py:56-64) the estimate and the target segment must have the
-                    # same number of frames: a shorter / longer target file raises instead of being trimmed silently
-                    _, target_mel, _ = _pre(model, tgt[break_point - seg_length:break_point], device)
-                    if target_mel.shape != denoised_mel.shape:
-                        raise RuntimeError("The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton "
-                                           "dimension 2" % (denoised_mel.shape[2], target_mel.shape[2]))
-                    m_lsd, m_lin = device_metrics(model.engine, denoised_mel.contiguous(), target_mel.contiguous())
-                    _, m_log = device_metrics(model.engine, out_model["mel"].contiguous(), to_log(target_mel))
-                    # non-log SiSpec is defined on from_log(model output) (eval_gsr_voicefixer.py:62), i.e. before unify_energy
+                full = segment.shape[0] // seg_length if k > 1 else 0
+                pieces = ([segment[:full * seg_length].reshape(full, seg_length)] if full else []) + \
+                         ([segment[full * seg_length:]] if segment.shape[0] > full * seg_length else [])
+                for piece in pieces:
+                    _, mel_noisy, seg_t = _pre(model, torch.from_numpy(np.ascontiguousarray(piece)).pin_memory().to(device, non_blocking=True), device)
+                    out_model = model(mel_noisy, check=False)
+                    denoised_mel = from_log(out_model["mel"])
                     if unify:
-                        _, m_lin = device_metrics(model.engine, from_log(out_model["mel"]).contiguous(), target_mel.contiguous())
-                    metrics = {"mel-lsd": m_lsd, "mel-sispec": m_log, "mel-non-log-sispec": m_lin,
-                               "mel-ssim": float(ssim(denoised_mel, target_mel))}
-                out = model.vocoder(denoised_mel, check=False)
-                out, peak = _peak_normalise(out)
-                peaks.append(peak)
-                out, _ = trim_center(out, seg_t)
-                writer.put(out[0, 0])
-                break_point += seg_length
+                        denoised_mel, mel_noisy = amp_to_original_f(mel_sp_est=denoised_mel, mel_sp_target=mel_noisy)
+                    if tgt is not None:
+                        # like the reference (eval_gsr_voicefixer.py:56-64) the estimate and the target segment must have the
+                        # same number of frames: a shorter / longer target file raises instead of being trimmed silently
+                        _, target_mel, _ = _pre(model, tgt[break_point - seg_length:break_point], device)
+                        if target_mel.shape != denoised_mel.shape:
+                            raise RuntimeError("The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton "
+                                               "dimension 2" % (denoised_mel.shape[2], target_mel.shape[2]))
+                        m_lsd, m_lin = device_metrics(model.engine, denoised_mel.contiguous(), target_mel.contiguous())
+                        _, m_log = device_metrics(model.engine, out_model["mel"].contiguous(), to_log(target_mel))
+                        # non-log SiSpec is defined on from_log(model output) (eval_gsr_voicefixer.py:62), i.e. before unify_energy
+                        if unify:
+                            _, m_lin = device_metrics(model.engine, from_log(out_model["mel"]).contiguous(), target_mel.contiguous())
+                        metrics = {"mel-lsd": m_lsd, "mel-sispec": m_log, "mel-non-log-sispec": m_lin,
+                                   "mel-ssim": float(ssim(denoised_mel, target_mel))}
+                    out = model.vocoder(denoised_mel, check=False)
+                    out, peak = _peak_normalise(out)
+                    peaks.append(peak)
+                    out, _ = trim_center(out, seg_t)
+                    for j in range(out.shape[0]):
+                        writer.put(out[j, 0])
+                    break_point += seg_length * out.shape[0]
             done = _file_flags_ok(model, writer)
         finally:
             reader.close()
