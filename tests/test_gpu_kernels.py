@@ -23,7 +23,8 @@ def _nchw(y):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 127, 32, 32), (1, 20, 7, 64, 128), (2, 5, 1, 384, 384),
-                                            (1, 16, 63, 32, 64), (3, 4, 3, 96, 256)])
+                                            (1, 16, 63, 32, 64), (3, 4, 3, 96, 256),
+                                            (1, 188, 3, 64, 96), (2, 94, 1, 96, 64)])      # tall narrow: fewer rows per tile (round 5)
 def test_conv3x3_prologue_residual(engine, B, H, W, Cin, Cout):
     """3x3 conv with BN-affine + LeakyReLU prologue, bias and residual epilogue vs fp64 torch."""
     x = _rand((B, Cin, H, W), 1)

@@ -718,6 +718,30 @@ def test_upsampler_patches_get_an_even_width():
     assert m.window_cost(8, 16, 17, [(0, 0), (0, 1), (1, 0), (1, 1)], m.key_2d)[0] == 1.5   # what the odd width cost
 
 
+def test_tall_narrow_images_keep_windowed_stages():
+    """The deep ResUNet levels of a LONG clip are tall narrow images (a 60-s segment: 376 x 7, 188 x 3, 94 x 1 pixels).  With
+    128 / TW rows per tile no tile shape had an all-taps window inside the 192-row patch buffer and plan_conv fell back to one
+    stage per (chunk, tap) -- nine times the stages and no split-K (round 5: 0.13 - 0.36 ms per launch for 0.05 ms of work).
+    The planner may now take fewer rows; shapes that fitted before are unchanged (the benched 10-s shapes among them)."""
+    import ctypes
+    from voicefixer_main_amd import _lib
+    lib = _lib.load_test()
+    out = (ctypes.c_int * 6)()
+    taps = [(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)]
+    dh, dw = (ctypes.c_int * 9)(*[t[0] for t in taps]), (ctypes.c_int * 9)(*[t[1] for t in taps])
+
+    def plan(Hg, Wg):
+        assert lib.vfx_plan_conv_geometry(Hg, Wg, 9, dh, dw, out) == 0
+        return list(out)
+    for Hg, Wg in [(188, 3), (94, 1), (376, 7), (47, 3), (200, 2), (1000, 1)]:
+        TH, TW, PW, P, per_tap, tiles = plan(Hg, Wg)
+        assert per_tap == 0 and P <= 192 and P == (TH + 2) * PW and TH * TW <= 128 and TH >= 1, (Hg, Wg, list(out))
+        assert tiles == -(-Hg // TH) * -(-Wg // TW)
+    # unchanged: the levels of a 10-s clip (Tpad = 1024) and of the 1-s chunk
+    assert plan(32, 3)[:5] == [32, 2, 4, 136, 0] and plan(16, 1)[:5] == [16, 1, 4, 72, 0]
+    assert plan(64, 7)[:2] == [16, 8] and plan(128, 15)[4] == 0 and plan(1024, 127)[4] == 0
+
+
 def test_tile_split_reciprocal_is_exact_including_one_tile_per_clip():
     """conv_common.h's div_recip(n, r) with the host's r = ceil(2^32 / d) (plan_resblock) -- restated here -- equals n // d for
     every tile count the plan admits (n * d < 2^32), including d = 1 (one tile per clip), where r = 2^32 does not fit 32 bits:

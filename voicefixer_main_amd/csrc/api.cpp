@@ -258,9 +258,21 @@ static void plan_conv(TapConvParams& p) {
   double best_util = -1.0;
   int64_t best_P = 0;
   const int sft0 = p.Hg == 1 ? 7 : 0;
+  // Rows of a TW-wide tile: 128 / TW, the image's height, and -- round 5 -- what keeps the all-taps window inside the patch
+  // buffer.  A TALL NARROW image (level 6 of a 60-s segment: 188 x 3 pixels; the bottleneck: 94 x 1) had no shape at all whose
+  // window fits at 128 / TW rows and fell back to one stage per (chunk, tap): nine times the stages, no split-K, 0.13 - 0.36 ms
+  // per launch where a 16 x 10 s batch takes 0.05 (profiles/r05_1x60_vs_16x10_per_launch.txt).  Shapes that fitted before keep
+  // their rows.
+  auto rows_of = [&](int sft) {
+    const int TW = 1 << sft;
+    const int64_t PW = TW + (int64_t)(dw_hi - dw_lo);
+    const int64_t fit = kPatchMaxRows / PW - (int64_t)(dh_hi - dh_lo);
+    return (int)std::max<int64_t>(0, std::min<int64_t>(std::min(128 / TW, p.Hg), fit));
+  };
   for (int sft = sft0; sft <= 7; ++sft) {
-    const int TW = 1 << sft, TH = std::min(128 / TW, p.Hg);
+    const int TW = 1 << sft, TH = rows_of(sft);
     if (TW > 2 * p.Wg && sft > sft0) break;
+    if (TH < 1) continue;
     const int64_t PH = TH + (int64_t)(dh_hi - dh_lo), PW = TW + (int64_t)(dw_hi - dw_lo);
     if (PH * PW > kPatchMaxRows || PW >= 65536) continue;
     const double covered = (double)((p.Hg + TH - 1) / TH) * ((p.Wg + TW - 1) / TW) * 128.0;
@@ -286,7 +298,7 @@ static void plan_conv(TapConvParams& p) {
       }
     }
   }
-  const int TW = 1 << tw_shift, TH = std::min(128 / TW, p.Hg);
+  const int TW = 1 << tw_shift, TH = window ? rows_of(tw_shift) : std::min(128 / TW, p.Hg);
   p.TH = TH;
   p.TW = TW;
   p.tw_shift = tw_shift;

@@ -622,7 +622,12 @@ int choose_ksplit(const TapConvParams& p) {
   // at most 8 slices; a batch of ordinary clips: >= 3 stages per slice, 128 blocks per clip aimed at (round 2); a short clip
   // (TapConvParams::short_clip: <= 128 padded frames): slices of one stage, 512 blocks per clip -- measured both ways in round 4
   // (profiles/r04_c8_splitk_ab.txt: each rule loses 20 % on the other's workload)
-  const int min_stages = p.short_clip ? 1 : 3, aim = p.short_clip ? 512 : 128;
+  // a LONG clip (short_clip < 0: -(padded frames / 1024), set by the ResUNet plans; round 5) comes in small batches by nature -- 6 clips
+  // of 60 s are all the tensor addressing allows -- so its deep launches aim at proportionally more blocks per clip: a 60-s
+  // segment (the handler's unit) ran its level-6 / bottleneck convolutions as 72 blocks walking 108 stages each, 0.13 - 0.36 ms
+  // per launch against 0.05 ms for the same level of a 16 x 10 s batch (profiles/r05_1x60_vs_16x10_per_launch.txt)
+  const int min_stages = p.short_clip > 0 ? 1 : 3;
+  const int aim = p.short_clip > 0 ? 512 : (p.short_clip < 0 ? std::min(1024, 128 * -p.short_clip) : 128);
   int s = std::min(8, std::min(p.nstages / min_stages, aim / std::max(par, 1)));
   int pow2 = 1;
   while (pow2 * 2 <= s) pow2 *= 2;

@@ -572,7 +572,7 @@ void build_unet_mel(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef log
   VFX_CHECK(pb.h->unet[VFX_MODEL_UNET_MEL], "mel ResUNet weights are not finalized");
   const UNetWeights& Wt = *pb.h->unet[VFX_MODEL_UNET_MEL];
   const int Tpad = (T + 63) / 64 * 64, W0 = 127;
-  pb.short_clip = Tpad <= 128 ? 1 : 0;  // split-K rule of the deep levels (TapConvParams::short_clip)
+  pb.short_clip = Tpad <= 128 ? 1 : (Tpad >= 2048 ? -(Tpad / 1024) : 0);  // split-K rule of the deep levels (TapConvParams::short_clip)
   Plan* pl = pb.plan;
   // a varlen batch (PlanBuilder::lens_t): every clip has its own frame count inside the SAME padded length -- the rows past it
   // are zeros like the network's own time padding (unet.py:75-77), so the trunk computes for each clip what its batch-of-one
@@ -598,7 +598,7 @@ void build_unet_spec(PlanBuilder& pb, int B, int T, BufRef sp, BufRef cosb, BufR
   VFX_CHECK(pb.h->unet[VFX_MODEL_UNET_SPEC], "spectrogram ResUNet weights are not finalized");
   const UNetWeights& Wt = *pb.h->unet[VFX_MODEL_UNET_SPEC];
   const int Tpad = (T + 63) / 64 * 64, W0 = 1024;
-  pb.short_clip = Tpad <= 128 ? 1 : 0;  // split-K rule of the deep levels (TapConvParams::short_clip)
+  pb.short_clip = Tpad <= 128 ? 1 : (Tpad >= 2048 ? -(Tpad / 1024) : 0);  // split-K rule of the deep levels (TapConvParams::short_clip)
   Plan* pl = pb.plan;
   const size_t x_off = pb.alloc_f((int64_t)B * Tpad * W0);
   pl->ops.push_back([=](const RunCtx& c) {

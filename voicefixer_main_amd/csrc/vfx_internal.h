@@ -183,7 +183,7 @@ struct TapConvParams {
   // cannot fill the chip whatever the batch is asked to be -- the deep launches are pure latency chains -- so the split aims at
   // 512 blocks per clip with slices of one stage (round 4: 3.16 -> 2.51 ms per 1-s chunk; the same rule costs a 16 x 10 s batch
   // +20 %, profiles/r04_c8_splitk_ab.txt).  A property of the CLIP, never of the batch: results stay batch-invariant.
-  int short_clip;
+  int short_clip;        // (< 0: a LONG clip of -short_clip x 1024 padded frames -- the split aims at 128 x that many blocks per clip)
   float* ws;
   int tuning;            // vfx_config.tuning of the handle (choose_ksplit)
   // Batches of clips of unequal length (vfx_restore_gsr_varlen; 1-D launches of the vocoder): lens[b] = length of clip b in
