@@ -27,8 +27,8 @@ product; 1 = split-bf16 everywhere (3 MFMAs per product), timed as well at N = 1
 `split_bf16_mode`; 0 = exact fp32 MFMA.
 
 Rank 0 prints ONE JSON line.  At N = 1 the default run also times configs[2] and configs[4] for a few steps in the same
-process and nests their value / ms_per_step / parity (vs the float64 oracle) / roofline under `aux_workloads`
-(--no-aux skips them).  Measured in the same run: `parity` (HIP outputs of the benched batch vs the CPU oracle on
+process and nests their value / ms_per_step / parity (vs the float64 oracle) / roofline under `aux_workloads`, together
+with `varlen_vctk`: 128 clips of 2 .. 8 s, no two of one length, through the padded-batch entry point (--no-aux skips them).  Measured in the same run: `parity` (HIP outputs of the benched batch vs the CPU oracle on
 the clips the oracle was run on; the run FAILS when the log-mel L1 exceeds the 1e-3 bar), `roofline` (HIP events around
 every convolution launch on its own stream over K more steps; `traffic` from two rocprofv3 PMC passes of a child run of
 the same workload), `roofline_hbm` (the HBM-bound front-end / back-end kernels), `cpu_baseline` (the CPU oracle, a port
@@ -729,6 +729,56 @@ def aux_workload(name, args, device, weights):
         return {"config": {"workload": name}, "error": repr(e)[:400]}
 
 
+def aux_varlen(args, device, weights, n=128, lo=2.0, hi=8.0):
+    """A test set of clips of UNEQUAL length (VCTK-shaped: 2 .. 8 s, no two alike) -- what the reference's harness iterates, one
+    handler call per file (evaluation_proc/eval.py:119-134) -- through dist.restore_sharded_lengths in a world of one: clips
+    bucketed by the ResUNet's padded frame count, one vfx_restore_gsr_varlen call per bucket (round 5).  Reported beside it: the
+    same clips one call per clip (rounds 1-4), bit-equality of the two on every clip, the shortest clip against the oracle."""
+    try:
+        from voicefixer_main_amd import dist as vdist
+        from voicefixer_main_amd import synth
+        w = Workload("gsr16x10", args, device, 0, 1, args.precision, clips_n=1, seconds=1.0, weights=weights)   # (its engine)
+        eng = w.eng
+        rng = np.random.default_rng(2025)
+        lens = [int(v) for v in rng.uniform(lo * 44100, hi * 44100, size=n)]
+        base = synth.make_clips(n, hi + 0.1, seed=77)[:, 0]
+        clips = [torch.from_numpy(base[i, :L].copy()).to(device) for i, L in enumerate(lens)]
+        total = sum(lens) / 44100.0
+        fn = vdist.checked_restore(eng)
+
+        def timed(f, reps=3):
+            f()
+            torch.cuda.synchronize(device)
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                out = f()
+                torch.cuda.synchronize(device)
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts)), out
+        dt, got = timed(lambda: vdist.restore_sharded_lengths(fn, clips, device))
+        dt1, one = timed(lambda: [eng.restore_gsr(c[None])[0] for c in clips], reps=1)
+        res = {"config": {"workload": "varlen_vctk", "clips": n, "clip_seconds_min_max": [round(min(lens) / 44100.0, 2), round(max(lens) / 44100.0, 2)],
+                          "audio_seconds": round(total, 1), "buckets": len({eng.padded_frames(L) for L in lens})},
+               "value": round(total / dt, 2), "unit": "audio-s/s", "seconds": round(dt, 4), "statistic": "median of 3 passes over the set",
+               "one_call_per_clip": {"value": round(total / dt1, 2), "seconds": round(dt1, 4)},
+               "varlen_equals_one_call_per_clip": bool(all(torch.equal(a, b) for a, b in zip(got, one))),
+               "dtype": dtype_string(True, args.precision, args.tuning)}
+        res.update(w.flags())
+        if not args.no_parity:
+            from oracle import pipeline
+            i = int(np.argmin(lens))
+            unet_sd, voc_sd = synth.make_resunet_state_dict(0), synth.make_vocoder_state_dict(1)
+            ref = pipeline.restore_gsr(unet_sd, voc_sd, base[i:i + 1, None, :lens[i]])
+            res["parity"] = {"clip": i, "wav_sisdr_db": round(sisdr_db(got[i].cpu().numpy(), ref["wav"][0, 0]), 2),
+                             "vs": "oracle.pipeline.restore_gsr on the shortest clip alone"}
+        del w
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:
+        return {"config": {"workload": "varlen_vctk"}, "error": repr(e)[:400]}
+
+
 # ---------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -908,6 +958,7 @@ def main():
             del w, eng
             torch.cuda.empty_cache()
             res["aux_workloads"] = {name: aux_workload(name, args, device, weights) for name in ("ssr_sr64", "stream1s")}
+            res["aux_workloads"]["varlen_vctk"] = aux_varlen(args, device, weights)
     if rank == 0:
         if failed:
             res["parity_failed"] = failed

@@ -190,6 +190,12 @@ int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_ou
 int vfx_restore_gsr_varlen(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out,
                            float* logmel_out, int flags, void* stream);
 
+/* The spectrogram-domain twin (the per-segment body of handler_ssr_unet, eval_ssr_unet.py:77-114: sp = |STFT(wav)|, model(sp, wav),
+ * models/components/unet_v2.py:86-148) for a batch of clips of unequal length: wav, wav_out (B, Lmax), lengths[b] (HOST) samples of
+ * clip b.  Per clip the frames and reflect padding of its own length, the trunk's zero padding behind its own last frame, the
+ * ISTFT to its own length; zeros past its end.  Same requirement: one padded frame count per call. */
+int vfx_restore_ssr_varlen(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out, void* stream);
+
 /*
  * Long-audio chunkers: the two `LambdaOverlapAdd` classes (tools/dsp/overlapadd.py:337-480 and
  * tools/dsp/overlapadd_boxcar.py:338-513) segment a signal, run the network per chunk and stitch.  The

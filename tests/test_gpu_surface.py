@@ -189,6 +189,32 @@ def test_restore_two_lengths_with_one_frame_count(engine, unet_sd, voc_sd):
         assert sisdr > engine.tol["sisdr"], (L, sisdr)
 
 
+def test_ssr_restore_list_of_unequal_lengths(engine):
+    """The spectrogram-domain twin (vfx_restore_ssr_varlen through SSR_UNet.restore_list): four clips of four lengths in one
+    padded-frame bucket plus one in another give, clip by clip, what `pre` + `forward` of that clip alone give -- bit for bit --
+    and what the float64 oracle computes for it (the full-band bars of the spectrogram path)."""
+    from oracle import pipeline
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.models import SSR_UNet
+    sd = synth.make_resunet_state_dict(2)
+    m = SSR_UNet(None, channels=1, engine=engine)
+    m.load_state_dict({"generator.unet." + k: v for k, v in sd.items()})
+    lens = [28500, 41000, 33333, 50017, 14312]                    # frames 65, 93, 76, 114 (pad to 128) and 33 (pads to 64)
+    clips, _ = _varlen_batch(lens, seed=130)
+    got = m.restore_list(clips)
+    assert [int(g.shape[0]) for g in got] == lens
+    for c, g in zip(clips, got):
+        x = c[None, None]
+        sp, _ = m.pre(x)
+        assert torch.equal(g, m(sp, x)["wav"][0, 0])
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    for j in (0, 3):
+        ref = pipeline.restore_ssr(sd64, clips[j].cpu().numpy().astype(np.float64)[None, None], dtype=torch.float64)["wav"][0, 0]
+        err = got[j].cpu().numpy().astype(np.float64) - ref
+        s = 10 * np.log10((ref ** 2).sum() / ((err ** 2).sum() + 1e-30))
+        assert s > (105.0 if engine.tol['name'] == 'fp32' else 88.0), (j, s)
+
+
 def test_restore_varlen_sub_batches_and_errors(engine, monkeypatch):
     clips, x = _varlen_batch(VARLEN, seed=90)
     want = engine.restore_gsr_varlen(x, VARLEN)

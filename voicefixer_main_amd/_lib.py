@@ -59,6 +59,7 @@ SIGNATURES = {
     "vfx_vocoder": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vfx_restore_gsr": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "vfx_restore_gsr_varlen": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_int), c_void_p, c_void_p, c_int, c_void_p]),
+    "vfx_restore_ssr_varlen": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_int), c_void_p, c_void_p]),
     "vfx_take_flags": (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
     "vfx_take_flags_masked": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "vfx_profile_begin": (c_int, [c_void_p]),

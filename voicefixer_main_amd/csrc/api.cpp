@@ -1361,6 +1361,68 @@ static int vfx_restore_gsr_varlen_1(vfx_handle* h, const float* wav, int B, int 
   VFX_API_END
 }
 
+// The spectrogram-domain twin: the per-segment body of handler_ssr_unet (eval_ssr_unet.py:77-114: sp = |STFT(wav)|, model(sp, wav))
+// for a batch of clips of unequal length -- per clip the frames and reflection of its own length, the trunk's zero time padding
+// behind its own last frame (unet_v2.py:103-110), the ISTFT to its own length (fDomainHelper.py:30-32); zeros past its end.
+// Same requirement as vfx_restore_gsr_varlen: one padded frame count per call.
+static int vfx_restore_ssr_varlen_1(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out, void* stream);
+int vfx_restore_ssr_varlen(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out, void* stream) {
+  if (!h || B <= 0 || Lmax <= 0 || !lengths) return vfx_restore_ssr_varlen_1(h, wav, B, Lmax, lengths, wav_out, stream);
+  const int T = Lmax / h->cfg.hop + 1;
+  const int step = std::min(kMaxVarlenClips, max_clips_per_launch(h, T, false, true, false));
+  for (int b = 0; b < B; b += step) {
+    const int rc = vfx_restore_ssr_varlen_1(h, wav + (int64_t)b * Lmax, std::min(step, B - b), Lmax, lengths + b,
+                                            wav_out + (int64_t)b * Lmax, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static int vfx_restore_ssr_varlen_1(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out, void* stream) {
+  VFX_API_BEGIN_H(h)
+  VFX_CHECK(h && wav && wav_out && lengths && B > 0 && B <= kMaxVarlenClips, "bad argument");
+  VFX_CHECK(h->unet[VFX_MODEL_UNET_SPEC], "vfx_restore_ssr_varlen: weights of the spectrogram ResUNet are not finalized");
+  const int hop = h->cfg.hop;
+  const int T = frames_of(h, Lmax), Tpad = (T + 63) / 64 * 64;
+  std::vector<int> host(3 * (size_t)B);
+  for (int b = 0; b < B; ++b) {
+    const int Lb = lengths[b];
+    VFX_CHECK(Lb > h->cfg.n_fft / 2 && Lb <= Lmax, "vfx_restore_ssr_varlen: clip %d has %d samples (need %d < length <= Lmax = %d)", b, Lb,
+              h->cfg.n_fft / 2, Lmax);
+    const int Tb = Lb / hop + 1;
+    VFX_CHECK((Tb + 63) / 64 * 64 == Tpad, "vfx_restore_ssr_varlen: clip %d has %d frames (padded %d) but the batch's longest row pads to %d -- "
+              "the clips of one call must share 64 * ceil(T / 64): bucket them by it", b, Tb, (Tb + 63) / 64 * 64, Tpad);
+    host[b] = Lb;
+    host[B + b] = Tb;
+    host[2 * (size_t)B + b] = Tb;  // (no vocoder here)
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int* const d_l = h->d_lens;
+  int* const d_t = h->d_lens + kMaxVarlenClips;
+  launch_set_lens(h->d_lens, kMaxVarlenClips, host.data(), B, s);
+  const size_t nsp = (size_t)B * T * (h->cfg.n_fft / 2 + 1);
+  auto plan = get_plan(h, key_of("restore_ssr_vl", B, Lmax), [&](PlanBuilder& pb) {
+    auto& nm = pb.plan->named;
+    const size_t o_sp = pb.alloc_f(nsp), o_cos = pb.alloc_f(nsp), o_sin = pb.alloc_f(nsp), o_re = pb.alloc_f(nsp), o_im = pb.alloc_f(nsp);
+    nm["re"] = o_re;
+    nm["im"] = o_im;
+    vfx_handle* hh = pb.h;
+    Plan* pl = pb.plan;
+    pb.lens_t = d_t;
+    pl->ops.push_back([=](const RunCtx& c) {  // one STFT for magnitude and phase (the reference runs two: eval_ssr_unet.py:80, unet_v2.py:96)
+      launch_stft_mel(hh->fe, c.ext[0], B, Lmax, T, nullptr, reinterpret_cast<float*>(pl->bound_base + o_sp),
+                      reinterpret_cast<float*>(pl->bound_base + o_cos), reinterpret_cast<float*>(pl->bound_base + o_sin), 0, hh->cfg.hop,
+                      1e-8f, c.stream, d_l);
+    });
+    build_unet_spec(pb, B, T, arena_buf(o_sp), arena_buf(o_cos), arena_buf(o_sin), arena_buf(o_re), arena_buf(o_im));
+  }, stream);
+  debug_poison(*plan, stream);
+  RunCtx ctx{s, {const_cast<float*>(wav)}, h->d_flags, &h->prof};
+  plan->run(ctx);
+  launch_istft(h->fe, reinterpret_cast<float*>(h->arena + plan->named["re"]), reinterpret_cast<float*>(h->arena + plan->named["im"]), B, T,
+               Lmax, hop, wav_out, s, d_l);
+  VFX_API_END
+}
+
 // ---------------------------------------------------------------------------------------------
 // live kernel timing (bench.py roofline): HIP events around every tap-convolution launch, on the
 // stream the kernels are launched on.

@@ -600,9 +600,10 @@ void build_unet_spec(PlanBuilder& pb, int B, int T, BufRef sp, BufRef cosb, BufR
   const int Tpad = (T + 63) / 64 * 64, W0 = 1024;
   pb.short_clip = Tpad <= 128 ? 1 : (Tpad >= 2048 ? -(Tpad / 1024) : 0);  // split-K rule of the deep levels (TapConvParams::short_clip)
   Plan* pl = pb.plan;
+  const int* lens_t = pb.lens_t;  // a varlen batch: the rows past a clip's own frames are zeros (cf. build_unet_mel)
   const size_t x_off = pb.alloc_f((int64_t)B * Tpad * W0);
   pl->ops.push_back([=](const RunCtx& c) {
-    launch_prep_spec(resolve(pl, c, sp), B, T, Tpad, reinterpret_cast<float*>(pl->bound_base + x_off), c.stream);
+    launch_prep_spec(resolve(pl, c, sp), B, T, Tpad, reinterpret_cast<float*>(pl->bound_base + x_off), c.stream, lens_t);
   });
   TrunkBuilder tb{pb, Wt, B};
   Act4 y = tb.run(x_off, Tpad, W0, /*both=*/true);

@@ -41,7 +41,8 @@ __global__ void k_prep_logmel(const float* __restrict__ mel, int B, int T, int T
 }
 
 // unet_v2.py:103-110: (B,T,1025) -> (B,Tpad,1024), zero rows beyond T, last bin dropped.
-__global__ void k_prep_spec(const float* __restrict__ sp, int B, int T, int Tpad, float* __restrict__ x) {
+__global__ void k_prep_spec(const float* __restrict__ sp, int B, int T, int Tpad, float* __restrict__ x,
+                            const int* __restrict__ lens_t /* frames per clip of a varlen batch, or null */) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)B * Tpad * 1024;
   if (idx >= total) return;
@@ -49,15 +50,15 @@ __global__ void k_prep_spec(const float* __restrict__ sp, int B, int T, int Tpad
   const int64_t r = idx >> 10;
   const int i = r % Tpad;
   const int b = r / Tpad;
-  x[idx] = i < T ? sp[((int64_t)b * T + i) * 1025 + f] : 0.f;
+  x[idx] = i < (lens_t ? min(T, lens_t[b]) : T) ? sp[((int64_t)b * T + i) * 1025 + f] : 0.f;
 }
 
 void launch_prep_logmel(const float* mel, int B, int T, int Tpad, float* x, int* flags, hipStream_t s, const int* lens_t) {
   hipLaunchKernelGGL(k_prep_logmel, dim3(nblocks((int64_t)B * Tpad * 127, 256)), dim3(256), 0, s, mel, B, T, Tpad, x, flags, lens_t);
   VFX_HIP(hipGetLastError());
 }
-void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s) {
-  hipLaunchKernelGGL(k_prep_spec, dim3(nblocks((int64_t)B * Tpad * 1024, 256)), dim3(256), 0, s, sp, B, T, Tpad, x);
+void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s, const int* lens_t) {
+  hipLaunchKernelGGL(k_prep_spec, dim3(nblocks((int64_t)B * Tpad * 1024, 256)), dim3(256), 0, s, sp, B, T, Tpad, x, lens_t);
   VFX_HIP(hipGetLastError());
 }
 

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(128) void k_mel_project(const float* __restrict__ s
 __global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_istft(const float* __restrict__ re, const float* __restrict__ im,
                                                               const float* __restrict__ window, const float2* __restrict__ tw,
                                                               const float2* __restrict__ rtw, int T, int L, int hop, int groups,
-                                                              int IH, float* __restrict__ wav) {
+                                                              int IH, float* __restrict__ wav, const int* __restrict__ lens) {
   __shared__ float2 twl[NC];
   __shared__ float2 wl[NC];  // the synthesis window, as pairs
   __shared__ float2 zbuf[STFT_WAVES][ZP];
@@ -373,6 +373,14 @@ __global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_istft(const float* __res
   int lane = tid & 63;
   const int span = IH * hop;
   const int p0 = g * span;                      // first owned position of the un-trimmed overlap-add buffer
+  // `lens` (a batch of clips of unequal length): clip b has lens[b] <= L samples, i.e. Tc = lens[b] / hop + 1 <= T frames -- the
+  // later frames of its rows of re / im do not exist for it and its samples past lens[b] are written as zeros; T and L stay the
+  // row strides
+  const int Ts = T, Ls = L;
+  if (lens) {
+    L = lens[b];
+    T = min(T, L / hop + 1);
+  }
   const int t_lo = max(0, g * IH - (NFFT - 1) / hop), t_hi = min(T - 1, g * IH + IH - 1);
   for (int i = tid; i < span; i += STFT_WAVES * 64) ola[i] = 0.f;
 #pragma unroll
@@ -387,8 +395,8 @@ __global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_istft(const float* __res
   // the spectrum of this wave's frame of a round: (Re, Im) of bins k and 1024 - k, k = lane + 64 r
   float2 xk[16], xn[16];
   auto load_spectrum = [&](int t) __attribute__((always_inline)) {
-    const float* R = re + ((int64_t)b * T + t) * NBINS;
-    const float* I = im + ((int64_t)b * T + t) * NBINS;
+    const float* R = re + ((int64_t)b * Ts + t) * NBINS;
+    const float* I = im + ((int64_t)b * Ts + t) * NBINS;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned k = (unsigned)(lane + 64 * r);
@@ -441,9 +449,9 @@ __global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_istft(const float* __res
   const int total = NFFT + hop * (T - 1);
   for (int i = tid; i < span; i += STFT_WAVES * 64) {
     const int p = p0 + i, n = p - NFFT / 2;
-    if (n < 0 || n >= L) continue;
+    if (n < 0 || n >= Ls) continue;
     float out = 0.f;
-    if (p < total) {
+    if (p < total && n < L) {
       float env = 0.f;
       int th = p / hop;                        // last frame starting at or before p
       if (th > T - 1) th = T - 1;
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(STFT_WAVES * 64, 2) void k_istft(const float* __res
       }
       out = env > 1.1754944e-38f ? ola[i] / env : ola[i];
     }
-    wav[(int64_t)b * L + n] = out;
+    wav[(int64_t)b * Ls + n] = out;
   }
 }
 
@@ -489,14 +497,14 @@ void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, 
 }
 
 void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop, float* wav,
-                  hipStream_t stream) {
+                  hipStream_t stream, const int* lens) {
   // groups cover the positions [0, 1024 + L) of the un-trimmed overlap-add buffer
   const int IH = (int64_t)B * T >= 4096 ? 16 : 2;
   const int span = IH * hop;
   const int groups = (NFFT / 2 + L + span - 1) / span;
   hipLaunchKernelGGL(k_istft, dim3(B * groups), dim3(256), (size_t)span * sizeof(float), stream, re, im, t.window,
                      reinterpret_cast<const float2*>(t.twiddle), reinterpret_cast<const float2*>(t.rtwiddle), T, L, hop,
-                     groups, IH, wav);
+                     groups, IH, wav, lens);
   VFX_HIP(hipGetLastError());
 }
 

@@ -328,11 +328,11 @@ void launch_stft_mel(const FrontEndTables& t, const float* wav, int B, int L, in
                      const int* lens = nullptr);
 void launch_mel_project(const FrontEndTables& t, const float* sp, int64_t rows, float* mel, hipStream_t stream);
 void launch_istft(const FrontEndTables& t, const float* re, const float* im, int B, int T, int L, int hop, float* wav,
-                  hipStream_t stream);
+                  hipStream_t stream, const int* lens = nullptr);  // lens: samples per clip of a varlen batch (device, [B])
 
 void launch_prep_logmel(const float* mel_linear, int B, int T, int Tpad, float* x, int* flags, hipStream_t s,
                         const int* lens_t = nullptr);  // lens_t: frames per clip of a varlen batch (device, [B])
-void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s);
+void launch_prep_spec(const float* sp, int B, int T, int Tpad, float* x, hipStream_t s, const int* lens_t = nullptr);
 void launch_conv_c1(const float* x, int B, int H, int W, const float* w9x32, float scale, float shift, float slope,
                     const float* wsc32, const float* bsc32, float* h, float* sc, hipStream_t s);
 void launch_avgpool2(const float* x, int B, int H, int W, int C, float* y, hipStream_t s);

@@ -283,6 +283,20 @@ class Engine:
                                                    int(bool(unify_energy)), self._stream()), "vfx_restore_gsr_varlen")
         return (out, logmel) if want_logmel else out
 
+    def restore_ssr_varlen(self, wav, lengths, out=None):
+        """ssr_unet / gsr_unet forward (sp = |STFT(wav)|, model(sp, wav)) for a batch of clips of UNEQUAL length: wav (B, Lmax),
+        clip b = wav[b, :lengths[b]] -> (B, Lmax), zero past a clip's end; one `padded_frames` bucket per call."""
+        wav = _dev_f32(wav, self.device)
+        B, L = wav.shape
+        lengths = [int(v) for v in lengths]
+        if len(lengths) != B:
+            raise ValueError("restore_ssr_varlen: %d lengths for %d clips" % (len(lengths), B))
+        arr = (ctypes.c_int * B)(*lengths)
+        if out is None:
+            out = torch.empty_like(wav)
+        _lib.check(self.lib.vfx_restore_ssr_varlen(self.h, _ptr(wav), B, L, arr, _ptr(out), self._stream()), "vfx_restore_ssr_varlen")
+        return out
+
     def check_negative_input(self):
         """`to_log`'s assert alone (pytorch_util.py:158): reads and clears ONLY the negative-input bit -- a saturation bit a
         deferred vocoder check still has to see stays raised."""

@@ -413,5 +413,20 @@ class SSR_UNet(_Base):
 
     __call__ = forward
 
+    def restore_list(self, wavs, max_batch=16):
+        """A test set of clips of ARBITRARY lengths through `pre` + `forward` (eval_ssr_unet.py:77-114, one handler call per file
+        in the reference): list of 1-D tensors -> list of restored 1-D tensors in the same order.  Clips whose frame counts pad
+        to the same multiple of 64 share one call of the library as a padded batch with their lengths (vfx_restore_ssr_varlen);
+        with torch.distributed initialised the list is dealt over the ranks (dist.restore_sharded_lengths)."""
+        from . import dist as vdist
+        eng = self.engine
+
+        def fn(x, lengths=None):
+            if lengths is None:
+                return eng.resunet_spec(eng.stft(x, want_mel=False, want_sp=True)["sp"], x)
+            return eng.restore_ssr_varlen(x, lengths)
+        fn.bucket_key = eng.padded_frames
+        return vdist.restore_sharded_lengths(fn, wavs, self.device, max_batch=max_batch)
+
 
 GSR_UNet = SSR_UNet
