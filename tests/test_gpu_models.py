@@ -267,6 +267,22 @@ def test_tuning_switches(name, bit, precision, unet_sd, voc_sd, capfd):
     assert d.mean() < tol["logmel_l1"] and d.max() < tol["logmel_max"], (d.mean(), d.max())
     assert _sisdr(out.cpu().numpy(), ref["wav"][:, 0]) > tol["sisdr"]
     assert eng.take_flags() == 0
+    # the same kernel selection on a batch of clips of UNEQUAL length (vfx_restore_gsr_varlen: every launch of the selected forms
+    # takes the per-clip lengths): three lengths in one padded-frame bucket, each equal to its own batch-of-one call.  The one
+    # combination the library refuses: the persistent C = 64 kernel on the fp32 trunk (no register left for the length).
+    lens = [66150, 61000, 57000]
+    x = torch.zeros((3, lens[0]))
+    for j, L in enumerate(lens):
+        x[j, :L] = torch.from_numpy(wav[j, 0, :L])
+    if name == "F32_TRUNK":
+        with pytest.raises(RuntimeError, match="fp16 trunk"):
+            eng.restore_gsr_varlen(x, lens)
+        eng.take_flags()
+        return
+    got = eng.restore_gsr_varlen(x, lens)
+    for j, L in enumerate(lens):
+        assert torch.equal(got[j, :L], eng.restore_gsr(x[j:j + 1, :L].contiguous())[0]), (name, j)
+    assert eng.take_flags() & 3 == 0
 
 
 _TUNING_REF = {}
