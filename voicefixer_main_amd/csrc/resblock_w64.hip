@@ -343,6 +343,59 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
   conv(prep2, NT1, 2 * NT1, false);
   VFX_TS(9);
 
+  // ---- phase 4 ------------------------------------------------------------------------------------------------------------------
+  if constexpr (X16) {
+    // fp16 trunk (round 5): ya = fp16(LeakyReLU(acc + b2)) straight from the accumulators -- the residual is inside them since
+    // phase 2 -- with NO staging through LDS and no barrier.  A lane holds, per position block and cout block, four runs of 4
+    // consecutive channels (8 bytes of fp16) 16 bytes apart; its partner 32 lanes away holds the runs in between.  One
+    // v_permlane32_swap per register pair trades run j + 1 of the lower lane for run j of the upper one: every lane ends up with
+    // 16 contiguous bytes and a store instruction writes 32 contiguous bytes of 32 rows.  (Rounds 3-4 staged the tile in LDS in two
+    // passes: 256 KB of LDS traffic and four block barriers per tile, 17 k of a block's 80 k cycles, profiles/r04_phase_timing_f16_trunk.txt.)
+    int l31e = l31, lhe = lh, we = wave_u;
+    asm volatile("" : "+v"(l31e), "+v"(lhe), "+s"(we));  // the epilogue's index math stays behind conv2 (hoisted into its last taps it spills)
+    const float aslope = p.act_slope;
+    const unsigned yabytes = (unsigned)((int64_t)p.B * T * C * 2);
+    const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(p.ya, 0, (int)yabytes, 0x00020000);
+    constexpr unsigned kOob = 0xC0000000u;  // beyond the descriptor (the launch checks the tensor is < 2 GiB), + 1 KB does not wrap
+    unsigned ya_sat = 0;
+    VFX_TS(10);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      f32x4 b2v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b2v[j] = *(const VFX_GLOBAL f32x4*)(p.b2 + (2 * we + cb) * 32 + 8 * j + 4 * lhe);
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const int m = a * 32 + l31e;
+        const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
+        const int pos = base_h + li * rowstride + lj;
+        const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) & (!p.fold | (j0 + lj - 1 < d));
+        const unsigned rowoff = ok ? (unsigned)(img * T + pos) * (unsigned)(C * 2) + (unsigned)((2 * we + cb) * 64 + 16 * lhe) : kOob;
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+          unsigned q[2][2];  // [run jp, jp + 1][channels 0-1, 2-3]
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            f32x4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = acc[cb][a][4 * (jp + r) + e] + b2v[jp + r][e];
+              u[e] = fmaxf(v, v * aslope);
+            }
+            q[r][0] = pack_f16x2(u[0], u[1], ya_sat);
+            q[r][1] = pack_f16x2(u[2], u[3], ya_sat);
+          }
+          // lanes 0-31 keep their run jp and receive the partner's run jp; lanes 32-63 receive the partner's run jp + 1 and keep theirs
+          const auto s0 = __builtin_amdgcn_permlane32_swap(q[0][0], q[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(q[0][1], q[1][1], false, false);
+          const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+          __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+        }
+      }
+    }
+    VFX_TS(11);
+    report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
+  } else {
   // ---- phase 4: y = conv2 + b2 + x, raw fp32 and (optionally) activated fp16 -----------------------------------------------------
   // Two passes of 128 channels (the pass of waves 0, 1, then the one of waves 2, 3) through a staged tile in LDS; every pass in
   // NSUB sub-passes of 32 rows whose residual is requested one sub-pass ahead (the loads of sub-pass s + 1 are issued BEFORE
@@ -459,7 +512,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
     if (pass == 0) { VFX_TS(11); }  // pass 0 stored
     if (pass + 1 < NEP) __syncthreads();  // the staged pass has been consumed
   }
-  if (X16 || p.ya) report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
+  if (p.ya) report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
+  }
   VFX_TS(12);
   VFX_TS_FLUSH(p.timing, tile, wave_u, NW);
 }
