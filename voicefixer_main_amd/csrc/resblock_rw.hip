@@ -65,7 +65,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   constexpr int NHALF = PAIR ? 2 : 1;       // the accumulators are staged over R0 (+ R1) at once, or in two halves over R0
   static_assert(NCQ == 8 && (MT / NHALF) * LDO * 4 <= (PAIR ? PR : PR + MT) * ROWB, "staging must fit");
   constexpr int WL_OFF = (PR + MT) * ROWB;  // pairs: weight fragments [conv2 A | conv1 B | conv2 B], 24 KB each
-  constexpr int BIAS_OFF = PAIR ? WL_OFF + 3 * 24 * 1024 : WL_OFF;  // b1 (pairs: b1, b2, second layer's b1, b2): C floats each
+  // DIRECT (round 5; single layers on the fp16 trunk): no staged tile.  The raw fp16 centre rows of the patch go to a third LDS
+  // region RX (MT rows, the layout of h) beside their operand form; phase 2 reads them back in ACCUMULATOR layout as the initial
+  // value of conv2's accumulators, and the epilogue stores y straight from the accumulators (v_permlane32_swap pairs a lane's
+  // 8-byte runs with its partner's into 16-byte stores, cf. resblock_w64.hip).  Per tile this removes 64 KB of staging writes and
+  // reads, three of the five block barriers and the 32 residual registers; one block per CU owns the CU's LDS, so RX is free.
+  constexpr bool DIRECT = !PAIR && X16;
+  constexpr int RX = WL_OFF;                // DIRECT: raw fp16 rows of the tile's MT positions
+  constexpr int BIAS_OFF = PAIR ? WL_OFF + 3 * 24 * 1024 : (DIRECT ? WL_OFF + MT * ROWB : WL_OFF);  // b1 (pairs: b1, b2, second layer's b1, b2; DIRECT: b1, b2): C floats each
   static_assert(!PAIR || NW == 8, "pairs: 256-position tiles");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -118,6 +125,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   float* const b1s = reinterpret_cast<float*>(lds + BIAS_OFF);
   if (tid < C) b1s[tid] = ((const VFX_GLOBAL float*)p.b1)[tid];
   f32x4 b2v = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * cg);
+  if constexpr (DIRECT) {
+    if (tid < C) b1s[C + tid] = ((const VFX_GLOBAL float*)p.b2)[tid];
+  }
   if constexpr (PAIR) {
     if (tid < C) {
       b1s[C + tid] = ((const VFX_GLOBAL float*)p.b2)[tid];
@@ -258,6 +268,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     {
       unsigned sat16 = 0;
       const f16x2 slope2 = {(_Float16)slope, (_Float16)slope};
+      u32x2 rres[WM][4];  // DIRECT: this lane's residual pieces (pixel m, channels wn * 32 + 8 j + 4 lh .. + 3) out of RX
+      if constexpr (DIRECT) {
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+          const int m = (wm * WM + a) * 32 + l31_v;
+          const char* rowx = lds + RX + m * ROWB + 8 * lh;
+          const int key = (m >> 1) & 7;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rres[a][j] = *reinterpret_cast<const u32x2*>(rowx + (((wn * 4 + j) ^ key) << 4));
+        }
+      }
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
         const int m = (wm * WM + a) * 32 + l31_v;
@@ -270,8 +291,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
           // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
           const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j] + b1v[0], acc[a][4 * j + 1] + b1v[1], hval, sat16), slope2);
           const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j + 2] + b1v[2], acc[a][4 * j + 3] + b1v[3], hval, sat16), slope2);
+          if constexpr (DIRECT) {  // conv2 accumulates on top of the residual
+            const f32x4 v = f16x4_widen(rres[a][j]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = 0.f;
+          }
           *reinterpret_cast<uint2*>(rowp + (((wn * 4 + j) ^ key) << 4)) = make_uint2(h01, h23);  // LeakyReLU(0) = 0: masked stays 0
         }
       }
@@ -291,7 +318,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         }
         mma_set(std::integral_constant<int, SECOND ? 3 : 1>{}, c, k, hbuf, rows);
       }
-    __syncthreads();  // every wave is done with the patch and h: the staged accumulators may overlay them
+    // every wave is done with the patch and h: the staged accumulators may overlay them.  (DIRECT stages nothing: the next
+    // tile's patch goes to R0 / RX, last read before this tile's "h is complete" barrier, and h is rewritten only behind the
+    // next tile's "patch is complete" barrier, which no wave passes before every wave has left this conv2.)
+    if constexpr (!DIRECT) __syncthreads();
   };
   // the accumulators of rows [half * MT / NHALF, (half + 1) * MT / NHALF) to the staging rows (floats, over R0 (+ R1))
   auto stage = [&](int half) __attribute__((always_inline)) {
@@ -336,7 +366,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       if constexpr (X16) {
 #pragma unroll
         for (int q = 0; q < NCQ; ++q) {
-          K[q] = f16x4_widen(PC[q]);
+          if constexpr (DIRECT) {  // the raw row piece beside its operand form: h pixel m = lr + RQ q, the layout of h
+            const int m = lr_v + RQ * q;
+            *reinterpret_cast<uint2*>(lds + RX + m * ROWB + (((cg >> 1) ^ ((m >> 1) & 7)) << 4) + 8 * (cg & 1)) = make_uint2(PC[q].x, PC[q].y);
+          } else {
+            K[q] = f16x4_widen(PC[q]);
+          }
           if (crow(q) < P) to_patch16(lds + R0, PC[q], crow(q));
         }
 #pragma unroll
@@ -387,6 +422,58 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       b2v = *reinterpret_cast<const f32x4*>(b1s + 3 * C + 4 * cg);
     }
 
+    if constexpr (DIRECT) {
+      // ---- epilogue, DIRECT: y = acc + b2 (the residual is inside the accumulators) straight to memory -----------------------------
+      char* const yb = reinterpret_cast<char*>(p.y) + ((int64_t)img * T * C + wn * 32 + 8 * lh) * 2;
+      char* const yab = reinterpret_cast<char*>(p.ya) + ((int64_t)img * T * C + wn * 32 + 8 * lh) * 2;
+      const bool have_y = p.y != nullptr, have_ya = p.ya != nullptr;
+      const float aslope = p.act_slope;
+      unsigned sat = 0;
+      f32x4 b2r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b2r[j] = *reinterpret_cast<const f32x4*>(b1s + C + wn * 32 + 8 * j + 4 * lh);
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const int m = (wm * WM + a) * 32 + l31_v;
+        const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
+        const int pos = base_h + li * rowstride + lj;
+        const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) & (!p.fold | (j0 + lj - 1 < d));
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+          f32x4 v[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[r][e] = acc[a][4 * (jp + r) + e] + b2r[jp + r][e];
+              acc[a][4 * (jp + r) + e] = 0.f;
+            }
+          // lanes 0-31 keep their run jp and receive the partner's run jp; lanes 32-63 receive the partner's run jp + 1 and keep theirs
+          if (have_y) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pack_f16x2(v[0][0], v[0][1], sat), pack_f16x2(v[1][0], v[1][1], sat), false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pack_f16x2(v[0][2], v[0][3], sat), pack_f16x2(v[1][2], v[1][3], sat), false, false);
+            const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+            if (ok) *(VFX_GLOBAL u32x4*)(yb + (int64_t)pos * C * 2 + 16 * jp) = w;
+          }
+          if (have_ya) {  // last layer in front of an upsampler: ya = fp16(LeakyReLU(y, act_slope))
+            unsigned q2[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              f32x4 u;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) u[e] = fmaxf(v[r][e], v[r][e] * aslope);
+              q2[r][0] = pack_f16x2(u[0], u[1], sat);
+              q2[r][1] = pack_f16x2(u[2], u[3], sat);
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(q2[0][0], q2[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(q2[0][1], q2[1][1], false, false);
+            const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+            if (ok) *(VFX_GLOBAL u32x4*)(yab + (int64_t)pos * C * 2 + 16 * jp) = w;
+          }
+        }
+      }
+      report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
+    } else
     // ---- epilogue: y = conv2 + residual + b2 in the layout of the centre loads ----------------------------------------------
     {
       char* const yi = reinterpret_cast<char*>(p.y) + ((int64_t)img * T * C + 4 * cg) * (X16 ? 2 : 4);
@@ -464,7 +551,9 @@ template <int NW, bool PAIR, bool X16, int HALO = 64>
 static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {
   constexpr int MT = NW * 32;
   // the two operand regions (the staged accumulators overlay them) + biases; pairs: + three sets of weight fragments
-  const size_t lds = (size_t)(MT + HALO + MT) * 128 + (PAIR ? (size_t)72 * 1024 + 4 * 64 * sizeof(float) : 64 * sizeof(float));
+  // (DIRECT = single layers on the fp16 trunk: + the raw rows RX and b2)
+  const size_t lds = (size_t)(MT + HALO + MT) * 128 + (PAIR ? (size_t)72 * 1024 + 4 * 64 * sizeof(float)
+                                                             : (X16 ? (size_t)MT * 128 + 2 * 64 * sizeof(float) : 64 * sizeof(float)));
   const int slots = cu_count_of_current_device() * (NW == 4 ? 2 : 1);  // 256 registers per wave: 8 waves per CU
   const int per_block = (int)((ntiles + slots - 1) / slots);
   const int grid = (int)((ntiles + per_block - 1) / per_block);
