@@ -58,6 +58,14 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   constexpr int NTOT = (PAIR ? 4 : 2) * NT1; // taps of the launch
   constexpr int LDO = C + 4;                 // staged output row (floats)
   constexpr int KEEP = MT / 8;               // centre rows per thread (16: rows rt + 8 j of one chunk)
+  // DIRECT (round 5, the fp16 trunk): no staged tile and no residual registers in store layout.  The patch rows use only the
+  // logical pieces 0..3 of their 128-byte rows (32 channels of fp16); the RAW fp16 values of the centre rows are parked in pieces
+  // 4..7 of the same rows.  After conv1 every wave reads its 64 couts x 64 positions of them back in ACCUMULATOR layout (before the
+  // barrier that hands the buffers over to h) and conv2 accumulates on top of the residual; the epilogue adds b2 and stores straight
+  // from the accumulators (v_permlane32_swap pairs a lane's 8-byte runs with its partner's into 16-byte stores, cf.
+  // resblock_w64.hip).  A pair keeps y1 = the first layer's output in 64 registers in accumulator layout: activated, it is
+  // written as the second layer's operand rows; raw, it is the initial value of the second conv2's accumulators.
+  constexpr bool DIRECT = X16;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = reinterpret_cast<char*>(smem);
@@ -205,7 +213,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       const int key = (prow[j] >> 1) & 7;
       uint2* const dst = reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((cgt >> 1) ^ key) << 4) + 8 * (cgt & 1));
       if constexpr (X16) {
-        if (j < KEEP) keep[j] = f16x4_widen(raw[j]);
+        if (j < KEEP)  // DIRECT: the raw piece beside its operand form, logical piece 4 + (cgt >> 1) of the same row
+          *reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((4 + (cgt >> 1)) ^ key) << 4) + 8 * (cgt & 1)) = make_uint2(raw[j].x, raw[j].y);
         const u32x2 v = f16x4_lrelu(raw[j], slope);  // packed: v_pk_mul_f16, v_pk_max_f16
         *dst = make_uint2(v.x, v.y);
       } else {
@@ -307,7 +316,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   // h = LeakyReLU(conv1 + bias) in operand form, zero where `valid` says the h pixel lies outside the tile's grid / the sequence.
   // Lane (l31, lh) of position block a holds h pixel m = 64 wm + 32 a + l31 and, in registers 4j .. 4j+3 of cout block n, channels
   // (2 wn + n) * 32 + 8j + 4lh .. +3: chunk 2 wn + n of the pixel's row, piece j, half lh.
-  auto write_h = [&](const float* bias, const bool (&valid)[WM]) __attribute__((always_inline)) {
+  // DIRECT: conv2's accumulators start from the residual -- `init` = 1: the raw fp16 pieces `rres` read out of the patch rows, 2: y1
+  u32x2 rres[WN][WM][4];
+  f32x16 y1[WN][WM];
+  auto write_h = [&](const float* bias, const bool (&valid)[WM], auto init_tag) __attribute__((always_inline)) {
+    constexpr int INIT = decltype(init_tag)::value;
     unsigned sat16 = 0;
     const f16x2 slope2 = {(_Float16)slope, (_Float16)slope};
 #pragma unroll
@@ -326,8 +339,17 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
           // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
           const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[n][a][4 * j] + b1v[j][0], acc[n][a][4 * j + 1] + b1v[j][1], valid[a], sat16), slope2);
           const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[n][a][4 * j + 2] + b1v[j][2], acc[n][a][4 * j + 3] + b1v[j][3], valid[a], sat16), slope2);
+          if constexpr (INIT == 1) {
+            const f32x4 v = f16x4_widen(rres[n][a][j]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[n][a][4 * j + e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[n][a][4 * j + e] = v[e];
+          } else if constexpr (INIT == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[n][a][4 * j + e] = y1[n][a][4 * j + e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[n][a][4 * j + e] = 0.f;
+          }
           *reinterpret_cast<uint2*>(rowp + ((j ^ key) << 4)) = make_uint2(h01, h23);  // LeakyReLU(0) = 0: masked stays 0
         }
       }
@@ -353,22 +375,90 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 
   // ---- first (or only) layer -----------------------------------------------------------------------------------------------------
   conv(prep1, 0, NT1, true);  // its last taps fetch the first taps of conv2
+  if constexpr (DIRECT) {  // the residual out of the patch rows' upper pieces, before the buffers are handed over to h
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      int r = arow1[a];
+      asm volatile("" : "+v"(r));
+      const int row = r + poff1;
+      const int key = swz_key(row);
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const char* rowp = lds + (2 * wn + n) * PBYTES + row * CROW + 8 * lh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rres[n][a][j] = *reinterpret_cast<const u32x2*>(rowp + (((4 + j) << 4) ^ key));
+      }
+    }
+  }
   VFX_TS(5);  // conv1 done
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
   VFX_TS(6);
-  write_h(p.b1, hval);
+  if constexpr (DIRECT) write_h(p.b1, hval, std::integral_constant<int, 1>{});
+  else write_h(p.b1, hval, std::integral_constant<int, 0>{});
   VFX_TS(7);  // h written
   __syncthreads();  // h is complete
   VFX_TS(8);
   conv(prep2, NT1, 2 * NT1, PAIR);
   VFX_TS(9);  // conv2 done
-  __syncthreads();  // every wave is done with h
+  if constexpr (!DIRECT || PAIR) __syncthreads();  // every wave is done with h
   VFX_TS(10);
-  stage_acc();
-  __syncthreads();
+  if constexpr (!DIRECT) {
+    stage_acc();
+    __syncthreads();
+  }
   VFX_TS(11);  // staged
 
-  if constexpr (PAIR) {
+  if constexpr (PAIR && DIRECT) {
+    // ---- between the layers, DIRECT: y1 = conv2 (on top of x) + b2 stays in registers in accumulator layout; LeakyReLU(y1) becomes the
+    // second layer's operand rows (index m at patch row m + d2; zero outside the sequence and on the two indices of the tile where y1
+    // is not valid) -----------------------------------------------------------------------------------------------------------------
+    {
+      unsigned f16_sat = 0;
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const int ch = 2 * wn + n;
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *(const VFX_GLOBAL f32x4*)(p.b2 + ch * 32 + 8 * j + 4 * lh);
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+          const int m = wm * 64 + a * 32 + l31;
+          const bool ok = (m >= 1) & (m <= MT - 2) & ((unsigned)(base_h + m) < (unsigned)Tb);
+          const int row = m + d2;
+          char* rowp = lds + ch * PBYTES + row * CROW + 8 * lh;
+          const int key = swz_key(row);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = acc[n][a][4 * j + e] + bv[j][e];
+              y1[n][a][4 * j + e] = t;
+              acc[n][a][4 * j + e] = 0.f;
+              v[e] = ok ? fmaxf(t, t * slope) : 0.f;
+            }
+            *reinterpret_cast<uint2*>(rowp + ((j << 4) ^ key)) = make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
+          }
+        }
+      }
+      report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
+    }
+    __syncthreads();  // the second layer's operand rows are visible
+    bool hval2[WM];
+    int l31o = l31;
+    asm volatile("" : "+v"(l31o));
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const int m = wm * 64 + a * 32 + l31o;
+      hval2[a] = (m >= 1 + d2) & (m <= MT - 2 - d2) & ((unsigned)(base_h + m) < (unsigned)Tb);
+    }
+    conv(prep1, 2 * NT1, 3 * NT1, true);
+    __syncthreads();
+    write_h(p.b1b, hval2, std::integral_constant<int, 2>{});
+    __syncthreads();
+    conv(prep2, 3 * NT1, 4 * NT1, false);
+  }
+  if constexpr (PAIR && !DIRECT) {
     // ---- between the layers: y1 = conv2 + b2 + x replaces x in the residual registers; LeakyReLU(y1) becomes the operand patch ----
     // (index m at patch row m + d2; zero outside the sequence -- the second layer's zero padding -- and on the two indices of the
     // tile where y1 is not valid).  Every staged row is read before any operand row is written: the two images overlap.
@@ -414,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         for (int r = 0; r < 16; ++r) acc[n][a][r] = 0.f;
     conv(prep1, 2 * NT1, 3 * NT1, true);
     __syncthreads();
-    write_h(p.b1b, hval2);
+    write_h(p.b1b, hval2, std::integral_constant<int, 0>{});
     __syncthreads();
     conv(prep2, 3 * NT1, 4 * NT1, false);
     __syncthreads();
@@ -422,6 +512,66 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     __syncthreads();
   }
 
+  if constexpr (DIRECT) {
+    // ---- y = acc + b2 (the residual is inside the accumulators) straight to memory -----------------------------------------------------
+    const float* const b2p = PAIR ? p.b2b : p.b2;
+    const float aslope = p.act_slope;
+    unsigned ya_sat = 0;
+    constexpr unsigned kOob = 0xC0000000u;  // beyond every descriptor (tensors < 2 GiB as fp16), + 256 B does not wrap
+    const unsigned ybytes = (unsigned)((int64_t)p.B * T * C * 2);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y ? (int)ybytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(p.ya, 0, p.ya ? (int)ybytes : 0, 0x00020000);
+    const bool have_y = p.y != nullptr, have_ya = p.ya != nullptr;
+    int l31e = l31, lhe = lh;
+    asm volatile("" : "+v"(l31e), "+v"(lhe));  // the epilogue's index math stays behind the last conv2
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+      const int ch = 2 * wn + n;
+      f32x4 bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = *(const VFX_GLOBAL f32x4*)(b2p + ch * 32 + 8 * j + 4 * lhe);
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const int m = wm * 64 + a * 32 + l31e;
+        const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
+        const int pos = PAIR ? base_h + m : base_h + li * rowstride + lj;
+        const bool ok = PAIR ? ((m >= 2 + d2) & (m <= MT - 3 - d2) & ((unsigned)pos < (unsigned)Tb))
+                             : ((li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) & (!p.fold | (j0 + lj - 1 < d)));
+        const unsigned rowoff = ok ? (unsigned)(img * T + pos) * (unsigned)(C * 2) + (unsigned)(ch * 64 + 16 * lhe) : kOob;
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+          f32x4 v[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[r][e] = acc[n][a][4 * (jp + r) + e] + bv[jp + r][e];
+          // lanes 0-31 keep their run jp and receive the partner's run jp; lanes 32-63 receive the partner's run jp + 1 and keep theirs
+          if (have_y) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pack_f16x2(v[0][0], v[0][1], ya_sat), pack_f16x2(v[1][0], v[1][1], ya_sat), false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pack_f16x2(v[0][2], v[0][3], ya_sat), pack_f16x2(v[1][2], v[1][3], ya_sat), false, false);
+            const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+          }
+          if (have_ya) {  // last layer of the stack: also the activated fp16 form for the upsampler that follows
+            unsigned q2[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              f32x4 u;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) u[e] = fmaxf(v[r][e], v[r][e] * aslope);
+              q2[r][0] = pack_f16x2(u[0], u[1], ya_sat);
+              q2[r][1] = pack_f16x2(u[2], u[3], ya_sat);
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(q2[0][0], q2[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(q2[0][1], q2[1][1], false, false);
+            const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+          }
+        }
+      }
+    }
+    report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
+  } else
   // ---- y = conv2 + b2 + residual: whole staged rows read back, the kept rows (x; a pair: y1) added, stored --------------------------
   {
     const f32x4 bv = *(const VFX_GLOBAL f32x4*)((PAIR ? p.b2b : p.b2) + 4 * c4);
