@@ -70,8 +70,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   // value of conv2's accumulators, and the epilogue stores y straight from the accumulators (v_permlane32_swap pairs a lane's
   // 8-byte runs with its partner's into 16-byte stores, cf. resblock_w64.hip).  Per tile this removes 64 KB of staging writes and
   // reads, three of the five block barriers and the 32 residual registers; one block per CU owns the CU's LDS, so RX is free.
-  constexpr bool DIRECT = !PAIR && X16;
-  constexpr int RX = WL_OFF;                // DIRECT: raw fp16 rows of the tile's MT positions
+  // A PAIR has no room for a third region (145 KB with its weight fragments): its raw rows wait in R1, which is idle until the
+  // first h is written -- at the price of one barrier between "every wave has read its residual" and the first h write -- and the
+  // first layer's output y1 stays in 32 registers in accumulator layout: activated, it is written as the second layer's operand
+  // rows; raw, it is the initial value of the second conv2's accumulators.  7 block barriers per tile instead of 13.
+  constexpr bool DIRECT = X16;
+  constexpr int RX = PAIR ? R1 : WL_OFF;    // DIRECT: raw fp16 rows of the tile's MT positions
   constexpr int BIAS_OFF = PAIR ? WL_OFF + 3 * 24 * 1024 : (DIRECT ? WL_OFF + MT * ROWB : WL_OFF);  // b1 (pairs: b1, b2, second layer's b1, b2; DIRECT: b1, b2): C floats each
   static_assert(!PAIR || NW == 8, "pairs: 256-position tiles");
 
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   float* const b1s = reinterpret_cast<float*>(lds + BIAS_OFF);
   if (tid < C) b1s[tid] = ((const VFX_GLOBAL float*)p.b1)[tid];
   f32x4 b2v = *(const VFX_GLOBAL f32x4*)(p.b2 + 4 * cg);
-  if constexpr (DIRECT) {
+  if constexpr (DIRECT && !PAIR) {
     if (tid < C) b1s[C + tid] = ((const VFX_GLOBAL float*)p.b2)[tid];
   }
   if constexpr (PAIR) {
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   // batches of clips of unequal length (ResBlockParams::lens): the end of the CURRENT tile's clip, set per tile -- positions past it
   // read as zeros, h (and a pair's intermediate tensor) is zero there, nothing is stored there
   int Tb = T;
+  f32x16 y1r[WM];  // DIRECT pairs: the first layer's output in accumulator layout (the second layer's residual)
   f32x16 acc[WM];
 #pragma unroll
   for (int a = 0; a < WM; ++a)
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       unsigned sat16 = 0;
       const f16x2 slope2 = {(_Float16)slope, (_Float16)slope};
       u32x2 rres[WM][4];  // DIRECT: this lane's residual pieces (pixel m, channels wn * 32 + 8 j + 4 lh .. + 3) out of RX
-      if constexpr (DIRECT) {
+      if constexpr (DIRECT && !SECOND) {
 #pragma unroll
         for (int a = 0; a < WM; ++a) {
           const int m = (wm * WM + a) * 32 + l31_v;
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
 #pragma unroll
           for (int j = 0; j < 4; ++j) rres[a][j] = *reinterpret_cast<const u32x2*>(rowx + (((wn * 4 + j) ^ key) << 4));
         }
+        if constexpr (PAIR) __syncthreads();  // RX = R1 = the h buffer of this layer: every wave has its residual before any h is written
       }
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
@@ -291,10 +297,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
           // convert first, activate the packed halves (conv_common.h: pack_f16x2_sat16 / lrelu_f16x2)
           const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j] + b1v[0], acc[a][4 * j + 1] + b1v[1], hval, sat16), slope2);
           const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j + 2] + b1v[2], acc[a][4 * j + 3] + b1v[3], hval, sat16), slope2);
-          if constexpr (DIRECT) {  // conv2 accumulates on top of the residual
+          if constexpr (DIRECT && !SECOND) {  // conv2 accumulates on top of the residual
             const f32x4 v = f16x4_widen(rres[a][j]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = v[e];
+          } else if constexpr (DIRECT) {     // a pair's second layer: on top of y1
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = y1r[a][4 * j + e];
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = 0.f;
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
     // every wave is done with the patch and h: the staged accumulators may overlay them.  (DIRECT stages nothing: the next
     // tile's patch goes to R0 / RX, last read before this tile's "h is complete" barrier, and h is rewritten only behind the
     // next tile's "patch is complete" barrier, which no wave passes before every wave has left this conv2.)
-    if constexpr (!DIRECT) __syncthreads();
+    if constexpr (!DIRECT || PAIR) __syncthreads();
   };
   // the accumulators of rows [half * MT / NHALF, (half + 1) * MT / NHALF) to the staging rows (floats, over R0 (+ R1))
   auto stage = [&](int half) __attribute__((always_inline)) {
@@ -394,7 +403,35 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
 
     layer(std::false_type{}, arow1, base_h);
 
-    if constexpr (PAIR) {
+    if constexpr (PAIR && DIRECT) {
+      // ---- between the layers, DIRECT: y1 = acc (conv2 on top of x) + b2 stays in registers; LeakyReLU(y1) becomes the second layer's
+      // operand rows in R1 (index m at row m; zero outside the sequence and on the two indices where y1 is not valid) -------------------
+      unsigned sat = 0;
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const int m = (wm * WM + a) * 32 + l31_v;
+        const bool ok = (m >= 1) & (m <= MT - 2) & ((unsigned)(base_h + m) < (unsigned)Tb);
+        char* rowp = lds + R1 + m * ROWB + 8 * lh;
+        const int key = (m >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 b2a = *reinterpret_cast<const f32x4*>(b1s + C + wn * 32 + 8 * j + 4 * lh);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = acc[a][4 * j + e] + b2a[e];
+            y1r[a][4 * j + e] = t;
+            acc[a][4 * j + e] = 0.f;
+            v[e] = ok ? fmaxf(t, t * slope) : 0.f;
+          }
+          *reinterpret_cast<uint2*>(rowp + (((wn * 4 + j) ^ key) << 4)) = make_uint2(pack_f16x2(v[0], v[1], sat), pack_f16x2(v[2], v[3], sat));
+        }
+      }
+      report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
+      __syncthreads();  // the second patch is complete
+      layer(std::true_type{}, arow1, base_h);
+    }
+    if constexpr (PAIR && !DIRECT) {
       // ---- first layer's epilogue: y1 = conv2 + x + b2 stays on the CU -- as the second layer's residual (registers, same
       // thread -> row map) and, activated, as its patch (R1).  Index m of the tile = position base_h + m for BOTH layers: the
       // first layer's outputs are m = 1 .. MT-2, the second one's h is right for m = 1+d2 .. MT-2-d2, its outputs for
@@ -431,13 +468,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       unsigned sat = 0;
       f32x4 b2r[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b2r[j] = *reinterpret_cast<const f32x4*>(b1s + C + wn * 32 + 8 * j + 4 * lh);
+      for (int j = 0; j < 4; ++j) b2r[j] = *reinterpret_cast<const f32x4*>(b1s + (PAIR ? 3 * C : C) + wn * 32 + 8 * j + 4 * lh);
 #pragma unroll
       for (int a = 0; a < WM; ++a) {
         const int m = (wm * WM + a) * 32 + l31_v;
         const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
-        const int pos = base_h + li * rowstride + lj;
-        const bool ok = (li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) & (!p.fold | (j0 + lj - 1 < d));
+        const int pos = PAIR ? base_h + m : base_h + li * rowstride + lj;
+        const bool ok = PAIR ? ((m >= 2 + d2) & (m <= MT - 3 - d2) & ((unsigned)pos < (unsigned)Tb))
+                             : ((li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) & (!p.fold | (j0 + lj - 1 < d)));
 #pragma unroll
         for (int jp = 0; jp < 4; jp += 2) {
           f32x4 v[2];
