@@ -284,6 +284,13 @@ def measure_conv_roofline(eng, step, args, traffic, ms_step=None, steps=None):
                                  "frac_hbm": round(v[3] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                  "hbm_bytes_per_launch": ((traffic or {}).get("kernels", {}).get(k) or {}).get("bytes_per_launch")}
                              for k, v in sorted(per.items())},
+        # the next kernels by share of GPU time, each against the MFMA peak: after round 5 the top two groups are within 4 % of each
+        # other (k_conv<128> f16 = 25 heterogeneous launches -- the C = 512 stack, the upsamplers, the condnet; k_resblock<256, 4> f16
+        # = the eight C = 256 layers), so which one "dominates" can change from box to box
+        "runners_up": [{"kernel": k, "ms_per_step": round(v[1] / steps, 3), "avg_launch_us": round(v[1] * 1e3 / max(v[0], 1), 2),
+                        "frac_mfma": round(v[2] / (v[1] * 1e-3) / 1e12 / peak, 4),
+                        "hbm_bytes_per_launch": ((traffic or {}).get("kernels", {}).get(k) or {}).get("bytes_per_launch")}
+                       for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])[1:3]],
         "all_conv_ms_per_step": round(ms / steps, 3),
         "all_conv_algorithmic_gflop_per_step": round(fl / steps / 1e9, 1),
     }), step_line(fl / steps, ms_step, peak)
