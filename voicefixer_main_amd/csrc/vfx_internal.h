@@ -74,7 +74,7 @@ constexpr int kKC = 32;             // input channels per K step
 constexpr int kIdentityLen = 4096;  // length of the identity scale/shift tables
 constexpr int kPatchMaxRows = 192;
 constexpr int kMaxVarlenClips = 1024;  // clips per launch of a varlen batch (vfx_handle::d_lens)
-constexpr size_t kMaxCachedPlans = 8;  // per handle: a plan owns host + device parameter blocks (the eval handler's last
+constexpr size_t kMaxCachedPlans = 32; // per handle (round 5: 8 -> 32 -- a file with a target alternates between more than eight (stage, B, T) keys and rebuilt plans on every call; a plan is ~0.4 MB on each side); a plan owns host + device parameter blocks (the eval handler's last
                                         // segment has a new length for every file)  // patch pixels per stage (6 row groups of 32)
 
 enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_ELU = 2 };
