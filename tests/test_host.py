@@ -718,6 +718,32 @@ def test_upsampler_patches_get_an_even_width():
     assert m.window_cost(8, 16, 17, [(0, 0), (0, 1), (1, 0), (1, 1)], m.key_2d)[0] == 1.5   # what the odd width cost
 
 
+def test_wav_reader_device_path_gives_the_values_of_read(tmp_path, monkeypatch):
+    """handlers._WavReader.read_device (round 5): a mono PCM16 file travels as its 2-byte samples and is widened on the device --
+    the values are those of `read` / `load_wav` bit for bit (int16 -> float32 -> / 32768 is exact in both places), segment by
+    segment incl. the short last one and the read past the end; a stereo file takes the host path (numpy's channel mean)."""
+    from voicefixer_main_amd import handlers
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self: self)           # no accelerator here: pinning is a no-op
+    rng = np.random.default_rng(3)
+    x = (rng.normal(size=100001) * 0.3).astype(np.float32)
+    mono = str(tmp_path / "m.wav")
+    handlers.save_wave(x, mono)
+    a, b = handlers._WavReader(mono), handlers._WavReader(mono)
+    for n in (60000, 60000, 7):
+        want, got = a.read(n), b.read_device(n, "cpu")
+        assert got.dtype == torch.float32 and np.array_equal(want, got.numpy())
+    assert len(a) == len(b) == 100001
+    a.close(), b.close()
+    import wave
+    st = str(tmp_path / "s.wav")
+    with wave.open(st, "wb") as f:
+        f.setnchannels(2), f.setsampwidth(2), f.setframerate(44100)
+        f.writeframes((rng.integers(-3000, 3000, size=(5000, 2))).astype("<i2").tobytes())
+    a, b = handlers._WavReader(st), handlers._WavReader(st)
+    assert np.array_equal(a.read(4000), b.read_device(4000, "cpu").numpy()) and np.array_equal(a.read(4000), b.read_device(4000, "cpu").numpy())
+    a.close(), b.close()
+
+
 def test_tall_narrow_images_keep_windowed_stages():
     """The deep ResUNet levels of a LONG clip are tall narrow images (a 60-s segment: 376 x 7, 188 x 3, 94 x 1 pixels).  With
     128 / TW rows per tile no tile shape had an all-taps window inside the 192-row patch buffer and plan_conv fell back to one
