@@ -13,6 +13,9 @@
  *     all work is enqueued on it, no entry point synchronises the device except
  *     vfx_create / vfx_load_tensor / vfx_finalize_weights / vfx_reserve / vfx_take_flags;
  *   - the handle owns a copy of the weights and one workspace arena; it is NOT thread-safe;
+ *   - calls on DIFFERENT streams of one device (two handles, or one handle moved between streams) take turns on the GPU
+ *     timeline: the library does not let its own launches of two streams overlap (profiles/r05_two_streams.md); a call made
+ *     while its stream is being captured into a hipGraph is exempt;
  *   - every function returns 0 on success, non-zero on failure; vfx_last_error() then
  *     returns a human-readable message (thread-local).
  *   - T = L / hop + 1 frames (center=True framing); Tpad = 64*ceil(T/64).

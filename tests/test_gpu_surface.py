@@ -231,6 +231,38 @@ def test_restore_varlen_sub_batches_and_errors(engine, monkeypatch):
     engine.take_flags()
 
 
+def test_two_handles_on_two_streams_give_the_sequential_results(engine):
+    """Two handles of one device driven from two HIP streams, batches alternating between them with nothing waited for in between:
+    every output equals, bit for bit, what the first handle alone computes on one stream.  (Round 5: with the launches of the two
+    streams free to overlap, k_voc_final's sums went wrong in lanes 48-63 of single instructions whenever the other stream's 16-bit
+    MFMA convolutions ran beside it -- a few hundred samples per batch, 1e-4 .. 1e-2 off, in the 16-bit AND the split-bf16 mode;
+    profiles/r05_two_streams.md.  StreamTurn (csrc/vfx_internal.h) now makes calls on different streams take turns.)"""
+    from tests.conftest import _make_engine
+    from voicefixer_main_amd import synth
+    twin = _make_engine(engine.cfg.precision)
+    base = torch.from_numpy(synth.make_clips(6, 3.0, seed=31)[:, 0]).cuda()
+    wavs = [base[:, :60000 + 12000 * k].contiguous() for k in range(6)]
+    ref = [engine.restore_gsr(w) for w in wavs]
+    mels = [engine.stft(w)["mel"] for w in wavs]
+    ref_voc = [engine.vocoder(m) for m in mels]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    engines = [engine, twin]
+    for rep in range(3):
+        got, got_voc = [], []
+        torch.cuda.synchronize()
+        for i, w in enumerate(wavs):
+            with torch.cuda.stream(streams[i % 2]):
+                got.append(engines[i % 2].restore_gsr(w))
+            with torch.cuda.stream(streams[(i + 1) % 2]):       # the vocoder alone beside the other handle's full restore
+                got_voc.append(engines[(i + 1) % 2].vocoder(mels[i]))
+        torch.cuda.synchronize()
+        for i in range(len(wavs)):
+            assert torch.equal(got[i], ref[i]), (rep, i, int((got[i] != ref[i]).sum()))
+            assert torch.equal(got_voc[i], ref_voc[i]), (rep, i, int((got_voc[i] != ref_voc[i]).sum()))
+    assert engine.take_flags() & 3 == 0 and twin.take_flags() & 3 == 0
+
+
 def test_restore_list_buckets_by_padded_frames(voicefixer):
     """restore_list on clips of seven lengths in two padded-frame buckets: two calls of the library instead of seven, results
     equal to one `restore` per clip."""

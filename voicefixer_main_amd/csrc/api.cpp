@@ -464,6 +464,22 @@ void Plan::run(const RunCtx& ctx) {
     }
     return;
   }
+  if (const char* solo = getenv("VFX_SOLO_OPS")) {
+    // "lo:hi": ops lo .. hi-1 of every plan run with nothing else on the device (a device-wide wait before and after each) --
+    // bisects which launch is disturbed by work of another stream (scripts/two_streams_solo_ops.py)
+    // (VFX_SOLO_PLAN_OPS=n: only plans of exactly n ops, e.g. the victim's, so that the other stream's plans run freely)
+    int lo = 0, hi = 0;
+    const int only = debug_level("VFX_SOLO_PLAN_OPS");
+    if (sscanf(solo, "%d:%d", &lo, &hi) == 2 && (!only || (int)ops.size() == only)) {
+      for (size_t i = 0; i < ops.size(); ++i) {
+        const bool alone = (int)i >= lo && (int)i < hi;
+        if (alone) VFX_HIP(hipDeviceSynchronize());
+        ops[i](ctx);
+        if (alone) VFX_HIP(hipDeviceSynchronize());
+      }
+      return;
+    }
+  }
   for (auto& f : ops) f(ctx);
 }
 
@@ -784,6 +800,19 @@ void init_front_end(vfx_handle* h) {
   h->fe.voc_inv_weight = h->blob.upload(invw);
 }
 
+bool stream_turns_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VFX_NO_STREAM_TURNS");
+    return !(e && atoi(e) != 0);
+  }();
+  return on;
+}
+
+DeviceTurn& device_turn(int device) {
+  static DeviceTurn turns[64];
+  return turns[(unsigned)device % 64u];
+}
+
 }  // namespace vfx
 
 // =============================================================================================
@@ -794,6 +823,8 @@ using namespace vfx;
 #define VFX_API_BEGIN try {
 // entry points that take a handle: NULL check + run on the handle's device, restore the caller's on exit
 #define VFX_API_BEGIN_H(h) try { VFX_CHECK((h) != nullptr, "NULL handle"); ::vfx::DeviceGuard device_guard_((h)->device);
+// ... and launch on a caller's stream: they take turns with calls on other streams of the device (StreamTurn, vfx_internal.h)
+#define VFX_API_BEGIN_HS(h, stream) VFX_API_BEGIN_H(h) ::vfx::StreamTurn stream_turn_((h)->device, (stream));
 #define VFX_API_END                         \
   }                                         \
   catch (const vfx::Error&) { return 1; }   \
@@ -957,7 +988,7 @@ static int frames_of(const vfx_handle* h, int L) { return L / h->cfg.hop + 1; }
 
 int vfx_stft_mel(vfx_handle* h, const float* wav, int B, int L, float* mel, float* sp, float* cosp, float* sinp,
                  int log10_mel, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && wav, "NULL argument");
   VFX_CHECK(B > 0 && L > h->cfg.n_fft / 2, "vfx_stft_mel: need B > 0 and L > n_fft/2 (reflect padding), got B=%d L=%d", B, L);
   launch_stft_mel(h->fe, wav, B, L, frames_of(h, L), mel, sp, cosp, sinp, log10_mel, h->cfg.hop, 1e-8f,
@@ -967,7 +998,7 @@ int vfx_stft_mel(vfx_handle* h, const float* wav, int B, int L, float* mel, floa
 
 int vfx_stft_phase(vfx_handle* h, const float* wav, int B, int L, float* sp, float* cosp, float* sinp, float eps,
                    void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(wav && (sp || cosp || sinp), "NULL argument");
   VFX_CHECK(B > 0 && L > h->cfg.n_fft / 2, "vfx_stft_phase: need B > 0 and L > n_fft/2 (reflect padding), got B=%d L=%d", B, L);
   VFX_CHECK(eps >= 0.f, "vfx_stft_phase: eps must be >= 0 (got %g)", (double)eps);
@@ -977,14 +1008,14 @@ int vfx_stft_phase(vfx_handle* h, const float* wav, int B, int L, float* sp, flo
 }
 
 int vfx_mel_project(vfx_handle* h, const float* sp, int64_t rows, float* mel, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && sp && mel && rows > 0, "bad argument");
   launch_mel_project(h->fe, sp, rows, mel, static_cast<hipStream_t>(stream));
   VFX_API_END
 }
 
 int vfx_spectral_metrics(vfx_handle* h, const float* est, const float* target, int B, int T, int F, float* out, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && est && target && out && B > 0 && T > 0 && F > 0 && B <= 65535, "bad argument");
   // per-frame partial sums live in the arena (no plan is running concurrently: single stream, single thread)
   Plan tmp;
@@ -997,7 +1028,7 @@ int vfx_spectral_metrics(vfx_handle* h, const float* est, const float* target, i
 
 int vfx_chunk_gather(vfx_handle* h, const float* x, int B, int L, int win, int hop, int lead, int n_chunks,
                      float* chunks, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && x && chunks && B > 0 && L > 0 && win > 0 && hop > 0 && lead >= 0 && n_chunks > 0, "bad argument");
   VFX_CHECK(B <= 65535 && n_chunks <= 65535, "chunk grid too large");
   launch_chunk_gather(x, B, L, win, hop, lead, n_chunks, chunks, static_cast<hipStream_t>(stream));
@@ -1006,7 +1037,7 @@ int vfx_chunk_gather(vfx_handle* h, const float* x, int B, int L, int win, int h
 
 int vfx_chunk_ola(vfx_handle* h, const float* frames, const float* window, float scale, int B, int n_chunks, int win,
                   int hop, int lead, int L, float* y, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && frames && y && B > 0 && L > 0 && win > 0 && hop > 0 && lead >= 0 && n_chunks > 0, "bad argument");
   VFX_CHECK(B <= 65535, "batch too large");
   launch_chunk_ola(frames, window, scale, B, n_chunks, win, hop, lead, L, y, static_cast<hipStream_t>(stream));
@@ -1014,7 +1045,7 @@ int vfx_chunk_ola(vfx_handle* h, const float* frames, const float* window, float
 }
 
 int vfx_istft(vfx_handle* h, const float* re, const float* im, int B, int T, int L, float* wav, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && re && im && wav && B > 0 && T > 0 && L > 0, "bad argument");
   launch_istft(h->fe, re, im, B, T, L, h->cfg.hop, wav, static_cast<hipStream_t>(stream));
   VFX_API_END
@@ -1139,7 +1170,7 @@ int vfx_resunet_mel(vfx_handle* h, const float* mel_linear, int B, int T, float*
   return 0;
 }
 static int vfx_resunet_mel_1(vfx_handle* h, const float* mel_linear, int B, int T, float* logmel_out, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && mel_linear && logmel_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL], "vfx_resunet_mel: weights of the mel ResUNet are not finalized");
   auto plan = get_plan(h, key_of("unet_mel", B, T),
@@ -1166,7 +1197,7 @@ int vfx_resunet_spec(vfx_handle* h, const float* sp, const float* wav, int B, in
 }
 static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, int B, int T, int L, float* wav_out,
                               void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && sp && wav && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->unet[VFX_MODEL_UNET_SPEC], "vfx_resunet_spec: weights of the spectrogram ResUNet are not finalized");
   VFX_CHECK(T == frames_of(h, L), "vfx_resunet_spec: T=%d does not match L=%d (expected %d frames)", T, L, frames_of(h, L));
@@ -1209,7 +1240,7 @@ int vfx_vocoder(vfx_handle* h, const float* mel_linear, int B, int T, float* wav
   return 0;
 }
 static int vfx_vocoder_1(vfx_handle* h, const float* mel_linear, int B, int T, float* wav_out, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && mel_linear && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->voc, "vfx_vocoder: vocoder weights are not finalized");
   auto plan = get_plan(h, key_of("vocoder", B, T), [&](PlanBuilder& pb) { build_vocoder(pb, B, T, ext(0), ext(1)); }, stream);
@@ -1235,7 +1266,7 @@ int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_ou
 }
 static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, float* wav_out, float* logmel_out, int flags,
                              void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && wav && wav_out && B > 0, "bad argument");
   VFX_CHECK(L > h->cfg.n_fft / 2, "vfx_restore_gsr: clip too short for reflect padding (L=%d)", L);
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL] && h->voc, "vfx_restore_gsr: weights are not finalized");
@@ -1303,7 +1334,7 @@ int vfx_restore_gsr_varlen(vfx_handle* h, const float* wav, int B, int Lmax, con
 }
 static int vfx_restore_gsr_varlen_1(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out,
                                     float* logmel_out, int flags, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && wav && wav_out && lengths && B > 0 && B <= kMaxVarlenClips, "bad argument");
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL] && h->voc, "vfx_restore_gsr_varlen: weights are not finalized");
   const int hop = h->cfg.hop;
@@ -1378,7 +1409,7 @@ int vfx_restore_ssr_varlen(vfx_handle* h, const float* wav, int B, int Lmax, con
   return 0;
 }
 static int vfx_restore_ssr_varlen_1(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out, void* stream) {
-  VFX_API_BEGIN_H(h)
+  VFX_API_BEGIN_HS(h, stream)
   VFX_CHECK(h && wav && wav_out && lengths && B > 0 && B <= kMaxVarlenClips, "bad argument");
   VFX_CHECK(h->unet[VFX_MODEL_UNET_SPEC], "vfx_restore_ssr_varlen: weights of the spectrogram ResUNet are not finalized");
   const int hop = h->cfg.hop;

@@ -237,6 +237,26 @@ void launch_voc_prep(const float* mel, int B, int T, int Tp, const float* inv_we
 // lane and row piece), the 7 x C/8 taps of the lane sit in registers, and the 8 partial sums are
 // completed with three DPP-sized xor shuffles each.  One atomicMax per block for the peak.
 // ---------------------------------------------------------------------------------------------
+#ifdef VFX_VF_DEBUG
+// Round-5 investigation build (scripts/two_streams_registers.py): every sum is kept twice, in separate registers; lanes whose copies
+// differ -- before the group reduction (code 1) or after it (code 2) -- are logged here.
+__device__ unsigned g_vf_dbg[1 + 8 * 4096];
+extern "C" int vfx_debug_read_vf(unsigned* out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vf_dbg), sizeof(unsigned) * (size_t)n_words, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int vfx_debug_reset_vf() {
+  unsigned zero = 0;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_vf_dbg), &zero, sizeof(zero), 0, hipMemcpyHostToDevice);
+}
+__device__ __forceinline__ void vf_log(unsigned code, int o, float a, float b) {
+  const unsigned slot = atomicAdd(&g_vf_dbg[0], 1u);
+  if (slot < 4096u) {
+    unsigned* w = &g_vf_dbg[1 + 8 * slot];
+    w[0] = code; w[1] = blockIdx.x; w[2] = blockIdx.y; w[3] = threadIdx.x; w[4] = (unsigned)o;
+    w[5] = __float_as_uint(a); w[6] = __float_as_uint(b); w[7] = 0;
+  }
+}
+#endif
 template <int CPL, bool X16>  // channels per lane = C / 8 (4, 8 or 16); X16: x is the fp16 trunk of the 16-bit mode
 __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, int T, const float* __restrict__ w /*[7][C]*/,
                                                     float bias, float slope, float* __restrict__ wav,
@@ -264,6 +284,11 @@ __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, 
   float acc[8];
 #pragma unroll
   for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+#ifdef VFX_VF_DEBUG
+  float acc2[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc2[o] = 0.f;
+#endif
   if (t0 < T) {
 #pragma unroll
     for (int r = 0; r < 14; ++r) {  // input row t0 - 3 + r feeds output o with tap k = r - o
@@ -291,11 +316,25 @@ __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, 
         if (k >= 0 && k < 7) {
 #pragma unroll
           for (int c = 0; c < CPL; ++c) acc[o] = fmaf(v[c], wk[k][c], acc[o]);
+#ifdef VFX_VF_DEBUG
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            float vv = v[c];
+            asm volatile("" : "+v"(vv));
+            acc2[o] = fmaf(vv, wk[k][c], acc2[o]);
+          }
+#endif
         }
       }
     }
   }
   float mine = 0.f;  // lane g finishes output t0 + g
+#ifdef VFX_VF_DEBUG
+  float mine2 = 0.f;
+#pragma unroll
+  for (int o = 0; o < 8; ++o)
+    if (__float_as_uint(acc[o]) != __float_as_uint(acc2[o])) vf_log(1u, o, acc[o], acc2[o]);
+#endif
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
     float s = acc[o];
@@ -303,7 +342,18 @@ __global__ __launch_bounds__(256) void k_voc_final(const float* __restrict__ x, 
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 4);
     mine = g == o ? s : mine;
+#ifdef VFX_VF_DEBUG
+    float s2 = acc2[o];
+    asm volatile("" : "+v"(s2));
+    s2 += __shfl_xor(s2, 1);
+    s2 += __shfl_xor(s2, 2);
+    s2 += __shfl_xor(s2, 4);
+    mine2 = g == o ? s2 : mine2;
+#endif
   }
+#ifdef VFX_VF_DEBUG
+  if (__float_as_uint(mine) != __float_as_uint(mine2)) vf_log(2u, g, mine, mine2);
+#endif
   const int t = t0 + g;
   float m = 0.f;
   if (t < T) {

@@ -9,6 +9,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,6 +54,51 @@ struct DeviceGuard {
   }
   DeviceGuard(const DeviceGuard&) = delete;
   DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// Calls on DIFFERENT streams of one device take turns on the GPU timeline: a call on stream S first makes S wait for the end of
+// the previous call of this library on that device when that one ran on another stream, and leaves an event behind for the
+// next one.  Round 5 measured why (profiles/r05_two_streams.md): with two handles on two streams, k_voc_final -- plain VALU
+// arithmetic -- sharing the device with the other stream's 16-bit MFMA convolutions (fp16 or split-bf16 operands; the fp32
+// MFMA path does not do it) computed wrong sums in lanes 48-63 of single instructions, a few hundred samples per batch, off by
+// 1e-4 .. 1e-2; every launch is correct when nothing of another stream runs beside it.  The cause is below this library (the
+// same two plans on ONE stream, or with a device-wide wait between them, are bit-exact); until it is understood the library
+// does not let its own launches overlap across streams.  Costs one hipStreamIsCapturing + one hipEventRecord per call; a call
+// made while its stream is being captured into a hipGraph is left alone (an event of another stream cannot enter a capture).
+// Host threads: the mutex is held for the duration of the call, so calls on one device are enqueued one at a time.
+// VFX_NO_STREAM_TURNS=1 in the environment switches the turns off (the scripts that reproduce the measurement need the overlap).
+struct DeviceTurn {
+  std::mutex mu;
+  hipEvent_t done = nullptr;   // end of the last call on this device
+  hipStream_t last = nullptr;  // ... which ran on this stream
+  bool any = false;
+};
+DeviceTurn& device_turn(int device);  // api.cpp
+bool stream_turns_enabled();          // api.cpp
+struct StreamTurn {
+  DeviceTurn& d;
+  std::unique_lock<std::mutex> lock;
+  hipStream_t s;
+  bool active = false;
+  StreamTurn(int device, void* stream) : d(device_turn(device)), lock(d.mu), s(static_cast<hipStream_t>(stream)) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
+      (void)hipGetLastError();
+      cs = hipStreamCaptureStatusNone;
+    }
+    active = cs == hipStreamCaptureStatusNone && stream_turns_enabled();
+    if (active && d.any && d.last != s) VFX_HIP(hipStreamWaitEvent(s, d.done, 0));
+  }
+  ~StreamTurn() {
+    if (!active) return;
+    if (!d.done && hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return;
+    if (hipEventRecord(d.done, s) == hipSuccess) {
+      d.last = s;
+      d.any = true;
+    }
+  }
+  StreamTurn(const StreamTurn&) = delete;
+  StreamTurn& operator=(const StreamTurn&) = delete;
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: done once per (kernel, device).
