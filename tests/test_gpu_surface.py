@@ -239,8 +239,9 @@ def test_two_handles_on_two_streams_give_the_sequential_results(engine):
     profiles/r05_two_streams.md.  StreamTurn (csrc/vfx_internal.h) now makes calls on different streams take turns.)"""
     from tests.conftest import _make_engine
     from voicefixer_main_amd import synth
-    # two FRESH handles: the session's `engine` has had its weights reloaded through VoiceFixer.load_state_dict by then (the same
-    # tensors through another host path: last-bit differences in the folded weights, nothing to do with streams)
+    # two FRESH handles: the session's `engine` carries state other tests gave it -- the `voicefixer` fixture's MelScale registers
+    # the torch-evaluated mel filterbank (bit-identical to the reference's buffer) in place of the library's built-in table, a
+    # last-bit difference that reaches every sample and has nothing to do with streams
     engine, twin = _make_engine(engine.cfg.precision), _make_engine(engine.cfg.precision)
     base = torch.from_numpy(synth.make_clips(6, 3.0, seed=31)[:, 0]).cuda()
     wavs = [base[:, :60000 + 12000 * k].contiguous() for k in range(6)]
