@@ -235,7 +235,7 @@ def test_two_handles_on_two_streams_give_the_sequential_results(engine):
     """Two handles of one device driven from two HIP streams, batches alternating between them with nothing waited for in between:
     every output equals, bit for bit, what the first handle alone computes on one stream.  (Round 5: with the launches of the two
     streams free to overlap, k_voc_final's sums went wrong in lanes 48-63 of single instructions whenever the other stream's 16-bit
-    MFMA convolutions ran beside it -- a few hundred samples per batch, 1e-4 .. 1e-2 off, in the 16-bit AND the split-bf16 mode;
+    MFMA convolutions ran at the same time -- a few hundred samples per batch, 1e-4 .. 1e-2 off, in the 16-bit AND the split-bf16 mode;
     profiles/r05_two_streams.md.  StreamTurn (csrc/vfx_internal.h) now makes calls on different streams take turns.)"""
     from tests.conftest import _make_engine
     from voicefixer_main_amd import synth

@@ -377,6 +377,22 @@ void launch_voc_final(const float* x, int x_f16, int B, int T, int C, const floa
                       unsigned* peak, hipStream_t s, const int* lens, int hop) {
   const dim3 grid((T + 255) / 256, B);
   if (peak) VFX_HIP(hipMemsetAsync(peak, 0, sizeof(unsigned) * B, s));
+#ifdef VFX_VF_LDS
+  // investigation build (profiles/r05_two_streams.md): the C = 32 tail asks for VFX_VF_LDS bytes of dynamic LDS it never touches, so
+  // that no convolution block (>= 49 KB) fits on a CU beside it -- does the fault need the two kernels on ONE CU?
+  if (C == 32) {
+    static bool once = [] {
+      VFX_HIP(hipFuncSetAttribute((const void*)k_voc_final<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, VFX_VF_LDS));
+      VFX_HIP(hipFuncSetAttribute((const void*)k_voc_final<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VFX_VF_LDS));
+      return true;
+    }();
+    (void)once;
+    if (x_f16) hipLaunchKernelGGL((k_voc_final<4, true>), grid, dim3(256), VFX_VF_LDS, s, x, T, w, bias, slope, wav, peak, lens, hop);
+    else hipLaunchKernelGGL((k_voc_final<4, false>), grid, dim3(256), VFX_VF_LDS, s, x, T, w, bias, slope, wav, peak, lens, hop);
+    VFX_HIP(hipGetLastError());
+    return;
+  }
+#endif
   switch (C * 2 + (x_f16 ? 1 : 0)) {
     case 64: hipLaunchKernelGGL((k_voc_final<4, false>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak, lens, hop); break;
     case 65: hipLaunchKernelGGL((k_voc_final<4, true>), grid, dim3(256), 0, s, x, T, w, bias, slope, wav, peak, lens, hop); break;

@@ -59,9 +59,9 @@ struct DeviceGuard {
 // Calls on DIFFERENT streams of one device take turns on the GPU timeline: a call on stream S first makes S wait for the end of
 // the previous call of this library on that device when that one ran on another stream, and leaves an event behind for the
 // next one.  Round 5 measured why (profiles/r05_two_streams.md): with two handles on two streams, k_voc_final -- plain VALU
-// arithmetic -- sharing the device with the other stream's 16-bit MFMA convolutions (fp16 or split-bf16 operands; the fp32
-// MFMA path does not do it) computed wrong sums in lanes 48-63 of single instructions, a few hundred samples per batch, off by
-// 1e-4 .. 1e-2; every launch is correct when nothing of another stream runs beside it.  The cause is below this library (the
+// arithmetic -- running while the other stream's 16-bit MFMA convolutions do (fp16 or split-bf16 operands; the fp32 MFMA path
+// does not do it; sharing a CU is not required) computed wrong sums in lanes 48-63 of single instructions, a few hundred
+// samples per batch, off by 1e-4 .. 1e-2; every launch is correct when nothing of another stream runs beside it.  The cause is below this library (the
 // same two plans on ONE stream, or with a device-wide wait between them, are bit-exact); until it is understood the library
 // does not let its own launches overlap across streams.  Costs one hipStreamIsCapturing + one hipEventRecord per call; a call
 // made while its stream is being captured into a hipGraph is left alone (an event of another stream cannot enter a capture).
