@@ -248,6 +248,84 @@ extern "C" int vfx_debug_reset_vf() {
   unsigned zero = 0;
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_vf_dbg), &zero, sizeof(zero), 0, hipMemcpyHostToDevice);
 }
+// Synthetic co-runners for the other stream (scripts/two_streams_burners.py): what kind of work disturbs k_voc_final?
+//   0: 16-bit MFMAs on registers only (v_mfma_f32_32x32x16_bf16, four independent accumulators per wave), no memory traffic
+//   1: the same with fp32 MFMAs (v_mfma_f32_32x32x2f32)        2: VALU FMAs only
+//   3: 16-byte LDS-DMA reads of a buffer (buffer_load ... lds, the convolutions' patch path), no arithmetic
+template <int KIND>
+__global__ __launch_bounds__(256) void k_burn(int iters, const float* __restrict__ src, unsigned src_bytes, float* __restrict__ out) {
+  const int tid = threadIdx.x;
+  float keep = 0.f;
+  if constexpr (KIND == 0) {
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] = (__bf16)(1.0f + 0.001f * (float)((tid + e) & 31));
+      b[e] = (__bf16)(0.5f - 0.002f * (float)((tid * 3 + e) & 15));
+    }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) keep += c0[r] + c1[r] + c2[r] + c3[r];
+  } else if constexpr (KIND == 1) {
+    const float a = 1.0f + 0.001f * (float)(tid & 31), b = 0.5f - 0.002f * (float)(tid & 15);
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, c3, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) keep += c0[r] + c1[r] + c2[r] + c3[r];
+  } else if constexpr (KIND == 2) {
+    float x0 = 1.0f + 0.001f * (float)tid, x1 = 0.5f, x2 = 0.25f, x3 = 0.125f;
+    const float m = 0.999f, d = 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        x0 = fmaf(x0, x1, d);   // cross-coupled: no closed form for the compiler to fold the loop into
+        x1 = fmaf(x1, x2, m);
+        x2 = fmaf(x2, x3, d);
+        x3 = fmaf(x3, x0, m);
+      }
+    }
+    keep = x0 + x1 + x2 + x3;
+  } else {
+    extern __shared__ float burn_lds[];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)src_bytes, 0x00020000);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned off = ((unsigned)blockIdx.x * 4096u + (unsigned)tid * 16u) % (src_bytes - 65536u);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)((char*)burn_lds + (q * 4 + wave) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)(off + (unsigned)q * 8192u), 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+      off = (off + 1048576u + 49152u) % (src_bytes - 65536u);
+      off &= ~15u;
+    }
+    __syncthreads();
+    keep = burn_lds[tid];
+  }
+  if (keep == 12345.678f) out[tid] = keep;  // keeps the work live
+}
+extern "C" int vfx_debug_burn(int kind, int blocks, int iters, const float* src, unsigned src_bytes, float* out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(k_burn<0>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
+    case 1: hipLaunchKernelGGL(k_burn<1>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
+    case 2: hipLaunchKernelGGL(k_burn<2>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
+    default: hipLaunchKernelGGL(k_burn<3>, dim3(blocks), dim3(256), 24576, s, iters, src, src_bytes, out); break;
+  }
+  return (int)hipGetLastError();
+}
 __device__ __forceinline__ void vf_log(unsigned code, int o, float a, float b) {
   const unsigned slot = atomicAdd(&g_vf_dbg[0], 1u);
   if (slot < 4096u) {
