@@ -48,9 +48,11 @@ def main():
         lib.vfx_debug_read_vf(buf, 1)
         return int(buf[0])
 
-    names = {0: "16-bit MFMA, registers only", 1: "fp32 MFMA, registers only", 2: "VALU FMA only", 3: "16-byte LDS-DMA reads only"}
-    for blocks in (2048, 64):
-        for kind in (0, 1, 2, 3):
+    names = {0: "16-bit MFMA, registers only", 1: "fp32 MFMA, registers only", 2: "VALU FMA only", 3: "16-byte LDS-DMA reads only",
+             4: "sleeping waves (wave slots only)", 5: "sleeping waves with 52 KB of LDS per block"}
+    kinds = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5]
+    for blocks in (8192, 2048, 64):
+        for kind in kinds:
             iters = 2000                        # calibrate to ~ the victim's time per batch
             for _ in range(4):
                 torch.cuda.synchronize()

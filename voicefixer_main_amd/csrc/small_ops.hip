@@ -296,6 +296,11 @@ __global__ __launch_bounds__(256) void k_burn(int iters, const float* __restrict
       }
     }
     keep = x0 + x1 + x2 + x3;
+  } else if constexpr (KIND == 4) {
+    // occupies wave slots (KIND 4: nothing else; launched with 52 KB of LDS as kind 5: three blocks fill a CU's LDS like the
+    // convolutions do) and sleeps: no arithmetic, no memory traffic -- does the victim only have to WAIT for resources?
+    for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(64);
+    keep = (float)iters;
   } else {
     extern __shared__ float burn_lds[];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)src_bytes, 0x00020000);
@@ -322,7 +327,17 @@ extern "C" int vfx_debug_burn(int kind, int blocks, int iters, const float* src,
     case 0: hipLaunchKernelGGL(k_burn<0>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
     case 1: hipLaunchKernelGGL(k_burn<1>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
     case 2: hipLaunchKernelGGL(k_burn<2>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
-    default: hipLaunchKernelGGL(k_burn<3>, dim3(blocks), dim3(256), 24576, s, iters, src, src_bytes, out); break;
+    case 3: hipLaunchKernelGGL(k_burn<3>, dim3(blocks), dim3(256), 24576, s, iters, src, src_bytes, out); break;
+    case 4: hipLaunchKernelGGL(k_burn<4>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
+    default: {
+      static bool once = [] {
+        VFX_HIP(hipFuncSetAttribute((const void*)k_burn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 53248));
+        return true;
+      }();
+      (void)once;
+      hipLaunchKernelGGL(k_burn<4>, dim3(blocks), dim3(256), 53248, s, iters, src, src_bytes, out);
+      break;
+    }
   }
   return (int)hipGetLastError();
 }
