@@ -29,7 +29,7 @@ def main():
     wavs = [base[:, :100000 + 20000 * k].contiguous() for k in range(6)]
     mels = [ev.stft(w)["mel"] for w in wavs]
     ref = [ev.vocoder(m) for m in mels]
-    src = torch.randn((64 << 20) // 4, device=dev)
+    src = torch.randn((64 << 20) // 4, device=dev) * 0.01       # (kinds 7 and 8 write into it)
     out = torch.zeros(256, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -49,11 +49,13 @@ def main():
         return int(buf[0])
 
     names = {0: "16-bit MFMA, registers only", 1: "fp32 MFMA, registers only", 2: "VALU FMA only", 3: "16-byte LDS-DMA reads only",
-             4: "sleeping waves (wave slots only)", 5: "sleeping waves with 52 KB of LDS per block"}
-    kinds = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5]
+             4: "sleeping waves (wave slots only)", 5: "sleeping waves with 52 KB of LDS per block",
+             6: "10 000 different VALU instructions per loop (~100 KB of code)", 7: "16-byte streaming stores only",
+             8: "a convolution in miniature (LDS-DMA, barrier, 16-bit MFMAs from LDS, stores)"}
+    kinds = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6, 7, 8]
     for blocks in (8192, 2048, 64):
         for kind in kinds:
-            iters = 2000                        # calibrate to ~ the victim's time per batch
+            iters = 2000 if kind != 6 else 4    # calibrate to ~ the victim's time per batch
             for _ in range(4):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -62,7 +64,7 @@ def main():
                 ms = (time.perf_counter() - t0) * 1e3
                 if 0.6 * victim_ms < ms < 1.6 * victim_ms:
                     break
-                iters = max(50, int(iters * victim_ms / max(ms, 0.02)))
+                iters = max(50 if kind != 6 else 1, int(iters * victim_ms / max(ms, 0.02)))
             lib.vfx_debug_reset_vf()
             wrong = 0
             for _ in range(4):

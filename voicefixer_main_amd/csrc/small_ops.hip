@@ -252,6 +252,7 @@ extern "C" int vfx_debug_reset_vf() {
 //   0: 16-bit MFMAs on registers only (v_mfma_f32_32x32x16_bf16, four independent accumulators per wave), no memory traffic
 //   1: the same with fp32 MFMAs (v_mfma_f32_32x32x2f32)        2: VALU FMAs only
 //   3: 16-byte LDS-DMA reads of a buffer (buffer_load ... lds, the convolutions' patch path), no arithmetic
+typedef unsigned ce_u32x4_burn __attribute__((ext_vector_type(4)));
 template <int KIND>
 __global__ __launch_bounds__(256) void k_burn(int iters, const float* __restrict__ src, unsigned src_bytes, float* __restrict__ out) {
   const int tid = threadIdx.x;
@@ -296,6 +297,53 @@ __global__ __launch_bounds__(256) void k_burn(int iters, const float* __restrict
       }
     }
     keep = x0 + x1 + x2 + x3;
+  } else if constexpr (KIND == 6) {
+    // 10 000 different VALU instructions in a row (~100 KB of code): every CU running it keeps replacing the instruction cache
+    // lines it shares with its neighbours -- does the victim only have to MISS in the instruction cache?
+    float x0 = 1.0f + 0.001f * (float)tid, x1 = 0.999f;
+#define VFX_B1(i) x0 = fmaf(x0, x1, 1.0f + (float)(i) * 1.0e-6f);
+#define VFX_B10(b) VFX_B1(b) VFX_B1(b + 1) VFX_B1(b + 2) VFX_B1(b + 3) VFX_B1(b + 4) VFX_B1(b + 5) VFX_B1(b + 6) VFX_B1(b + 7) VFX_B1(b + 8) VFX_B1(b + 9)
+#define VFX_B100(b) VFX_B10(b) VFX_B10(b + 10) VFX_B10(b + 20) VFX_B10(b + 30) VFX_B10(b + 40) VFX_B10(b + 50) VFX_B10(b + 60) VFX_B10(b + 70) VFX_B10(b + 80) VFX_B10(b + 90)
+#define VFX_B1000(b) VFX_B100(b) VFX_B100(b + 100) VFX_B100(b + 200) VFX_B100(b + 300) VFX_B100(b + 400) VFX_B100(b + 500) VFX_B100(b + 600) VFX_B100(b + 700) VFX_B100(b + 800) VFX_B100(b + 900)
+    for (int i = 0; i < iters; ++i) {
+      VFX_B1000(0) VFX_B1000(1000) VFX_B1000(2000) VFX_B1000(3000) VFX_B1000(4000)
+      VFX_B1000(5000) VFX_B1000(6000) VFX_B1000(7000) VFX_B1000(8000) VFX_B1000(9000)
+      x1 = 0.999f + 1e-9f * x0;
+    }
+    keep = x0;
+  } else if constexpr (KIND == 7 || KIND == 8) {
+    // 7: 16-byte streaming stores only.  8: a convolution's loop in miniature -- LDS-DMA reads, a wait, a block barrier, 16-bit MFMAs
+    // on fragments read from LDS, 16-byte stores
+    extern __shared__ float burn_lds[];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)src_bytes, 0x00020000);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned off = ((unsigned)blockIdx.x * 4096u + (unsigned)tid * 16u) % (src_bytes - 65536u);
+    f32x16 c0 = {}, c1 = {};
+    f32x4 val = {1.0f + 0.001f * (float)tid, 2.0f, 3.0f, 4.0f};
+    for (int i = 0; i < iters; ++i) {
+      if constexpr (KIND == 8) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)((char*)burn_lds + (q * 4 + wave) * 1024);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, (int)(off + (unsigned)q * 8192u), 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>((const char*)burn_lds + t * 4096 + (tid & 255) * 16);
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>((const char*)burn_lds + t * 4096 + ((tid + 64) & 255) * 16);
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+        }
+        __syncthreads();
+        val[0] = c0[0] + c1[1];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ce_u32x4_burn, val), rsrc, (int)off, 0, 0);
+      off = (off + 1048576u + 49152u) % (src_bytes - 65536u);
+      off &= ~15u;
+    }
+    keep = c0[3] + c1[5] + val[1];
   } else if constexpr (KIND == 4) {
     // occupies wave slots (KIND 4: nothing else; launched with 52 KB of LDS as kind 5: three blocks fill a CU's LDS like the
     // convolutions do) and sleeps: no arithmetic, no memory traffic -- does the victim only have to WAIT for resources?
@@ -329,6 +377,9 @@ extern "C" int vfx_debug_burn(int kind, int blocks, int iters, const float* src,
     case 2: hipLaunchKernelGGL(k_burn<2>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
     case 3: hipLaunchKernelGGL(k_burn<3>, dim3(blocks), dim3(256), 24576, s, iters, src, src_bytes, out); break;
     case 4: hipLaunchKernelGGL(k_burn<4>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
+    case 6: hipLaunchKernelGGL(k_burn<6>, dim3(blocks), dim3(256), 0, s, iters, src, src_bytes, out); break;
+    case 7: hipLaunchKernelGGL(k_burn<7>, dim3(blocks), dim3(256), 24576, s, iters, src, src_bytes, out); break;
+    case 8: hipLaunchKernelGGL(k_burn<8>, dim3(blocks), dim3(256), 24576, s, iters, src, src_bytes, out); break;
     default: {
       static bool once = [] {
         VFX_HIP(hipFuncSetAttribute((const void*)k_burn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 53248));
