@@ -15,7 +15,8 @@
  *   - the handle owns a copy of the weights and one workspace arena; it is NOT thread-safe;
  *   - calls on DIFFERENT streams of one device (two handles, or one handle moved between streams) take turns on the GPU
  *     timeline: the library does not let its own launches of two streams overlap (profiles/r05_two_streams.md); a call made
- *     while its stream is being captured into a hipGraph is exempt;
+ *     while its stream is being captured into a hipGraph is exempt -- bracket the graph's replays with vfx_turn_begin /
+ *     vfx_turn_end when another stream of the device may run calls of this library at the same time;
  *   - every function returns 0 on success, non-zero on failure; vfx_last_error() then
  *     returns a human-readable message (thread-local).
  *   - T = L / hop + 1 frames (center=True framing); Tpad = 64*ceil(T/64).
@@ -62,9 +63,11 @@ enum {
   VFX_TUNE_F32_TRUNK = 64,         /* 16-bit mode: the residual trunk of the fused ResStacks (C = 64 / 128 / 256) travels as fp32
                                       between the layers (the round-3 form: 8 - 12 bytes per element and layer) instead of
                                       fp16 (4 bytes per element and layer; the sums themselves are fp32 in registers either way) */
-  VFX_TUNE_SMALL_2D_TILES = 128    /* fused ConvBlockRes of the ResUNets at C = 32: 8 x 16 / 16 x 8 h tiles (84 outputs per 128 positions)
+  VFX_TUNE_SMALL_2D_TILES = 128,   /* fused ConvBlockRes of the ResUNets at C = 32: 8 x 16 / 16 x 8 h tiles (84 outputs per 128 positions)
                                       instead of 16 x 16 (196 per 256); the entry block (Cin = 1) and the two-source block of that
                                       level, which exist on 16 x 16 tiles only, as two launches each */
+  VFX_TUNE_DEBUG_POISON_ARENA = 256 /* debug aid, no kernel selection: the handle's workspace arena is filled with NaN patterns when
+                                      it grows and before every call, so that a kernel reading a buffer nobody wrote shows up */
 };
 
 typedef struct vfx_config {
@@ -230,6 +233,17 @@ int vfx_spectral_metrics(vfx_handle* h, const float* est, const float* target, i
 int vfx_take_flags(vfx_handle* h, void* stream, int* flags_out);
 /* ... only the bits in `mask` (VFX_FLAG_*): the others stay raised for a later check. */
 int vfx_take_flags_masked(vfx_handle* h, void* stream, int mask, int* flags_out);
+
+/*
+ * Turns for work the library does not enqueue itself.  Calls of this library on different streams of one device take turns on
+ * the GPU timeline (see "Conventions"); a call made during a stream capture is exempt, so the REPLAY of a hipGraph captured
+ * from such calls must be bracketed by the caller when anything of this library may run on another stream of the device at
+ * the same time:  vfx_turn_begin(device, s); hipGraphLaunch(graph, s); vfx_turn_end(device, s);  (Engine.replay does this).
+ * begin makes `s` wait for the end of the device's previous turn, end leaves the event the next call waits for.  Not needed
+ * when everything of a process runs on one stream per device.
+ */
+int vfx_turn_begin(int device, void* stream);
+int vfx_turn_end(int device, void* stream);
 
 /*
  * Live kernel timing for the roofline report: between vfx_profile_begin and vfx_profile_end

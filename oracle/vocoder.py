@@ -31,7 +31,7 @@ State-dict key convention (mirrors nn.Sequential indexing of the package):
   generator.1.{weight,bias}                       first k7 conv
   generator.{3,6,9,12}.layer.{weight,bias}        transposed-conv upsamplers
   generator.{4,7,10,13}.res_layers.{i}.{1,3}.{weight,bias}
-  generator.16.{weight,bias}                      last k7 conv
+  generator.{3 n + 4}.{weight,bias}               last k7 conv (n stages; 16 for the table above)
 """
 from dataclasses import dataclass, field
 from typing import List
@@ -112,7 +112,8 @@ def generator(sd, cond, cfg=VocoderConfig()):
         x = _res_stack(sd, "generator.%d" % (idx + 1), x, depth, cfg)
         idx += 3
     x = F.leaky_relu(x, cfg.up_slope)
-    x = F.conv1d(F.pad(x, (3, 3), mode="reflect"), sd["generator.16.weight"], sd["generator.16.bias"])
+    last = "generator.%d" % (idx + 1)          # nn.Sequential indexing: activation at idx - 1, pad at idx, conv at idx + 1 (16 for 4 stages)
+    x = F.conv1d(F.pad(x, (3, 3), mode="reflect"), sd[last + ".weight"], sd[last + ".bias"])
     return torch.tanh(x)
 
 

@@ -50,6 +50,44 @@ def test_vocoder_vs_oracle(engine, voc_sd, B, T):
     assert np.abs(got - ref).max() < engine.tol['voc_max'], np.abs(got - ref).max()
 
 
+ALT_TABLES = {
+    # the recalled table is scales (7, 7, 3, 3), depth (8, 8, 8, 8), 1024 channels, condnet 5 x 512, dilations 3^i (synth.VocoderSpec)
+    "scales3737_depth4683": dict(upsample_scales=(3, 7, 3, 7), resstack_depth=(4, 6, 8, 3)),
+    "half_width_base2": dict(channels=512, cond_channels=256, cond_layers=3, upsample_scales=(7, 3, 7, 3), resstack_depth=(2, 3, 5, 8),
+                             dilation_base=2),
+    "three_stages_977": dict(channels=512, cond_channels=384, cond_layers=4, upsample_scales=(9, 7, 7), resstack_depth=(3, 5, 4)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ALT_TABLES))
+def test_vocoder_alternate_tables(engine, name):
+    """The vocoder's layer table is RECALLED (oracle/vocoder.py: parity unpinned), so the kernels must follow `vfx_config`, not be
+    specialised to the guess: the same plan builder on three other tables -- another scale order and other depths per stage; half
+    the width, a shorter condnet, dilations 2^i and a 32-channel tail; three stages with a stride of 9 -- against the oracle run
+    with the same table, in every arithmetic mode."""
+    from oracle import vocoder as voc
+    from voicefixer_main_amd import synth
+    from voicefixer_main_amd.engine import Engine, MODEL_VOCODER
+    t = ALT_TABLES[name]
+    spec = type("Spec", (synth.VocoderSpec,), dict(t))
+    ocfg = voc.VocoderConfig(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in t.items()})
+    n = len(spec.upsample_scales)
+    sd = synth.make_vocoder_state_dict(11, spec)
+    cfg = {"precision": engine.precision, "voc_channels": spec.channels, "voc_cond_channels": spec.cond_channels,
+           "voc_cond_layers": spec.cond_layers, "voc_n_stages": n, "voc_scales": list(spec.upsample_scales) + [0] * (8 - n),
+           "voc_depth": list(spec.resstack_depth) + [0] * (8 - n), "voc_dilation_base": spec.dilation_base}
+    eng = Engine("cuda:0", config=cfg)
+    eng.load_state_dict(MODEL_VOCODER, sd)
+    B, T = 2, 23
+    mel = _mel_input(B, T, seed=5)
+    ref = voc.vocoder(sd, torch.from_numpy(mel), ocfg).numpy()[:, 0]
+    got = eng.vocoder(torch.from_numpy(mel[:, 0])).cpu().numpy()
+    assert got.shape == ref.shape == (B, (T + T % 2 + 4) * 441)
+    assert np.abs(got - ref).max() < engine.tol['voc_max'], (name, np.abs(got - ref).max())
+    assert eng.take_flags() & 3 == 0
+    eng.close()
+
+
 def test_restore_gsr_vs_oracle(engine, unet_sd, voc_sd):
     from oracle import pipeline
     from voicefixer_main_amd import synth
@@ -66,12 +104,11 @@ def test_restore_gsr_vs_oracle(engine, unet_sd, voc_sd):
 
 
 def test_poisoned_arena_stays_finite(unet_sd, voc_sd, monkeypatch):
-    """The workspace arena is filled with NaN patterns before every plan run (VFX_POISON_ARENA=2): every stage must
+    """The workspace arena is filled with NaN patterns before every plan run (vfx_config.tuning & VFX_TUNE_DEBUG_POISON_ARENA): every stage must
     produce finite output, i.e. no kernel reads a workspace buffer before something wrote it."""
     from voicefixer_main_amd import synth
     from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER
-    monkeypatch.setenv("VFX_POISON_ARENA", "2")  # 2: re-poisoned before every plan run, whatever ran before
-    eng = Engine("cuda:0", config={"precision": 1})
+    eng = Engine("cuda:0", config={"precision": 1, "tuning": 256})   # re-poisoned before every plan run, whatever ran before
     eng.load_state_dict(MODEL_UNET_MEL, unet_sd)
     eng.load_state_dict(MODEL_VOCODER, voc_sd)
     eng.load_state_dict(MODEL_UNET_SPEC, synth.make_resunet_state_dict(2))
@@ -243,7 +280,8 @@ def test_fp16_vocoder_dynamic_range_flag_and_rerun(unet_sd, voc_sd):
 # vfx_config.tuning (include/vfx.h): every kernel-selection switch of the product path, exercised in process.  Each bit
 # replaces one kernel family by an older / simpler form of the same arithmetic; the results must stay within the mode's bars.
 TUNING = [("NO_FUSED_STACKS", 1, 2), ("NO_FUSED_WIDE", 2, 2), ("NO_FUSED_UNET", 4, 1), ("NO_PERSISTENT_C64", 8, 2),
-          ("NO_PAIRS", 16, 2), ("NO_SPLITK", 32, 1), ("F32_TRUNK", 64, 2), ("SMALL_2D_TILES", 128, 1), ("NO_FUSED_STACKS", 1, 1)]
+          ("NO_PAIRS", 16, 2), ("NO_SPLITK", 32, 1), ("F32_TRUNK", 64, 2), ("SMALL_2D_TILES", 128, 1), ("NO_FUSED_STACKS", 1, 1),
+          ("DEBUG_POISON_ARENA", 256, 2)]
 
 
 @pytest.mark.parametrize("name,bit,precision", TUNING, ids=["%s-p%d" % (n, p) for n, _, p in TUNING])

@@ -266,6 +266,48 @@ def test_two_handles_on_two_streams_give_the_sequential_results(engine):
     assert engine.take_flags() & 3 == 0 and twin.take_flags() & 3 == 0
 
 
+def test_graph_replay_takes_its_turn_beside_a_live_call_on_another_stream(engine):
+    """A hipGraph captured from one handle and replayed on stream A through Engine.replay (vfx_turn_begin / vfx_turn_end around the
+    replay) while a second handle makes live calls on stream B: every output equals the sequential one bit for bit.  A captured
+    call is exempt from the library's turns, so a bare graph.replay() beside another stream's calls would be exactly the overlap
+    round 5 found faulty ("Streams"); the bracket restores the rule."""
+    from tests.conftest import _make_engine
+    from voicefixer_main_amd import synth
+    e1, e2 = _make_engine(engine.cfg.precision), _make_engine(engine.cfg.precision)
+    base = torch.from_numpy(synth.make_clips(6, 3.0, seed=37)[:, 0]).cuda()
+    wav_g = base[:, :90000].contiguous()
+    live = [base[:, :60000 + 12000 * k].contiguous() for k in range(4)]
+    ref_g = e1.restore_gsr(wav_g).clone()
+    ref_live = [e2.restore_gsr(w).clone() for w in live]
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    out_g = torch.empty_like(wav_g)
+    graph = torch.cuda.CUDAGraph()
+    sa.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(sa):
+        e1.restore_gsr(wav_g, out=out_g)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=sa):
+            e1.restore_gsr(wav_g, out=out_g)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        got = []
+        for w in live:
+            with torch.cuda.stream(sa):
+                out_g.zero_()
+                e1.replay(graph)
+                g_now = out_g.clone()
+            with torch.cuda.stream(sb):
+                got.append(e2.restore_gsr(w))
+            with torch.cuda.stream(sa):
+                assert torch.equal(g_now, ref_g), (rep, int((g_now != ref_g).sum()))    # (synchronises stream A only)
+        torch.cuda.synchronize()
+        for i, w in enumerate(live):
+            assert torch.equal(got[i], ref_live[i]), (rep, i, int((got[i] != ref_live[i]).sum()))
+    assert e1.take_flags() & 3 == 0 and e2.take_flags() & 3 == 0
+    del graph
+    e1.unpin_plans()
+
+
 def test_restore_list_buckets_by_padded_frames(voicefixer):
     """restore_list on clips of seven lengths in two padded-frame buckets: two calls of the library instead of seven, results
     equal to one `restore` per clip."""

@@ -440,22 +440,28 @@ void finish_params(TapConvParams& p) {
 // ---------------------------------------------------------------------------------------------
 // plans
 // ---------------------------------------------------------------------------------------------
-// Debug hooks.  VFX_POISON_ARENA=2: the bytes of the arena the plan owns are set to NaN patterns before EVERY call, so
-// that a kernel reading a workspace buffer nobody wrote shows up whatever ran before.  VFX_DEBUG_NAN: after every
-// GEMM-shaped launch the outputs are scanned for non-finite values (synchronises; the first hit is reported on stderr).
-static int debug_level(const char* name) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : 0;
+// Debug hooks.  vfx_config.tuning & VFX_TUNE_DEBUG_POISON_ARENA (per handle): the bytes of the arena the plan owns are set to NaN
+// patterns before EVERY call (and when the arena grows), so that a kernel reading a workspace buffer nobody wrote shows up whatever
+// ran before.  VFX_DEBUG_NAN in the environment, read ONCE per process: after every GEMM-shaped launch the outputs are scanned for
+// non-finite values (synchronises; the first hit is reported on stderr).  Plan::run and the entry points do no getenv.
+struct DebugSwitches {
+  int debug_nan = 0;
+  DebugSwitches() {
+    if (const char* e = getenv("VFX_DEBUG_NAN")) debug_nan = atoi(e);
+  }
+};
+static const DebugSwitches& debug_switches() {
+  static const DebugSwitches s;
+  return s;
 }
-
 // Called by the entry points before anything of the call is staged in the arena.
-static void debug_poison(const Plan& plan, void* stream) {
-  if (debug_level("VFX_POISON_ARENA") >= 2 && plan.bound_base && plan.arena_bytes)
+static void debug_poison(const vfx_handle* h, const Plan& plan, void* stream) {
+  if ((h->cfg.tuning & VFX_TUNE_DEBUG_POISON_ARENA) && plan.bound_base && plan.arena_bytes)
     VFX_HIP(hipMemsetAsync(plan.bound_base, 0xFF, plan.arena_bytes, static_cast<hipStream_t>(stream)));
 }
 
 void Plan::run(const RunCtx& ctx) {
-  if (debug_level("VFX_DEBUG_NAN") >= 2 && bound_base && arena_bytes) {
+  if (debug_switches().debug_nan >= 2 && bound_base && arena_bytes) {
     // whole-arena scan after every op (tiny shapes only)
     for (size_t i = 0; i < ops.size(); ++i) {
       ops[i](ctx);
@@ -463,22 +469,6 @@ void Plan::run(const RunCtx& ctx) {
       fprintf(stderr, "[vfx debug] after op %zu of %zu: %lld non-finite floats in the arena\n", i, ops.size(), (long long)bad);
     }
     return;
-  }
-  if (const char* solo = getenv("VFX_SOLO_OPS")) {
-    // "lo:hi": ops lo .. hi-1 of every plan run with nothing else on the device (a device-wide wait before and after each) --
-    // bisects which launch is disturbed by work of another stream (scripts/two_streams_solo_ops.py)
-    // (VFX_SOLO_PLAN_OPS=n: only plans of exactly n ops, e.g. the victim's, so that the other stream's plans run freely)
-    int lo = 0, hi = 0;
-    const int only = debug_level("VFX_SOLO_PLAN_OPS");
-    if (sscanf(solo, "%d:%d", &lo, &hi) == 2 && (!only || (int)ops.size() == only)) {
-      for (size_t i = 0; i < ops.size(); ++i) {
-        const bool alone = (int)i >= lo && (int)i < hi;
-        if (alone) VFX_HIP(hipDeviceSynchronize());
-        ops[i](ctx);
-        if (alone) VFX_HIP(hipDeviceSynchronize());
-      }
-      return;
-    }
   }
   for (auto& f : ops) f(ctx);
 }
@@ -566,7 +556,7 @@ void PlanBuilder::add_conv(TapConvParams p) {
     } else {
       launch(pl->host_params[idx], pl->dev_params + idx, c.stream);
     }
-    if (debug_level("VFX_DEBUG_NAN")) {
+    if (debug_switches().debug_nan) {
       const TapConvParams& q = pl->host_params[idx];
       int K = 0;
       for (int s2 = 0; s2 < q.nseg; ++s2) K += q.seg[s2].ntaps * q.seg[s2].C;
@@ -635,7 +625,7 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
     } else {
       launch_resblock(hp, pl->dev_rb + idx, c.stream);
     }
-    if (debug_level("VFX_DEBUG_NAN") && hp.y && !hp.x16)
+    if (debug_switches().debug_nan && hp.y && !hp.x16)
       debug_scan(pl, "resblock y", idx, hp.y, (int64_t)hp.B * hp.T * hp.C, hp.B * hp.T, hp.C, 6 * hp.C, c.stream);
   });
 }
@@ -659,7 +649,7 @@ static char* ensure_arena(vfx_handle* h, size_t bytes) {
   VFX_HIP(hipMalloc(&p, want));
   // Debug aid (tests): a freshly grown arena is filled with NaN patterns, so that a kernel reading a
   // workspace buffer before anything wrote it shows up as NaN instead of silently using stale values.
-  if (getenv("VFX_POISON_ARENA")) VFX_HIP(hipMemset(p, 0xFF, want));
+  if (h->cfg.tuning & VFX_TUNE_DEBUG_POISON_ARENA) VFX_HIP(hipMemset(p, 0xFF, want));
   h->arena = static_cast<char*>(p);
   h->arena_bytes = want;
   return h->arena;
@@ -872,12 +862,12 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   h->device = device;
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
   VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
-  VFX_CHECK((h->cfg.tuning & ~255) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
+  VFX_CHECK((h->cfg.tuning & ~511) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
   if (h->cfg.tuning) {  // never silent: a non-default kernel selection is announced
     static const char* names[] = {"NO_FUSED_STACKS", "NO_FUSED_WIDE", "NO_FUSED_UNET", "NO_PERSISTENT_C64", "NO_PAIRS", "NO_SPLITK",
-                                  "F32_TRUNK", "SMALL_2D_TILES"};
+                                  "F32_TRUNK", "SMALL_2D_TILES", "DEBUG_POISON_ARENA"};
     std::string msg;
-    for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < 9; ++b)
       if (h->cfg.tuning & (1 << b)) msg += std::string(msg.empty() ? "" : " | ") + "VFX_TUNE_" + names[b];
     fprintf(stderr, "[libvfx] handle on device %d uses non-default kernel selection: tuning = 0x%x (%s)\n", device, h->cfg.tuning,
             msg.c_str());
@@ -978,6 +968,30 @@ int vfx_take_flags_masked(vfx_handle* h, void* stream, int mask, int* flags_out)
   VFX_HIP(hipStreamSynchronize(s));
   if (v & ~mask) launch_or_flags(h->d_flags, v & ~mask, s);  // in stream order, before anything the caller enqueues next
   *flags_out = v & mask;
+  VFX_API_END
+}
+
+// The two halves of a turn for work this library does not enqueue itself: the replay of a hipGraph captured from its calls
+// (a captured call is exempt from the turns, so its replay would otherwise overlap a live call of another stream).
+int vfx_turn_begin(int device, void* stream) {
+  VFX_API_BEGIN
+  DeviceGuard device_guard_(device);
+  if (stream_turns_enabled()) {
+    DeviceTurn& d = device_turn(device);
+    std::lock_guard<std::mutex> lock(d.mu);
+    turn_wait(d, static_cast<hipStream_t>(stream));
+  }
+  VFX_API_END
+}
+
+int vfx_turn_end(int device, void* stream) {
+  VFX_API_BEGIN
+  DeviceGuard device_guard_(device);
+  if (stream_turns_enabled()) {
+    DeviceTurn& d = device_turn(device);
+    std::lock_guard<std::mutex> lock(d.mu);
+    VFX_CHECK(turn_record(d, static_cast<hipStream_t>(stream)), "vfx_turn_end: cannot record the end of the turn on this stream");
+  }
   VFX_API_END
 }
 
@@ -1175,7 +1189,7 @@ static int vfx_resunet_mel_1(vfx_handle* h, const float* mel_linear, int B, int 
   VFX_CHECK(h->unet[VFX_MODEL_UNET_MEL], "vfx_resunet_mel: weights of the mel ResUNet are not finalized");
   auto plan = get_plan(h, key_of("unet_mel", B, T),
                        [&](PlanBuilder& pb) { build_unet_mel(pb, B, T, ext(0), ext(1)); }, stream);
-  debug_poison(*plan, stream);
+  debug_poison(h, *plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
@@ -1210,7 +1224,7 @@ static int vfx_resunet_spec_1(vfx_handle* h, const float* sp, const float* wav, 
     nm["im"] = pb.alloc_f(nsp);
     build_unet_spec(pb, B, T, ext(0), arena_buf(nm["cos"]), arena_buf(nm["sin"]), arena_buf(nm["re"]), arena_buf(nm["im"]));
   }, stream);
-  debug_poison(*plan, stream);
+  debug_poison(h, *plan, stream);
   const size_t off_cos = plan->named["cos"], off_sin = plan->named["sin"], off_re = plan->named["re"],
                off_im = plan->named["im"];
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1244,7 +1258,7 @@ static int vfx_vocoder_1(vfx_handle* h, const float* mel_linear, int B, int T, f
   VFX_CHECK(h && mel_linear && wav_out && B > 0 && T > 0, "bad argument");
   VFX_CHECK(h->voc, "vfx_vocoder: vocoder weights are not finalized");
   auto plan = get_plan(h, key_of("vocoder", B, T), [&](PlanBuilder& pb) { build_vocoder(pb, B, T, ext(0), ext(1)); }, stream);
-  debug_poison(*plan, stream);
+  debug_poison(h, *plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(mel_linear), wav_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
@@ -1302,7 +1316,7 @@ static int vfx_restore_gsr_1(vfx_handle* h, const float* wav, int B, int L, floa
                        reinterpret_cast<float*>(pl->bound_base + o_pk), /*have_peak=*/true, c.ext[1], c.stream, c.flags);
     });
   }, stream);
-  debug_poison(*plan, stream);
+  debug_poison(h, *plan, stream);
   RunCtx ctx{static_cast<hipStream_t>(stream), {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
@@ -1386,7 +1400,7 @@ static int vfx_restore_gsr_varlen_1(vfx_handle* h, const float* wav, int B, int 
                               reinterpret_cast<float*>(pl->bound_base + o_pk), c.ext[1], c.stream, c.flags);
     });
   }, stream);
-  debug_poison(*plan, stream);
+  debug_poison(h, *plan, stream);
   RunCtx ctx{s, {const_cast<float*>(wav), wav_out, logmel_out}, h->d_flags, &h->prof};
   plan->run(ctx);
   VFX_API_END
@@ -1446,7 +1460,7 @@ static int vfx_restore_ssr_varlen_1(vfx_handle* h, const float* wav, int B, int 
     });
     build_unet_spec(pb, B, T, arena_buf(o_sp), arena_buf(o_cos), arena_buf(o_sin), arena_buf(o_re), arena_buf(o_im));
   }, stream);
-  debug_poison(*plan, stream);
+  debug_poison(h, *plan, stream);
   RunCtx ctx{s, {const_cast<float*>(wav)}, h->d_flags, &h->prof};
   plan->run(ctx);
   launch_istft(h->fe, reinterpret_cast<float*>(h->arena + plan->named["re"]), reinterpret_cast<float*>(h->arena + plan->named["im"]), B, T,

@@ -56,25 +56,44 @@ struct DeviceGuard {
   DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
-// Calls on DIFFERENT streams of one device take turns on the GPU timeline: a call on stream S first makes S wait for the end of
-// the previous call of this library on that device when that one ran on another stream, and leaves an event behind for the
-// next one.  Round 5 measured why (profiles/r05_two_streams.md): with two handles on two streams, k_voc_final -- plain VALU
-// arithmetic -- running while the other stream's 16-bit MFMA convolutions do (fp16 or split-bf16 operands; the fp32 MFMA path
-// does not do it; sharing a CU is not required) computed wrong sums in lanes 48-63 of single instructions, a few hundred
-// samples per batch, off by 1e-4 .. 1e-2; every launch is correct when nothing of another stream runs beside it.  The cause is below this library (the
-// same two plans on ONE stream, or with a device-wide wait between them, are bit-exact); until it is understood the library
-// does not let its own launches overlap across streams.  Costs one hipStreamIsCapturing + one hipEventRecord per call; a call
-// made while its stream is being captured into a hipGraph is left alone (an event of another stream cannot enter a capture).
-// Host threads: the mutex is held for the duration of the call, so calls on one device are enqueued one at a time.
-// VFX_NO_STREAM_TURNS=1 in the environment switches the turns off (the scripts that reproduce the measurement need the overlap).
+// Calls on DIFFERENT streams of one device take turns on the GPU timeline: a call first makes its stream wait for the end of the
+// previous call of this library on that device and leaves an event behind for the next one.  Why (profiles/r05_two_streams.md,
+// profiles/r06_two_streams_xcd.md): with two handles on two streams, k_voc_final -- plain VALU arithmetic -- running while the
+// other stream's 16-bit MFMA convolutions of THIS library do (fp16 or split-bf16 operands; not the fp32 MFMA form, not torch's
+// hipBLASLt kernels, not any of eight synthetic co-runners; sharing a CU is not required) delivered wrong sums in lanes 48-63 of
+// single instructions, a few hundred samples per batch, off by 1e-4 .. 1e-2; every launch is correct when nothing of another
+// stream runs beside it.  What is KNOWN: the condition needs this library's hand-scheduled 16-bit convolution kernels on one
+// queue and a VALU-dense kernel on another; the same plans on ONE stream, or with a device-wide wait between them, are
+// bit-exact.  What is NOT known: the mechanism (an open issue; the aggressors are the kernels with inline-asm loads,
+// hand-counted vmcnt and LDS-DMA reads past the buffer bound, so a cause inside this library is not excluded).  Until it is, the
+// library does not let its own launches overlap across streams.
+//   * The wait is unconditional (an event of the stream's own past is free): no reliance on comparing stream handles, which a
+//     destroyed-and-reused stream address would defeat.
+//   * A call made while its stream is being CAPTURED into a hipGraph is left alone (an event of another stream cannot enter a
+//     capture); a REPLAY of such a graph is not a call of this library -- callers bracket it with vfx_turn_begin / vfx_turn_end
+//     (include/vfx.h; Engine.replay) or keep replays on the one stream everything else uses.
+//   * Host threads: the mutex is held for the duration of a call (the next call's wait needs this call's end event, which exists
+//     only once the call is enqueued), so calls on one device are ENQUEUED one at a time, plan builds included.  Handles are
+//     not thread-safe anyway; multi-threaded callers serialise on this lock per device.
+//   * Other PROCESSES on the same GPU are outside this guard: one process per GPU (dist.py) is the supported deployment.
+// VFX_NO_STREAM_TURNS=1 in the environment switches the turns off (scripts/two_streams_xcd.py needs the overlap it measures).
 struct DeviceTurn {
   std::mutex mu;
   hipEvent_t done = nullptr;   // end of the last call on this device
-  hipStream_t last = nullptr;  // ... which ran on this stream
   bool any = false;
 };
 DeviceTurn& device_turn(int device);  // api.cpp
 bool stream_turns_enabled();          // api.cpp
+// the two halves, also exported as vfx_turn_begin / vfx_turn_end (each takes the lock for its own bookkeeping only)
+inline void turn_wait(DeviceTurn& d, hipStream_t s) {
+  if (d.any) VFX_HIP(hipStreamWaitEvent(s, d.done, 0));
+}
+inline bool turn_record(DeviceTurn& d, hipStream_t s) {
+  if (!d.done && hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return false;
+  if (hipEventRecord(d.done, s) != hipSuccess) return false;
+  d.any = true;
+  return true;
+}
 struct StreamTurn {
   DeviceTurn& d;
   std::unique_lock<std::mutex> lock;
@@ -87,15 +106,10 @@ struct StreamTurn {
       cs = hipStreamCaptureStatusNone;
     }
     active = cs == hipStreamCaptureStatusNone && stream_turns_enabled();
-    if (active && d.any && d.last != s) VFX_HIP(hipStreamWaitEvent(s, d.done, 0));
+    if (active) turn_wait(d, s);
   }
   ~StreamTurn() {
-    if (!active) return;
-    if (!d.done && hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return;
-    if (hipEventRecord(d.done, s) == hipSuccess) {
-      d.last = s;
-      d.any = true;
-    }
+    if (active) (void)turn_record(d, s);
   }
   StreamTurn(const StreamTurn&) = delete;
   StreamTurn& operator=(const StreamTurn&) = delete;

@@ -133,6 +133,18 @@ class Engine:
         (a handle with a captured plan refuses to move its arena: reserve() the largest shape before capturing)."""
         _lib.check(self.lib.vfx_unpin_plans(self.h), "vfx_unpin_plans")
 
+    def replay(self, graph):
+        """Replay a torch.cuda.CUDAGraph captured from this engine's calls on the current stream, inside the device's turn:
+        captured calls are exempt from the library's one-stream-at-a-time rule (vfx.h, "Turns"), their replay is not a call of
+        the library -- this brackets it so that it cannot overlap a live call on another stream of the device."""
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        s = self._stream()
+        _lib.check(self.lib.vfx_turn_begin(idx, s), "vfx_turn_begin")
+        try:
+            graph.replay()
+        finally:
+            _lib.check(self.lib.vfx_turn_end(idx, s), "vfx_turn_end")
+
     def workspace_bytes(self, model, B, T):
         return int(self.lib.vfx_workspace_bytes(self.h, model, B, T))
 

@@ -137,7 +137,7 @@ def vocoder_layout(spec=VocoderSpec):
             out.append(("generator.%d.res_layers.%d.1" % (idx + 1, i), (c, c, 3)))
             out.append(("generator.%d.res_layers.%d.3" % (idx + 1, i), (c, c, 3)))
         idx += 3
-    out.append(("generator.16", (1, c, 7)))
+    out.append(("generator.%d" % (idx + 1), (1, c, 7)))      # 16 for four stages
     return out
 
 
@@ -153,7 +153,7 @@ def make_vocoder_state_dict(seed=1, spec=VocoderSpec):
         gain = 1.0
         if ".res_layers." in name and name.endswith(".3"):
             gain = 0.25
-        if name == "generator.16":
+        if shape[0] == 1:                     # the last k7 convolution
             gain = 0.35
         bound = gain * float(np.sqrt(3.0 / fan_in))
         sd[name + ".weight"] = (torch.rand(shape, generator=gen) * 2.0 - 1.0) * bound
