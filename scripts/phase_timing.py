@@ -15,6 +15,42 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+RW_STAMPS = {0: "tile start", 1: "wait for the prefetched patch + patch rows -> LDS", 2: "barrier (patch complete)", 3: "request next patch",
+             4: "conv1", 5: "residual read + h write", 6: "barrier (h complete)", 7: "conv2", 8: "y1 -> second patch + barrier",
+             9: "conv1 (second layer)", 10: "h write (second layer)", 11: "barrier", 12: "conv2 (second layer)", 13: "epilogue (direct stores issued)"}
+
+
+def rw_case(eng, buf, g, d, d2, out):
+    """The persistent C = 64 kernel (resblock_rw.hip): 8 waves per block, stamps per tile; single layer or pair."""
+    C, T, B = 64, 1006 * 441, 16
+    x = torch.randn((B, T, C), generator=g).cuda()
+    mk = lambda: ((torch.randn((C, C, 3), generator=g) * 0.05).numpy(), (torch.randn((C,), generator=g) * 0.1).numpy(),
+                  (torch.randn((C, C, 3), generator=g) * 0.05).numpy(), (torch.randn((C,), generator=g) * 0.1).numpy())
+    la, lb = mk(), mk()
+    call = (lambda: eng.op_resblock(x, la[0], la[1], la[2], la[3], d, 0.01, True)) if d2 is None else \
+        (lambda: eng.op_resblock_pair(x, la, d, lb, d2, 0.01))
+    call()
+    buf.zero_()
+    torch.cuda.synchronize()
+    call()
+    torch.cuda.synchronize()
+    ts = buf.cpu().numpy().astype(np.uint64).reshape(-1, 8, 16)
+    ts = ts[ts[:, 0, 13] != 0].astype(np.float64)
+    idx = [i for i in range(14) if ts[0, 0, i] != 0]
+    life = ts[:, :, 13] - ts[:, :, 0]
+    span = ts[:, :, 13].max() - ts[:, :, 0].min()
+    name = "C64_d%d" % d + ("" if d2 is None else "_%d" % d2)
+    res = {"tiles": int(ts.shape[0]), "mean_tile_cycles": float(life.mean()), "kernel_span_cycles": float(span), "phases": {}}
+    print("== C = 64, d = %s: %d tiles, tile time %.0f cycles (mean over waves), kernel span %.0f cycles = %.1f tiles per CU back to back" % (
+        d if d2 is None else (d, d2), ts.shape[0], life.mean(), span, span / life.mean()))
+    for a, b in zip(idx[:-1], idx[1:]):
+        v = float((ts[:, :, b] - ts[:, :, a]).mean())
+        vmax = float((ts[:, :, b] - ts[:, :, a]).max(axis=1).mean())
+        res["phases"]["%02d %s" % (b, RW_STAMPS[b])] = v
+        print("   %-52s %8.0f cycles  %5.1f %%   (slowest wave of a tile: %6.0f)" % (RW_STAMPS[b], v, 100.0 * v / life.mean(), vmax))
+    out[name] = res
+
+
 PHASES = ["setup+request", "patch wait", "transform", "barrier", "conv1", "barrier", "h write", "barrier", "conv2", "barrier",
           "stage / pass 0", "epilogue rest"]
 
@@ -27,7 +63,10 @@ def main():
     eng = Engine("cuda:0", config={"precision": 2})
     out = {}
     g = torch.Generator().manual_seed(0)
-    for C, T in ((256, 49294), (128, 147882)):
+    if "--c64" in sys.argv or "--only-c64" in sys.argv:
+        for d, d2 in ((1, None), (81, None), (243, None), (2187, None), (1, 3), (9, 27)):
+            rw_case(eng, buf, g, d, d2, out)
+    for C, T in (() if "--only-c64" in sys.argv else ((256, 49294), (128, 147882))):
         B = 16
         x = torch.randn((B, T, C), generator=g).cuda()
         w1, w2 = (torch.randn((C, C, 3), generator=g) * 0.05).numpy(), (torch.randn((C, C, 3), generator=g) * 0.05).numpy()

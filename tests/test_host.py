@@ -142,6 +142,104 @@ def test_handler_glue_matches_oracle_glue():
     assert float(handlers.sispec(est, est)) > 60
 
 
+def _stub_handler_run(monkeypatch, tmp_path, n_samples, truncate_to=None, oom_batches=0, seg=44100):
+    """handler_gsr_voicefixer's segment / break_point bookkeeping on the CPU: a stub model whose `vocoder` returns the segment it was
+    given with 2 x 882 samples of padding (trim_center crops them), a file writer without pinned memory.  The output file must
+    hold exactly the samples the reader delivered."""
+    import wave
+    from voicefixer_main_amd import handlers
+    rng = np.random.default_rng(n_samples)
+    pcm = rng.integers(-20000, 20000, size=n_samples, dtype=np.int16)
+    src, dst = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    with wave.open(src, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(44100)
+        f.writeframes(pcm.tobytes())
+    if truncate_to is not None:                      # the header keeps promising n_samples frames
+        raw = open(src, "rb").read()
+        open(src, "wb").write(raw[:44 + 2 * truncate_to])
+        pcm = pcm[:truncate_to]
+    calls = {"batches": [], "oom_left": oom_batches}
+
+    class Writer:
+        def __init__(self, fname, sample_rate=44100):
+            self.fname, self.parts = fname, []
+
+        def put(self, seg_):
+            self.parts.append((seg_.double() * 2 ** 15).to(torch.int32).to(torch.int16).numpy())
+
+        def flush(self, block=True):
+            pass
+
+        def close(self, ok=True):
+            if ok:
+                handlers.save_wave(np.concatenate(self.parts).astype(np.float64) / 2 ** 15, self.fname)
+
+    class FHelper:
+        def wav_to_spectrogram_phase(self, x):
+            model.last_x = x
+            T = x.shape[-1] // 441 + 1
+            return torch.ones((x.shape[0], 1, T, 1025)), None, None
+
+    class Model:
+        f_helper = FHelper()
+        engine = type("E", (), {"take_flags": staticmethod(lambda: 0)})()
+
+        def to(self, device):
+            return self
+
+        def mel(self, sp):                     # (B, 1, 1025, T) -> (B, 1, 128, T)
+            return sp[:, :, :128, :]
+
+        def __call__(self, mel, check=True):
+            calls["batches"].append(mel.shape[0])
+            if mel.shape[0] > 1 and calls["oom_left"] > 0:
+                calls["oom_left"] -= 1
+                raise RuntimeError("HIP out of memory. Tried to allocate 3.00 GiB")
+            return {"mel": handlers.to_log(mel)}
+
+        def vocoder(self, mel, check=True):
+            return torch.nn.functional.pad(self.last_x, (882, 882))
+
+    model = Model()
+    monkeypatch.setattr(handlers, "_WavWriter", Writer)
+    monkeypatch.setattr(handlers._WavReader, "read_device", lambda self, count, device: torch.from_numpy(np.ascontiguousarray(self.read(count))))
+    monkeypatch.setattr(handlers, "SEG_SECONDS", seg // 44100)     # 1-s segments instead of 60-s ones
+    monkeypatch.setitem(handlers._state, "model", model)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    handlers.handler_gsr_voicefixer(src, dst, None, "unused.ckpt", torch.device("cpu"))
+    got = np.frombuffer(wave.open(dst, "rb").readframes(10 ** 9), dtype="<i2")
+    return pcm, got, calls
+
+
+def test_handler_segment_batches_bookkeeping(monkeypatch, tmp_path):
+    """Without a target the handler runs the FULL segments of a file up to MAX_SEGMENT_BATCH at a time (handlers.py): 6.3 segments
+    are calls of 4, 2 and the 0.3-segment tail; every sample appears once, in order."""
+    pcm, got, calls = _stub_handler_run(monkeypatch, tmp_path, int(44100 * 6.3))
+    assert calls["batches"] == [4, 2, 1]
+    assert np.array_equal(pcm, got)
+    # exactly k full segments: no tail call
+    pcm, got, calls = _stub_handler_run(monkeypatch, tmp_path, 44100 * 5)
+    assert calls["batches"] == [4, 1] and np.array_equal(pcm, got)
+
+
+def test_handler_header_promises_more_frames_than_the_file_holds(monkeypatch, tmp_path):
+    """A truncated file (the header says 9.5 segments, the data chunk ends after 5.25): the batched reads come back short, the loop
+    ends at the real end of the data and the output holds exactly what was there."""
+    pcm, got, calls = _stub_handler_run(monkeypatch, tmp_path, int(44100 * 9.5), truncate_to=int(44100 * 5.25))
+    assert np.array_equal(pcm, got)
+    assert sum(calls["batches"][:2]) == 5 and calls["batches"][-1] == 1
+
+
+def test_handler_batched_segments_fall_back_on_out_of_memory(monkeypatch, tmp_path):
+    """A batch of segments that does not fit (RuntimeError: out of memory) is retried one segment per call -- the reference's own
+    loop -- instead of failing the file."""
+    pcm, got, calls = _stub_handler_run(monkeypatch, tmp_path, int(44100 * 6.3), oom_batches=1)
+    assert calls["batches"] == [4, 1, 1, 1, 1, 2, 1]
+    assert np.array_equal(pcm, got)
+
+
 def test_ssim_matches_the_skimage_algorithm():
     """handlers.ssim restates skimage.metrics.structural_similarity(win_size=7) (evaluation_proc/metrics.py:97-106;
     skimage is not installed): checked against the published algorithm written with scipy's uniform_filter."""

@@ -788,6 +788,9 @@ void plan_resblock(ResBlockParams& p) {
   // 16-bit mode, C = 64: the persistent register-weights kernel (resblock_rw.hip) with its own tile size
   p.rw = (!p.asrc && p.hionly && p.C == 64 && resblock_rw_tile(p.tuning) != 0) ? 1 : 0;
   if (p.rw) p.tile_m = resblock_rw_tile(p.tuning);
+#ifdef VFX_RW_SINGLE_MT
+  if (p.rw && p.dil2 == 0 && p.x16) p.tile_m = VFX_RW_SINGLE_MT;  // measurement builds: single layers on two 4-wave blocks per CU
+#endif
   const int MT = p.tile_m ? p.tile_m : CBM;  // h positions per tile (resblock_rw: 128 or 256)
   // patch rows per buffer: MT + 64 (= kPatchMaxRows for MT = 128); the 4-wave form of the wide layer keeps four chunk
   // buffers in half a CU's LDS: 160 rows (resblock_w64.hip)

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   // batches of clips of unequal length (ResBlockParams::lens): the end of the CURRENT tile's clip, set per tile -- positions past it
   // read as zeros, h (and a pair's intermediate tensor) is zero there, nothing is stored there
   int Tb = T;
+  VFX_TS_DECL;  // timing builds (-DVFX_TIMING, scripts/phase_timing.py): per tile and wave, s_memtime at the phase boundaries
   f32x16 y1r[WM];  // DIRECT pairs: the first layer's output in accumulator layout (the second layer's residual)
   f32x16 acc[WM];
 #pragma unroll
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         }
         mma_set(std::integral_constant<int, SECOND ? 2 : 0>{}, c, k, patch, rows);
       }
+    VFX_TS(SECOND ? 9 : 4);  // conv1 done
     // h = LeakyReLU(conv1 + b1) as fp16 operands, zero outside the sequence
     {
       unsigned sat16 = 0;
@@ -313,7 +315,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       }
       report_f16_saturation(f16_sat16_bad(sat16), p.flags);
     }
+    VFX_TS(SECOND ? 10 : 5);  // residual read, h written
     __syncthreads();  // h is complete
+    VFX_TS(SECOND ? 11 : 6);
     // conv2 from the resident h
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -350,6 +354,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   if (t_begin < t_end) request(t_begin);
   __syncthreads();  // the biases (and the fragments a pair keeps in LDS) are there
   for (int t = t_begin; t < t_end; ++t) {
+    VFX_TS(0);
     asm volatile("" : "+v"(lr_v), "+v"(l31_v));
     int img, j0, base_h;
     tile_geom(t, img, j0, base_h);
@@ -398,10 +403,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
       }
     }
+    VFX_TS(1);  // patch rows written
     __syncthreads();  // the patch is complete
+    VFX_TS(2);
     if (t + 1 < t_end) request(t + 1);  // lands while this tile is computed and stored
+    VFX_TS(3);  // next patch requested
 
     layer(std::false_type{}, arow1, base_h);
+    VFX_TS(7);  // first (only) layer: conv2 done
 
     if constexpr (PAIR && DIRECT) {
       // ---- between the layers, DIRECT: y1 = acc (conv2 on top of x) + b2 stays in registers; LeakyReLU(y1) becomes the second layer's
@@ -429,7 +438,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
       }
       report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
       __syncthreads();  // the second patch is complete
+      VFX_TS(8);  // y1 formed, second patch written, barrier passed
       layer(std::true_type{}, arow1, base_h);
+      VFX_TS(12);  // second layer: conv2 done
     }
     if constexpr (PAIR && !DIRECT) {
       // ---- first layer's epilogue: y1 = conv2 + x + b2 stays on the CU -- as the second layer's residual (registers, same
@@ -511,6 +522,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
         }
       }
       report_f16_saturation(f16_sat_bits_bad(sat), p.flags);
+      VFX_TS(13);  // stores issued
+      VFX_TS_FLUSH(p.timing, t, wave_u, NW);
     } else
     // ---- epilogue: y = conv2 + residual + b2 in the layout of the centre loads ----------------------------------------------
     {
@@ -619,6 +632,8 @@ void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams,
     if (hp.x16 && hp.patch_rows) launch_rw<8, false, true, 128>(dparams, ntiles, stream);
     else if (hp.x16) launch_rw<8, false, true>(dparams, ntiles, stream);
     else launch_rw<8, false, false>(dparams, ntiles, stream);
+  } else if (hp.tile_m == 128 && hp.x16 && !hp.patch_rows) {
+    launch_rw<4, false, true>(dparams, ntiles, stream);  // two 4-wave blocks per CU (measurement builds: -DVFX_RW_SINGLE_MT=128)
   } else VFX_CHECK(false, "resblock_rw: tile of %d positions", hp.tile_m);
   VFX_HIP(hipGetLastError());
 }

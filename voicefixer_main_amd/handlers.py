@@ -294,6 +294,11 @@ def _peak_normalise(out):
     return torch.where(peak > 1.0, out / peak, out), peak.max()
 
 
+def _is_out_of_memory(e):
+    m = str(e).lower()
+    return "out of memory" in m or "hipmalloc" in m or "hiperroroutofmemory" in m
+
+
 def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=False, meta={}):
     """eval_gsr_voicefixer.py:37-77.  Same calls on the model surface, in the same order, as the reference; what differs is
     WHEN the host waits: the reference's two host syncs per segment (to_log's assert inside the model call, the peak
@@ -333,9 +338,20 @@ def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=Fals
                 full = segment.shape[0] // seg_length if k > 1 else 0
                 pieces = ([segment[:full * seg_length].reshape(full, seg_length)] if full else []) + \
                          ([segment[full * seg_length:]] if segment.shape[0] > full * seg_length else [])
-                for piece in pieces:
-                    _, mel_noisy, seg_t = _pre(model, piece.contiguous(), device)
-                    out_model = model(mel_noisy, check=False)
+                queue = list(pieces)
+                while queue:
+                    piece = queue.pop(0)
+                    try:
+                        _, mel_noisy, seg_t = _pre(model, piece.contiguous(), device)
+                        out_model = model(mel_noisy, check=False)
+                    except RuntimeError as e:
+                        # a batch of full segments needs k times the workspace of one (about 0.8 GB per 60-s segment): on a
+                        # smaller or shared GPU fall back to the reference's one segment per call instead of failing the file
+                        if piece.dim() == 2 and piece.shape[0] > 1 and _is_out_of_memory(e):
+                            torch.cuda.empty_cache()
+                            queue = [piece[j:j + 1] for j in range(piece.shape[0])] + queue
+                            continue
+                        raise
                     denoised_mel = from_log(out_model["mel"])
                     if unify:
                         denoised_mel, mel_noisy = amp_to_original_f(mel_sp_est=denoised_mel, mel_sp_target=mel_noisy)
@@ -353,7 +369,15 @@ def handler_gsr_voicefixer(input, output, target, ckpt, device, needrefresh=Fals
                             _, m_lin = device_metrics(model.engine, from_log(out_model["mel"]).contiguous(), target_mel.contiguous())
                         metrics = {"mel-lsd": m_lsd, "mel-sispec": m_log, "mel-non-log-sispec": m_lin,
                                    "mel-ssim": float(ssim(denoised_mel, target_mel))}
-                    out = model.vocoder(denoised_mel, check=False)
+                    try:
+                        out = model.vocoder(denoised_mel, check=False)
+                    except RuntimeError as e:      # (the vocoder's workspace is the larger one: the same fallback)
+                        if piece.dim() == 2 and piece.shape[0] > 1 and _is_out_of_memory(e):
+                            del out_model, denoised_mel, mel_noisy
+                            torch.cuda.empty_cache()
+                            queue = [piece[j:j + 1] for j in range(piece.shape[0])] + queue
+                            continue
+                        raise
                     out, peak = _peak_normalise(out)
                     peaks.append(peak)
                     out, _ = trim_center(out, seg_t)
