@@ -75,7 +75,9 @@ struct DeviceGuard {
 //   * Host threads: the mutex is held for the duration of a call (the next call's wait needs this call's end event, which exists
 //     only once the call is enqueued), so calls on one device are ENQUEUED one at a time, plan builds included.  Handles are
 //     not thread-safe anyway; multi-threaded callers serialise on this lock per device.
-//   * Other PROCESSES on the same GPU are outside this guard: one process per GPU (dist.py) is the supported deployment.
+//   * Other PROCESSES on the same GPU are outside this guard -- and round 6 measured that a second process running this library's
+//     ResUNet disturbs this process's k_voc_final just the same (every batch wrong, RAS counters silent): one process per GPU
+//     (dist.py) is the supported deployment.
 // VFX_NO_STREAM_TURNS=1 in the environment switches the turns off (scripts/two_streams_xcd.py needs the overlap it measures).
 struct DeviceTurn {
   std::mutex mu;

@@ -47,6 +47,11 @@ bool stack_fused_wide(const vfx_config& cfg, int channels) {
   return !stack_fused(cfg, channels) && cfg.precision == 2 && resblock_w64_supported(channels) && !(cfg.tuning & VFX_TUNE_NO_FUSED_WIDE);
 }
 
+// An ACTIVATED tensor of the 16-bit mode is an fp16 tensor read in 64-channel stages (pack_conv mode 3, k_conv's H64 form): it exists
+// for channel counts that are multiples of 64 only.  A narrower tensor (a 32-channel stack of another layer table:
+// tests/test_gpu_models.py::test_vocoder_alternate_tables) stays raw fp32 and its consumers apply their prologues themselves.
+bool act_form_ok(const vfx_config& cfg, int channels) { return cfg.precision != 2 || channels % 64 == 0; }
+
 // Packing of the fused layers' weights: pack_mode(raw source)
 int fused_layer_mode(const vfx_config& cfg, int) { return pack_mode(cfg, false); }
 
@@ -117,7 +122,7 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
     up.cout = c / 2;
     // the upsampler reads the activated trunk, unless the stack in front of it is fused on the raw trunk only (in the
     // 16-bit mode the last fused layer also writes the activated fp16 form)
-    up.mode = pack_mode(cfg, st == 0 || !stack_fused(cfg, c) || cfg.precision == 2);
+    up.mode = pack_mode(cfg, (st == 0 || !stack_fused(cfg, c) || cfg.precision == 2) && act_form_ok(cfg, c));
     for (int r = 0; r < s; ++r) {
       std::vector<std::pair<int, int>> taps;
       for (auto& ek : phase_taps(s, pad, r)) taps.push_back({0, ek.second});
@@ -138,7 +143,7 @@ std::shared_ptr<VocoderWeights> build_vocoder_weights(vfx_handle* h) {
       snprintf(a, sizeof(a), "generator.%d.res_layers.%d.1", idx + 1, i);
       snprintf(b, sizeof(b), "generator.%d.res_layers.%d.3", idx + 1, i);
       // unfused layers read the activated trunk / the activated h; the fused kernel transforms raw patches itself
-      const bool act = !stack_fused(cfg, c);  // (mode 3 = the packing for activated sources)
+      const bool act = !stack_fused(cfg, c) && act_form_ok(cfg, c);  // (mode 3 = the packing for activated sources)
       stack.push_back({load_conv1d(h, a, c, c, 3, act), load_conv1d(h, b, c, c, 3, act)});
     }
     W->res.push_back(stack);
@@ -283,7 +288,8 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
     Forms y;
     if (t16 && fuse) y.raw = pb.alloc_f(act_floats(nel));
     else if (!t16) y.raw = pb.alloc_f(nel);
-    if (!fuse) y.act = pb.alloc_f(act_floats(nel));
+    const bool act_ok = act_form_ok(cfg, up.cout);  // (false: a 32-channel stack of the 16-bit mode -- raw fp32 tensors throughout)
+    if (!fuse && act_ok) y.act = pb.alloc_f(act_floats(nel));
     const bool up_src_act = cur.act != kNone;  // the producer already applied LeakyReLU(up_slope)
     VFX_CHECK(up.mode == pack_mode(cfg, up_src_act), "vocoder plan: upsampler %d is packed for another source form", st);
     {
@@ -305,7 +311,7 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         p.out_act = const_cast<float*>(rel_ptr(y.raw));  // fp16(y): LeakyReLU with slope 1
       } else {
         if (!t16) p.out = const_cast<float*>(rel_ptr(y.raw));
-        if (!fuse) {
+        if (!fuse && act_ok) {
           p.out_act = const_cast<float*>(rel_ptr(y.act));
           p.act_slope = cfg.voc_res_slope;
         }
@@ -427,6 +433,16 @@ void build_vocoder(PlanBuilder& pb, int B, int T, BufRef mel_linear, BufRef wav_
         rp.dil = dil;
         rp.hionly = 1;
         pb.add_resblock(rp);
+        free_forms(cur);
+        cur = y2;
+      } else if (!act_ok) {
+        // no activated form at this width: both convolutions read raw fp32 tensors through their own LeakyReLU prologue
+        const Forms hbuf = conv1d(layer.first, cur.raw, Tlen, 3, dil, ACT_LEAKY, cfg.voc_res_slope, false, nullptr,
+                                  /*src_act=*/false, /*want_raw=*/true, ACT_NONE, 1.f);
+        // (a following upsampler would read 32 channels: raw as well)
+        const Forms y2 = conv1d(layer.second, hbuf.raw, Tlen, 3, 1, ACT_LEAKY, cfg.voc_res_slope, false, &cur.raw,
+                                /*src_act=*/false, /*want_raw=*/true, ACT_NONE, 1.f);
+        free_forms(hbuf);
         free_forms(cur);
         cur = y2;
       } else {

@@ -120,7 +120,8 @@ def checked_restore(engine, **kw):
         if lengths is None or len(set(int(v) for v in lengths)) == 1 and int(lengths[0]) == x.shape[-1]:
             return engine.restore_gsr_checked(x, **kw)
         return engine.restore_gsr_varlen_checked(x, lengths, **kw)
-    fn.bucket_key = engine.padded_frames
+    # an engine that cannot run padded batches (Engine.supports_varlen: the 16-bit mode on the fp32 trunk) buckets by exact length
+    fn.bucket_key = engine.padded_frames if engine.supports_varlen() else (lambda L: int(L))
     return fn
 
 

@@ -278,6 +278,15 @@ class Engine:
         restore_gsr_varlen."""
         return -(-self.frames(L) // 64) * 64
 
+    def supports_varlen(self):
+        """False for the one configuration vfx_restore_gsr_varlen refuses: the 16-bit mode on the fp32 trunk (VFX_TUNE_F32_TRUNK, or
+        a ResStack slope outside (0, 1]) -- the persistent C = 64 kernel has no register left for a clip's length there.  Callers
+        that bucket clips (dist.checked_restore, VoiceFixer.restore_list) then batch EQUAL lengths only, as rounds 1-4 did."""
+        if self.precision != 2:
+            return True
+        slope = float(self.cfg.voc_res_slope)
+        return not (int(self.cfg.tuning) & _lib.TUNE_F32_TRUNK) and 0.0 < slope <= 1.0
+
     def restore_gsr_varlen(self, wav, lengths, unify_energy=False, want_logmel=False, out=None):
         """The handler() segment body for a batch of clips of UNEQUAL length: wav (B, Lmax), clip b = wav[b, :lengths[b]]
         -> restored (B, Lmax), zero past a clip's end.  Every clip gets what its own restore_gsr(wav[b:b+1, :lengths[b]])
