@@ -50,9 +50,11 @@ def main():
         k = (r["kernel"].replace(";", ","), int(r["Wi"]) if r["kernel"].startswith("k_resblock") else 0, int(r["M"]), int(r["Cout"]))
         per.setdefault(k, []).append((float(r["ms"]), float(r["tflops"])))
     stacks = collections.OrderedDict()
-    res = {"tag": tag, "precision": precision, "reps": reps, "checksum": float(out.double().abs().sum().item()),
+    import hashlib
+    sha = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]      # bit-identity of two builds on the same input
+    res = {"tag": tag, "precision": precision, "reps": reps, "checksum": float(out.double().abs().sum().item()), "sha256_16": sha,
            "finite": bool(torch.isfinite(out).all().item()), "flags": eng.take_flags(), "layers": []}
-    print("== %s (precision %d, %d reps) checksum %.6e finite %s" % (tag, precision, reps, res["checksum"], res["finite"]))
+    print("== %s (precision %d, %d reps) checksum %.9e sha256 %s finite %s" % (tag, precision, reps, res["checksum"], sha, res["finite"]))
     for (k, d, M, C), v in per.items():
         t = sorted(x[0] for x in v)
         med, mn = t[len(t) // 2], t[0]

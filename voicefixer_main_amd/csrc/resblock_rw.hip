@@ -575,6 +575,413 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_resblock_rw16 (round 6): the same layer / layer pair on the fp16 trunk (X16, DIRECT) with a tile loop that spends its
+// instructions on the tile.  The phase stamps of round 6 (profiles/r06_c2_phase_timing_c64_before.txt) and the instruction counts of
+// the loop body say what k_resblock_rw<.., X16> is bound by: ~1 830 instructions per tile and wave, 48 of them MFMAs, at ~8 cycles
+// each -- three integer divisions per tile_geom() (twice per tile), 22 instructions per 8-byte row piece of the patch request (a
+// multiply-shift division, two exec-mask save / restore pairs, a branch, 64-bit address arithmetic), twelve such pieces per
+// thread, exec-masked stores, the tile's geometry recomputed three times.  Two 4-wave blocks per CU instead of one 8-wave block
+// (profiles/r06_c2_voc_layers_rw_4wave_blocks_loser.txt) changed nothing: the waves are issue-bound, not latency-bound.  Here:
+//   * a thread's row piece is 16 bytes (8 channels; 8 lanes per 128-byte row): 4 + 1 (+ 1) loads per tile instead of 8 + 2 (+ 2),
+//     one ds_write_b128 per operand piece and one per raw piece;
+//   * the loads and stores go through buffer descriptors that cover exactly the tile's CLIP (base = clip, num_records = its own
+//     length): positions in front of / behind the clip are out of range -- zeros on loads, dropped stores -- with no compare, no
+//     exec mask and no branch; a load is v_add + buffer_load, its byte offset inside the patch a per-thread constant;
+//   * everything that depends on the lane only (patch row of an h pixel, its position offset, its output offset, the LDS
+//     addresses of the patch writes) is computed once per block;
+//   * the tile coordinates advance by increments (no division after the first tile);
+//   * a varlen batch reads the clip's length with a scalar load (the global load the compiler made of it waited vmcnt(0): for
+//     every store of the previous tile).
+// Same products, same sums, same rounding as k_resblock_rw<8, PAIR, true, HALO>: bit-identical results.
+template <bool PAIR, int HALO = 64>
+__global__ __launch_bounds__(512, 2) void k_resblock_rw16(const ResBlockParams* __restrict__ pp, int ntiles, int per_block) {
+  constexpr int C = 64, NW = 8, NTHR = NW * 64, WM = 2, MT = 256, PR = MT + HALO;
+  constexpr int RQ = NTHR / 8;              // rows per load group: 8 lanes x 16 bytes = one 128-byte row of the fp16 trunk
+  constexpr int NCQ = MT / RQ;              // centre loads per thread (4)
+  constexpr int NHQ = HALO / RQ;            // halo loads per thread (1 or 2)
+  constexpr int ROWB = 128;
+  constexpr int R0 = 0, R1 = PR * ROWB;
+  constexpr int WL_OFF = (PR + MT) * ROWB;
+  constexpr int RX = PAIR ? R1 : WL_OFF;    // raw fp16 rows of the tile's MT positions (a pair parks them in the idle h region)
+  constexpr int BIAS_OFF = PAIR ? WL_OFF + 3 * 24 * 1024 : WL_OFF + MT * ROWB;
+  constexpr unsigned kOob = 0x80000000u;    // beyond every descriptor of a clip (< 2^28 bytes), also after a tile's base is added
+  static_assert(HALO == 64 || (HALO == 128 && !PAIR), "the wide patch exists for single layers");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds = reinterpret_cast<char*>(smem);
+
+  const ResBlockParams& p = *pp;
+  const int tid = threadIdx.x;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int wm = wave_u >> 1, wn = wave_u & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int lr8 = tid >> 3, c8 = tid & 7;
+  const int T = p.T, d = p.dil, W1 = p.W1, TH = p.TH, PW = p.PW, P = p.P;
+  const int rowstride = p.fold ? d : 0;
+  const int tiles_w = p.tiles_w, tiles_h = p.tiles_h, TWo = p.TWo;
+  const float slope = p.slope;
+  const int d2 = p.dil2;
+  const int c0 = p.fold ? PW : d;  // patch row of h pixel 0
+
+  // ---- weights (as k_resblock_rw): this wave's 32 output channels, all taps, for the lifetime of the block ------------------------
+  f16x8 W[PAIR ? 1 : 2][2][3][2];
+  {
+    const int64_t ts = (int64_t)C * kKC;
+    const unsigned nb_off = (unsigned)(wn * 1024 + lane * 4) * 4u;
+#pragma unroll
+    for (int set = 0; set < (PAIR ? 4 : 2); ++set)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float* wt = set == 0 ? p.w1 : (set == 1 ? p.w2 : (set == 2 ? p.w1b : p.w2b));
+          const char* w = reinterpret_cast<const char*>(wt + (3 * c + k) * ts) + nb_off;
+          if (PAIR && set >= 1) {
+            if (wm == 0) {
+#pragma unroll
+              for (int s2 = 0; s2 < 2; ++s2)
+                *reinterpret_cast<f32x4*>(lds + WL_OFF + (((((set - 1) * 6 + 3 * c + k) * 2 + s2) * 2 + wn) << 10) + lane * 16) =
+                    *(const VFX_GLOBAL f32x4*)(w + 2048 * s2);
+            }
+          } else {
+            W[set][c][k][0] = __builtin_bit_cast(f16x8, *(const VFX_GLOBAL f32x4*)(w));
+            W[set][c][k][1] = __builtin_bit_cast(f16x8, *(const VFX_GLOBAL f32x4*)(w + 2048));
+          }
+        }
+  }
+  float* const b1s = reinterpret_cast<float*>(lds + BIAS_OFF);  // b1, b2 (pairs: + the second layer's b1, b2): C floats each
+  if (tid < C) {
+    b1s[tid] = ((const VFX_GLOBAL float*)p.b1)[tid];
+    b1s[C + tid] = ((const VFX_GLOBAL float*)p.b2)[tid];
+    if constexpr (PAIR) {
+      b1s[2 * C + tid] = ((const VFX_GLOBAL float*)p.b1b)[tid];
+      b1s[3 * C + tid] = ((const VFX_GLOBAL float*)p.b2b)[tid];
+    }
+  }
+
+  // ---- per-lane geometry, once per block -------------------------------------------------------------------------------------------
+  const unsigned inv_pw = ((1u << 20) + PW - 1) / PW, inv_w1 = ((1u << 20) + W1 - 1) / W1;  // rows < 512, divisors <= 320: exact
+  int arow1[WM];   // patch row of this lane's h pixel m = (wm WM + a) 32 + l31
+  int hrel[WM];    // its position relative to h pixel (0, 0); far negative when the tile's grid has no such pixel
+  int orel[WM];    // the same for an OUTPUT pixel (not on the grid's left / right edge); far negative otherwise
+  int ljt[WM];     // its column in the grid (the fold limit of the last tile column)
+#pragma unroll
+  for (int a = 0; a < WM; ++a) {
+    const int m = (wm * WM + a) * 32 + l31;
+    const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
+    arow1[a] = li < TH ? li * PW + lj : 0;
+    hrel[a] = li < TH ? li * rowstride + lj : -(1 << 29);
+    if constexpr (PAIR) orel[a] = (m >= 2 + d2 && m <= MT - 3 - d2) ? m : -(1 << 29);   // (pairs: index m = position base_h + m)
+    else orel[a] = (li < TH && lj >= 1 && lj <= W1 - 2) ? li * rowstride + lj : -(1 << 29);
+    ljt[a] = lj;
+  }
+  // the patch request of this thread: byte offset of its piece of patch row pr relative to the patch origin (kOob: no such row)
+  unsigned voff_tab[NCQ + NHQ];
+  int prow_h[NHQ];  // patch rows of the halo loads (the centre loads: lr8 + RQ q + c0)
+#pragma unroll
+  for (int q = 0; q < NCQ + NHQ; ++q) {
+    int pr;
+    if (q < NCQ) {
+      pr = lr8 + RQ * q + c0;
+    } else {
+      const int hr = lr8 + RQ * (q - NCQ);
+      pr = hr < c0 ? hr : hr + MT;
+      prow_h[q - NCQ] = pr;
+    }
+    const int pi = (int)(((unsigned)pr * inv_pw) >> 20);
+    const int rel = pi * rowstride + (pr - pi * PW);
+    voff_tab[q] = pr < P ? (unsigned)rel * (unsigned)(C * 2) + 16u * c8 : kOob;
+  }
+  // LDS addresses of the patch writes: the 16-byte piece c8 of row r sits at slot c8 ^ ((r >> 1) & 7); rows RQ apart share a key
+  const int wr_patch = R0 + (lr8 + c0) * ROWB + ((c8 ^ (((lr8 + c0) >> 1) & 7)) << 4);   // centre load q: + RQ q rows
+  const int wr_raw = RX + lr8 * ROWB + ((c8 ^ ((lr8 >> 1) & 7)) << 4);                  // its raw copy at h pixel lr8 + RQ q
+  int wr_halo[NHQ];
+#pragma unroll
+  for (int q = 0; q < NHQ; ++q) wr_halo[q] = R0 + prow_h[q] * ROWB + ((c8 ^ ((prow_h[q] >> 1) & 7)) << 4);
+
+  // ---- tile cursor: (img, ti, tj) of the current tile and of the next one, advanced by increments -------------------------------------
+  const int t_begin = blockIdx.x * per_block, t_end = min(t_begin + per_block, ntiles);
+  int img = 0, ti = 0, tj = 0;
+  if (t_begin < t_end) {
+    tj = t_begin % tiles_w;
+    const int r = t_begin / tiles_w;
+    ti = r % tiles_h;
+    img = r / tiles_h;
+  }
+  auto advance = [&](int& im, int& i, int& j) __attribute__((always_inline)) {
+    if (++j == tiles_w) {
+      j = 0;
+      if (++i == tiles_h) {
+        i = 0;
+        ++im;
+      }
+    }
+  };
+  auto base_of = [&](int i, int j) __attribute__((always_inline)) {  // position of h pixel 0 (pairs: of index 0)
+    const int j0 = j * TWo;
+    return PAIR ? j0 - 2 - d2 : (p.fold ? i * TH * d + j0 - 1 : j0 - 1);
+  };
+  auto clip_len = [&](int im) __attribute__((always_inline)) {  // a varlen batch: the end of clip `im` (scalar load)
+    return p.lens ? min(T, ((const VFX_CONST int*)p.lens)[im] * p.lens_mul) : T;
+  };
+
+  u32x4 PC[NCQ], PH[NHQ];  // the raw patch of the NEXT tile, in flight / landed
+  auto request = [&](int im, int i, int j) __attribute__((always_inline)) {
+    const int Tn = clip_len(im);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x) + (int64_t)im * T * (C * 2)), 0, Tn * (C * 2), 0x00020000);
+    const unsigned sbase = (unsigned)(base_of(i, j) - d) * (unsigned)(C * 2);  // patch origin (may be negative: wraps out of range)
+#pragma unroll
+    for (int q = 0; q < NCQ; ++q) PC[q] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(voff_tab[q] + sbase), 0, 0);
+#pragma unroll
+    for (int q = 0; q < NHQ; ++q) PH[q] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(voff_tab[NCQ + q] + sbase), 0, 0);
+  };
+  // 8 raw fp16 values -> LeakyReLU on the packed halves (max(x, slope x), 0 < slope <= 1)
+  auto lrelu8 = [&](const u32x4& r) __attribute__((always_inline)) {
+    const u32x2 a = f16x4_lrelu(u32x2{r[0], r[1]}, slope), b = f16x4_lrelu(u32x2{r[2], r[3]}, slope);
+    return u32x4{a.x, a.y, b.x, b.y};
+  };
+
+  int Tb = T;
+  VFX_TS_DECL;
+  f32x16 y1r[WM];
+  f32x16 acc[WM];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  auto mma = [&](const f16x8 (&w)[2], const char* img_base, const int (&row)[WM], int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f16x8 ah[WM];
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+        ah[a] = *reinterpret_cast<const f16x8*>(img_base + row[a] * ROWB + ((64 * c + 32 * s + 16 * lh) ^ swz_key(row[a])));
+#pragma unroll
+      for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], ah[a], acc[a], 0, 0, 0);
+    }
+  };
+  auto mma_set = [&](auto set_tag, int c, int k, const char* img_base, const int (&row)[WM]) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
+    if constexpr (PAIR && SET >= 1) {
+      f16x8 w[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        w[s2] = *reinterpret_cast<const f16x8*>(lds + WL_OFF + (((((SET - 1) * 6 + 3 * c + k) * 2 + s2) * 2 + wn) << 10) + lane * 16);
+      mma(w, img_base, row, c);
+    } else {
+      mma(W[SET][c][k], img_base, row, c);
+    }
+  };
+
+  // conv1 -> h -> conv2 of ONE layer over the index space of the tile (cf. k_resblock_rw); the accumulators hold conv2 on return
+  auto layer = [&](auto second_tag, int base_h) __attribute__((always_inline)) {
+    constexpr bool SECOND = decltype(second_tag)::value;
+    const char* patch = lds + (SECOND ? R1 : R0);
+    char* hbuf = lds + (SECOND ? R0 : R1);
+    const float* bias1 = b1s + (SECOND ? 2 * C : 0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        int rows[WM];
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+          if constexpr (SECOND) {
+            const int r = (wm * WM + a) * 32 + l31 + (k - 1) * d2;
+            rows[a] = r < 0 ? 0 : (r > MT - 1 ? MT - 1 : r);
+          } else {
+            rows[a] = arow1[a] + p.poff[k];
+          }
+        }
+        mma_set(std::integral_constant<int, SECOND ? 2 : 0>{}, c, k, patch, rows);
+      }
+    VFX_TS(SECOND ? 9 : 4);  // conv1 done
+    {
+      unsigned sat16 = 0;
+      const f16x2 slope2 = {(_Float16)slope, (_Float16)slope};
+      u32x2 rres[WM][4];
+      if constexpr (!SECOND) {
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+          const int m = (wm * WM + a) * 32 + l31;
+          const char* rowx = lds + RX + m * ROWB + 8 * lh;
+          const int key = (m >> 1) & 7;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rres[a][j] = *reinterpret_cast<const u32x2*>(rowx + (((wn * 4 + j) ^ key) << 4));
+        }
+        if constexpr (PAIR) __syncthreads();  // RX = R1 = the h buffer of this layer: every wave has its residual before any h is written
+      }
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const int m = (wm * WM + a) * 32 + l31;
+        const bool hval = (unsigned)(base_h + (SECOND ? m : hrel[a])) < (unsigned)Tb;
+        char* rowp = hbuf + m * ROWB + 8 * lh;
+        const int key = (m >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 b1v = *reinterpret_cast<const f32x4*>(bias1 + wn * 32 + 8 * j + 4 * lh);
+          const unsigned h01 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j] + b1v[0], acc[a][4 * j + 1] + b1v[1], hval, sat16), slope2);
+          const unsigned h23 = lrelu_f16x2(pack_f16x2_sat16(acc[a][4 * j + 2] + b1v[2], acc[a][4 * j + 3] + b1v[3], hval, sat16), slope2);
+          if constexpr (!SECOND) {  // conv2 accumulates on top of the residual
+            const f32x4 v = f16x4_widen(rres[a][j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = v[e];
+          } else {                  // a pair's second layer: on top of y1
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][4 * j + e] = y1r[a][4 * j + e];
+          }
+          *reinterpret_cast<uint2*>(rowp + (((wn * 4 + j) ^ key) << 4)) = make_uint2(h01, h23);
+        }
+      }
+      report_f16_saturation(f16_sat16_bad(sat16), p.flags);
+    }
+    VFX_TS(SECOND ? 10 : 5);  // residual read, h written
+    __syncthreads();  // h is complete
+    VFX_TS(SECOND ? 11 : 6);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        int rows[WM];
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+          const int r = (wm * WM + a) * 32 + l31 + k - 1;
+          rows[a] = r < 0 ? 0 : (r > MT - 1 ? MT - 1 : r);  // clamped rows only feed outputs that are masked anyway
+        }
+        mma_set(std::integral_constant<int, SECOND ? 3 : 1>{}, c, k, hbuf, rows);
+      }
+    if constexpr (PAIR) __syncthreads();  // (single layers: see k_resblock_rw -- the next patch write is ordered by the next tile's barriers)
+  };
+
+  if (t_begin < t_end) request(img, ti, tj);
+  __syncthreads();  // the biases (and the fragments a pair keeps in LDS) are there
+  for (int t = t_begin; t < t_end; ++t) {
+    VFX_TS(0);
+    const int base_h = base_of(ti, tj);
+    const int j0 = tj * TWo;
+    int nimg = img, nti = ti, ntj = tj;  // the next tile
+    advance(nimg, nti, ntj);
+    if (p.lens) {
+      Tb = clip_len(img);
+      if ((PAIR ? j0 : base_h + 1) >= Tb) {  // the tile lies wholly past the end of its clip: nothing to compute or store
+        if (t + 1 < t_end) request(nimg, nti, ntj);
+        img = nimg, ti = nti, tj = ntj;
+        continue;
+      }
+    }
+    // ---- the landed patch: to LDS as operands, its centre rows also raw (the residual) -------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < NCQ; ++q) {
+      *reinterpret_cast<u32x4*>(lds + wr_raw + q * RQ * ROWB) = PC[q];
+      *reinterpret_cast<u32x4*>(lds + wr_patch + q * RQ * ROWB) = lrelu8(PC[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NHQ; ++q) *reinterpret_cast<u32x4*>(lds + wr_halo[q]) = lrelu8(PH[q]);
+    VFX_TS(1);  // patch rows written
+    __syncthreads();  // the patch is complete
+    VFX_TS(2);
+    if (t + 1 < t_end) request(nimg, nti, ntj);  // lands while this tile is computed and stored
+    VFX_TS(3);  // next patch requested
+
+    layer(std::false_type{}, base_h);
+    VFX_TS(7);  // first (only) layer: conv2 done
+
+    if constexpr (PAIR) {
+      // ---- between the layers: y1 = acc (conv2 on top of x) + b2 stays in registers; LeakyReLU(y1) becomes the second layer's operand
+      // rows in R1 (index m at row m; zero outside the sequence and on the two indices where y1 is not valid) ---------------------------
+      unsigned sat16 = 0;
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const int m = (wm * WM + a) * 32 + l31;
+        const bool ok = (m >= 1) & (m <= MT - 2) & ((unsigned)(base_h + m) < (unsigned)Tb);
+        char* rowp = lds + R1 + m * ROWB + 8 * lh;
+        const int key = (m >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 b2a = *reinterpret_cast<const f32x4*>(b1s + C + wn * 32 + 8 * j + 4 * lh);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float tt = acc[a][4 * j + e] + b2a[e];
+            y1r[a][4 * j + e] = tt;
+            acc[a][4 * j + e] = 0.f;
+            v[e] = fmaxf(tt, tt * slope);
+          }
+          *reinterpret_cast<uint2*>(rowp + (((wn * 4 + j) ^ key) << 4)) =
+              make_uint2(pack_f16x2_sat16(v[0], v[1], ok, sat16), pack_f16x2_sat16(v[2], v[3], ok, sat16));
+        }
+      }
+      report_f16_saturation(f16_sat16_bad(sat16), p.flags);
+      __syncthreads();  // the second patch is complete
+      VFX_TS(8);
+      layer(std::true_type{}, base_h);
+      VFX_TS(12);  // second layer: conv2 done
+    }
+
+    // ---- epilogue: y = acc + b2 (the residual is inside the accumulators) straight to memory, through descriptors of the clip ------------
+    {
+      const int ybytes = Tb * (C * 2);
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+          p.y ? reinterpret_cast<char*>(p.y) + (int64_t)img * T * (C * 2) : nullptr, 0, p.y ? ybytes : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(
+          p.ya ? reinterpret_cast<char*>(p.ya) + (int64_t)img * T * (C * 2) : nullptr, 0, p.ya ? ybytes : 0, 0x00020000);
+      const bool have_y = p.y != nullptr, have_ya = p.ya != nullptr;
+      const float aslope = p.act_slope;
+      unsigned sat16 = 0;
+      f32x4 b2r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b2r[j] = *reinterpret_cast<const f32x4*>(b1s + (PAIR ? 3 * C : C) + wn * 32 + 8 * j + 4 * lh);
+      const unsigned lane_off = (unsigned)(wn * 64 + 16 * lh);
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        // an output pixel of the tile's grid, inside the row of d samples (folded tiles: the last tile column may stick out)
+        const bool ok = (orel[a] >= 0) & (PAIR | !p.fold | (j0 + ljt[a] - 1 < d));
+        const unsigned rowoff = ok ? (unsigned)(base_h + orel[a]) * (unsigned)(C * 2) + lane_off : kOob;  // (past the clip: out of range)
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+          f32x4 v[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[r][e] = acc[a][4 * (jp + r) + e] + b2r[jp + r][e];
+              acc[a][4 * (jp + r) + e] = 0.f;
+            }
+          // lanes 0-31 keep their run jp and receive the partner's run jp; lanes 32-63 receive the partner's run jp + 1 and keep theirs
+          if (have_y) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pack_f16x2_sat16(v[0][0], v[0][1], true, sat16), pack_f16x2_sat16(v[1][0], v[1][1], true, sat16), false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pack_f16x2_sat16(v[0][2], v[0][3], true, sat16), pack_f16x2_sat16(v[1][2], v[1][3], true, sat16), false, false);
+            const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+          }
+          if (have_ya) {  // last layer in front of an upsampler: ya = fp16(LeakyReLU(y, act_slope))
+            unsigned q2[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              f32x4 u;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) u[e] = fmaxf(v[r][e], v[r][e] * aslope);
+              q2[r][0] = pack_f16x2_sat16(u[0], u[1], true, sat16);
+              q2[r][1] = pack_f16x2_sat16(u[2], u[3], true, sat16);
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(q2[0][0], q2[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(q2[0][1], q2[1][1], false, false);
+            const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+          }
+        }
+      }
+      report_f16_saturation(f16_sat16_bad(sat16), p.flags);
+    }
+    VFX_TS(13);  // stores issued
+    VFX_TS_FLUSH(p.timing, t, wave_u, NW);
+    img = nimg, ti = nti, tj = ntj;
+  }
+}
+
 // h positions per tile of the register-weights kernel: 256; 0 = off (VFX_TUNE_NO_PERSISTENT_C64: k_resblock runs the layer)
 int resblock_rw_tile(int tuning) { return (tuning & VFX_TUNE_NO_PERSISTENT_C64) ? 0 : 256; }
 
@@ -598,6 +1005,22 @@ int cu_count_of_current_device() {
   return cus[dev];
 }
 
+template <bool PAIR, int HALO = 64>
+static void launch_rw16(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {
+  constexpr int MT = 256;
+  // the layout of k_resblock_rw<8, PAIR, true, HALO>: the two operand regions, the raw rows (singles: a third region), the biases,
+  // a pair's three sets of weight fragments
+  const size_t lds = (size_t)(MT + HALO + MT) * 128 + (PAIR ? (size_t)72 * 1024 + 4 * 64 * sizeof(float) : (size_t)MT * 128 + 2 * 64 * sizeof(float));
+  const int slots = cu_count_of_current_device();  // 256 registers per wave: one 8-wave block per CU
+  const int per_block = (int)((ntiles + slots - 1) / slots);
+  const int grid = (int)((ntiles + per_block - 1) / per_block);
+  static uint64_t attr_devices = 0;
+  if (first_use_on_current_device(attr_devices)) {
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_rw16<PAIR, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL((k_resblock_rw16<PAIR, HALO>), dim3(grid), dim3(512), lds, stream, dparams, (int)ntiles, per_block);
+}
+
 template <int NW, bool PAIR, bool X16, int HALO = 64>
 static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {
   constexpr int MT = NW * 32;
@@ -615,6 +1038,13 @@ static void launch_rw(const ResBlockParams* dparams, int64_t ntiles, hipStream_t
   hipLaunchKernelGGL((k_resblock_rw<NW, PAIR, X16, HALO>), dim3(grid), dim3(NW * 64), lds, stream, dparams, (int)ntiles, per_block);
 }
 
+// measurement builds (-DVFX_RW_OLD16): the fp16-trunk layers on k_resblock_rw<.., X16> as in round 5 (same-box A/B of k_resblock_rw16)
+#ifdef VFX_RW_OLD16
+constexpr bool kOldRw16 = true;
+#else
+constexpr bool kOldRw16 = false;
+#endif
+
 void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
   VFX_CHECK(hp.rw && hp.hionly && hp.C == 64 && !hp.geo2d && !hp.asrc, "resblock_rw: needs the 16-bit mode and C = 64");
   VFX_CHECK(!hp.lens || hp.x16, "resblock_rw: a batch of clips of unequal length needs the fp16 trunk of the 16-bit mode (not with "
@@ -625,11 +1055,14 @@ void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams,
   VFX_CHECK(!hp.x16 || (hp.slope > 0.f && hp.slope <= 1.f), "resblock_rw: the packed LeakyReLU of the fp16 trunk needs 0 < slope <= 1");
   if (hp.dil2 > 0) {
     VFX_CHECK(hp.tile_m == 256 && !hp.fold && hp.w1b && hp.w2b && hp.b1b && hp.b2b, "resblock_rw: bad layer pair");
-    if (hp.x16) launch_rw<8, true, true>(dparams, ntiles, stream);
+    if (hp.x16 && !kOldRw16) launch_rw16<true>(dparams, ntiles, stream);
+    else if (hp.x16) launch_rw<8, true, true>(dparams, ntiles, stream);
     else launch_rw<8, true, false>(dparams, ntiles, stream);
   } else if (hp.tile_m == 256) {
     VFX_CHECK(hp.patch_rows == 0 || (hp.patch_rows == 256 + 128 && hp.x16 && hp.fold), "resblock_rw: bad patch geometry");
-    if (hp.x16 && hp.patch_rows) launch_rw<8, false, true, 128>(dparams, ntiles, stream);
+    if (hp.x16 && hp.patch_rows && !kOldRw16) launch_rw16<false, 128>(dparams, ntiles, stream);
+    else if (hp.x16 && !kOldRw16) launch_rw16<false>(dparams, ntiles, stream);
+    else if (hp.x16 && hp.patch_rows) launch_rw<8, false, true, 128>(dparams, ntiles, stream);
     else if (hp.x16) launch_rw<8, false, true>(dparams, ntiles, stream);
     else launch_rw<8, false, false>(dparams, ntiles, stream);
   } else if (hp.tile_m == 128 && hp.x16 && !hp.patch_rows) {
