@@ -594,6 +594,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
 //   * a varlen batch reads the clip's length with a scalar load (the global load the compiler made of it waited vmcnt(0): for
 //     every store of the previous tile).
 // Same products, same sums, same rounding as k_resblock_rw<8, PAIR, true, HALO>: bit-identical results.
+// Measured and NOT kept (profiles/r06_c4_voc_layers_store_pairing_and_nt_losers.txt, same box, alternating): pairing the two 32-byte
+// pieces a lane pair holds of a row with those of the pixel 16 lanes away (v_permlane16_swap: two stores of 64 bytes of 16 rows each
+// instead of two of 32 bytes of all 32 rows) -- singles 2.34-2.38 -> 2.85 ms; the same with non-temporal stores (aux = 2): 2.95 ms.
 template <bool PAIR, int HALO = 64>
 __global__ __launch_bounds__(512, 2) void k_resblock_rw16(const ResBlockParams* __restrict__ pp, int ntiles, int per_block) {
   constexpr int C = 64, NW = 8, NTHR = NW * 64, WM = 2, MT = 256, PR = MT + HALO;
