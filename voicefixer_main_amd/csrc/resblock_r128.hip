@@ -187,14 +187,46 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
   const int rt = tid >> 5, ct = (tid >> 3) & 3, cgt = tid & 7;
   constexpr int NROW = PR / 8;      // rows per thread: 16 centre + 4 halo
   f32x4 keep[KEEP];
-  {
+  if constexpr (X16) {
+    // fp16 trunk (round 6): a thread's row piece is 16 bytes = 8 channels (16 lanes per 256-byte row), ten loads per thread instead of
+    // twenty, through a descriptor that covers exactly the tile's CLIP -- positions in front of / behind the clip are out of range
+    // and arrive as zeros, no compare per row -- and one ds_write_b128 per operand piece / raw piece (the phase stamps and
+    // instruction counts of round 6 say the block is bound by the instructions it issues: the request + transform of the 8-byte
+    // form were 530 VALU instructions per wave and tile).
+    const int rt16 = tid >> 4, c16 = tid & 15;
+    const int ct2 = c16 >> 2, pc = c16 & 3;  // 32-channel chunk, 16-byte piece inside the chunk's 64 bytes of operands
+    constexpr int NROW2 = PR / 16;           // 8 centre rows + 2 halo rows per thread
+    constexpr unsigned kOobL = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x) + (int64_t)img * T * (C * 2)), 0, Tb * (C * 2), 0x00020000);
+    int prow[NROW2];
+    u32x4 raw[NROW2];
+#pragma unroll
+    for (int j = 0; j < NROW2; ++j) {
+      const int hh = rt16 + 16 * (j - MT / 16);
+      prow[j] = j < MT / 16 ? rt16 + 16 * j + off : (hh < off ? hh : hh + MT);
+      const int pi = (int)(((unsigned)prow[j] * inv_pw) >> 20), pj = prow[j] - pi * PW;
+      const int pos = base_x + pi * rowstride + pj;
+      const unsigned o = prow[j] < P ? (unsigned)pos * (unsigned)(C * 2) + 16u * c16 : kOobL;
+      raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all ten loads are in flight before the first row is converted
+    VFX_TS(1);  // patch requested
+#pragma unroll
+    for (int j = 0; j < NROW2; ++j) {
+      const int key = (prow[j] >> 1) & 7;
+      const int at = ct2 * PBYTES + prow[j] * CROW + ((pc ^ key) << 4);
+      // DIRECT: the raw piece beside its operand form, logical piece 4 + pc of the same row (slot (4 + pc) ^ key = the operand's slot ^ 4)
+      if (j < MT / 16) *reinterpret_cast<u32x4*>(lds + (at ^ 64)) = raw[j];
+      const u32x2 lo = f16x4_lrelu(u32x2{raw[j][0], raw[j][1]}, slope), hi = f16x4_lrelu(u32x2{raw[j][2], raw[j][3]}, slope);
+      *reinterpret_cast<u32x4*>(lds + at) = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+  } else {
     unsigned f16_sat = 0;
-    constexpr unsigned EB = X16 ? 2u : 4u;  // bytes per element of x
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(unsigned)((int64_t)p.B * T * C * EB), 0x00020000);
-    const unsigned lane_off = (unsigned)(ct * 32 + cgt * 4) * EB;
-    typedef typename std::conditional<X16, u32x2, u32x4>::type raw_t;  // 4 channels of one row
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(unsigned)((int64_t)p.B * T * C * 4u), 0x00020000);
+    const unsigned lane_off = (unsigned)(ct * 32 + cgt * 4) * 4u;
     int prow[NROW];
-    raw_t raw[NROW];
+    u32x4 raw[NROW];
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
       const int hh = rt + 8 * (j - KEEP);
@@ -202,9 +234,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
       const int pi = (int)(((unsigned)prow[j] * inv_pw) >> 20), pj = prow[j] - pi * PW;
       const int pos = base_x + pi * rowstride + pj;
       const bool ok = (prow[j] < P) & ((unsigned)pos < (unsigned)Tb);
-      const unsigned o = ok ? (unsigned)(img * T + pos) * (unsigned)(C * EB) + lane_off : 0xfffffff0u;
-      if constexpr (X16) raw[j] = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)o, 0, 0);
-      else raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
+      const unsigned o = ok ? (unsigned)(img * T + pos) * (unsigned)(C * 4u) + lane_off : 0xfffffff0u;
+      raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // all twenty loads are in flight before the first row is converted
     VFX_TS(1);  // patch requested
@@ -212,21 +243,14 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     for (int j = 0; j < NROW; ++j) {
       const int key = (prow[j] >> 1) & 7;
       uint2* const dst = reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((cgt >> 1) ^ key) << 4) + 8 * (cgt & 1));
-      if constexpr (X16) {
-        if (j < KEEP)  // DIRECT: the raw piece beside its operand form, logical piece 4 + (cgt >> 1) of the same row
-          *reinterpret_cast<uint2*>(lds + ct * PBYTES + prow[j] * CROW + (((4 + (cgt >> 1)) ^ key) << 4) + 8 * (cgt & 1)) = make_uint2(raw[j].x, raw[j].y);
-        const u32x2 v = f16x4_lrelu(raw[j], slope);  // packed: v_pk_mul_f16, v_pk_max_f16
-        *dst = make_uint2(v.x, v.y);
-      } else {
-        const f32x4 r = __builtin_bit_cast(f32x4, raw[j]);
-        if (j < KEEP) keep[j] = r;
-        f32x4 v;
+      const f32x4 r = __builtin_bit_cast(f32x4, raw[j]);
+      if (j < KEEP) keep[j] = r;
+      f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(r[e], r[e] * slope);
-        *dst = make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
-      }
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(r[e], r[e] * slope);
+      *dst = make_uint2(pack_f16x2(v[0], v[1], f16_sat), pack_f16x2(v[2], v[3], f16_sat));
     }
-    if constexpr (!X16) report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
+    report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
   }
   VFX_TS(2);  // loaded and transformed
   VFX_TS(3);
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
       int r = second ? wm * 64 + a * 32 + l31 : arow1[a];
-      asm volatile("" : "+v"(r));  // per-tap addresses are recomputed, not kept
+      if constexpr (PAIR || !X16) asm volatile("" : "+v"(r));  // per-tap addresses are recomputed, not kept (single layers on the fp16 trunk have the registers: the six (tap, block) rows are computed once)
       const int row = r + (second ? k * d2 : (k == 0 ? poff0 : (k == 1 ? poff1 : poff2)));
       rb[g & 1][a] = c * PBYTES + row * CROW;
       kx[g & 1][a] = swz_key(row) ^ (16 * lh);
@@ -252,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     const int gl = g >= 3 * NT1 ? g - 3 * NT1 : g - NT1;
     const int c = gl / 3, k = gl % 3;
     int lrow = l31;
-    asm volatile("" : "+v"(lrow));
+    if constexpr (PAIR || !X16) asm volatile("" : "+v"(lrow));
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
       const int r0 = wm * 64 + a * 32 + lrow + k - 1;
@@ -516,11 +540,14 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     // ---- y = acc + b2 (the residual is inside the accumulators) straight to memory -----------------------------------------------------
     const float* const b2p = PAIR ? p.b2b : p.b2;
     const float aslope = p.act_slope;
-    unsigned ya_sat = 0;
-    constexpr unsigned kOob = 0xC0000000u;  // beyond every descriptor (tensors < 2 GiB as fp16), + 256 B does not wrap
-    const unsigned ybytes = (unsigned)((int64_t)p.B * T * C * 2);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y ? (int)ybytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(p.ya, 0, p.ya ? (int)ybytes : 0, 0x00020000);
+    unsigned sat16 = 0;
+    constexpr unsigned kOob = 0x80000000u;  // beyond every descriptor of a clip (< 2^28 bytes), + 256 B does not wrap
+    // descriptors of the tile's CLIP (round 6): positions past its own end are out of range -- their stores are dropped without a compare
+    const int ybytes = Tb * (C * 2);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        p.y ? reinterpret_cast<char*>(p.y) + (int64_t)img * T * (C * 2) : nullptr, 0, p.y ? ybytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc(
+        p.ya ? reinterpret_cast<char*>(p.ya) + (int64_t)img * T * (C * 2) : nullptr, 0, p.ya ? ybytes : 0, 0x00020000);
     const bool have_y = p.y != nullptr, have_ya = p.ya != nullptr;
     int l31e = l31, lhe = lh;
     asm volatile("" : "+v"(l31e), "+v"(lhe));  // the epilogue's index math stays behind the last conv2
@@ -535,9 +562,9 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         const int m = wm * 64 + a * 32 + l31e;
         const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
         const int pos = PAIR ? base_h + m : base_h + li * rowstride + lj;
-        const bool ok = PAIR ? ((m >= 2 + d2) & (m <= MT - 3 - d2) & ((unsigned)pos < (unsigned)Tb))
-                             : ((li < TH) & (lj >= 1) & (lj <= W1 - 2) & ((unsigned)pos < (unsigned)Tb) & (!p.fold | (j0 + lj - 1 < d)));
-        const unsigned rowoff = ok ? (unsigned)(img * T + pos) * (unsigned)(C * 2) + (unsigned)(ch * 64 + 16 * lhe) : kOob;
+        const bool ok = PAIR ? ((m >= 2 + d2) & (m <= MT - 3 - d2))
+                             : ((li < TH) & (lj >= 1) & (lj <= W1 - 2) & (!p.fold | (j0 + lj - 1 < d)));
+        const unsigned rowoff = ok ? (unsigned)pos * (unsigned)(C * 2) + (unsigned)(ch * 64 + 16 * lhe) : kOob;  // (ok: pos >= 0)
 #pragma unroll
         for (int jp = 0; jp < 4; jp += 2) {
           f32x4 v[2];
@@ -547,8 +574,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
             for (int e = 0; e < 4; ++e) v[r][e] = acc[n][a][4 * (jp + r) + e] + bv[jp + r][e];
           // lanes 0-31 keep their run jp and receive the partner's run jp; lanes 32-63 receive the partner's run jp + 1 and keep theirs
           if (have_y) {
-            const auto s0 = __builtin_amdgcn_permlane32_swap(pack_f16x2(v[0][0], v[0][1], ya_sat), pack_f16x2(v[1][0], v[1][1], ya_sat), false, false);
-            const auto s1 = __builtin_amdgcn_permlane32_swap(pack_f16x2(v[0][2], v[0][3], ya_sat), pack_f16x2(v[1][2], v[1][3], ya_sat), false, false);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pack_f16x2_sat16(v[0][0], v[0][1], true, sat16), pack_f16x2_sat16(v[1][0], v[1][1], true, sat16), false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pack_f16x2_sat16(v[0][2], v[0][3], true, sat16), pack_f16x2_sat16(v[1][2], v[1][3], true, sat16), false, false);
             const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
             __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
           }
@@ -559,8 +586,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
               f32x4 u;
 #pragma unroll
               for (int e = 0; e < 4; ++e) u[e] = fmaxf(v[r][e], v[r][e] * aslope);
-              q2[r][0] = pack_f16x2(u[0], u[1], ya_sat);
-              q2[r][1] = pack_f16x2(u[2], u[3], ya_sat);
+              q2[r][0] = pack_f16x2_sat16(u[0], u[1], true, sat16);
+              q2[r][1] = pack_f16x2_sat16(u[2], u[3], true, sat16);
             }
             const auto s0 = __builtin_amdgcn_permlane32_swap(q2[0][0], q2[1][0], false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(q2[0][1], q2[1][1], false, false);
@@ -570,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         }
       }
     }
-    report_f16_saturation(f16_sat_bits_bad(ya_sat), p.flags);
+    report_f16_saturation(f16_sat16_bad(sat16), p.flags);
   } else
   // ---- y = conv2 + b2 + residual: whole staged rows read back, the kept rows (x; a pair: y1) added, stored --------------------------
   {
