@@ -66,6 +66,8 @@ enum {
   VFX_TUNE_SMALL_2D_TILES = 128,   /* fused ConvBlockRes of the ResUNets at C = 32: 8 x 16 / 16 x 8 h tiles (84 outputs per 128 positions)
                                       instead of 16 x 16 (196 per 256); the entry block (Cin = 1) and the two-source block of that
                                       level, which exist on 16 x 16 tiles only, as two launches each */
+  VFX_TUNE_NO_FUSED_UPSAMPLERS = 512, /* 16-bit mode: the vocoder's ConvTranspose1d upsamplers as phased tap-convolution launches (one block per
+                                      tile, phase and cout range) instead of k_up16 (one block per tile of input positions, all phases) */
   VFX_TUNE_DEBUG_POISON_ARENA = 256 /* debug aid, no kernel selection: the handle's workspace arena is filled with NaN patterns when
                                       it grows and before every call, so that a kernel reading a buffer nobody wrote shows up */
 };

@@ -5,6 +5,7 @@ k_resblock<C, NW, HI>                  ->  "k_resblock<C, NW>"      (+ " f16")
 k_resblock_w64<C, X16>                 ->  "k_resblock<C, 4> f16"
 k_resblock_r128<PAIR, X16>             ->  "k_resblock<128, 4> f16" / "k_resblock_pair<128, 4> f16"
 k_resblock_rw<NW, PAIR, X16>           ->  "k_resblock<64, NW> f16" / "k_resblock_pair<64, NW> f16"
+k_resblock_rw16<PAIR, HALO>            ->  "k_resblock<64, 8> f16" / "k_resblock_pair<64, 8> f16"
 (X16 = the fp16 trunk of round 4: same rows of the tables, the bench line's `dtype` names the trunk format)
 """
 import re
@@ -26,6 +27,8 @@ def short(n, width=40):
         if len(args) >= 2 and args[1] == "true":         # two layers per launch
             return "k_resblock_pair<64, %s> f16" % args[0]
         return "k_resblock<64, %s> f16" % args[0]
+    if name == "k_resblock_rw16":                        # round 6: the same kernel with the lean tile loop (fp16 trunk); <PAIR, HALO>
+        return "k_resblock_pair<64, 8> f16" if args and args[0] == "true" else "k_resblock<64, 8> f16"
     if name == "k_resblock" and len(args) >= 2:
         hi = len(args) >= 3 and args[2] == "true"
         return "k_resblock<%s, %s>%s" % (args[0], args[1], " f16" if hi else "")

@@ -62,6 +62,8 @@ def main():
         if k.startswith("k_resblock"):
             print("  %-34s d=%-5d x%d  median %.4f ms  min %.4f  (%.0f TF)" % (k, d, calls, med, mn, sorted(x[1] for x in v)[len(v) // 2]))
             res["layers"].append({"kernel": k, "dil": d, "median_ms": med, "min_ms": mn})
+        elif "--convs" in sys.argv:      # the tap-convolution launches too (condnet, k7, upsamplers, the C = 512 stack): M, Cout
+            print("  %-34s M=%-8d Cout=%-5d x%d  median %.4f ms  min %.4f  (%.0f TF)" % (k, M, C, calls, med, mn, sorted(x[1] for x in v)[len(v) // 2]))
         s = stacks.setdefault(k, [0.0, 0])
         s[0] += sum(t) / reps
         s[1] += calls

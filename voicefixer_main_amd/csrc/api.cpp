@@ -587,6 +587,7 @@ void PlanBuilder::add_conv_phased(TapConvParams p, const std::vector<TapSeg>& ph
   const double fl = 2.0 * (double)hp.M * hp.cout_phase * k;
   plan->conv_flops += fl - conv_flops(hp);
   hp.flops_override = fl;
+  hp.up16 = (!(h->cfg.tuning & VFX_TUNE_NO_FUSED_UPSAMPLERS) && upsample16_ok(hp)) ? 1 : 0;
 }
 
 void PlanBuilder::add_resblock(ResBlockParams p) {
@@ -862,12 +863,12 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   h->device = device;
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
   VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
-  VFX_CHECK((h->cfg.tuning & ~511) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
+  VFX_CHECK((h->cfg.tuning & ~1023) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
   if (h->cfg.tuning) {  // never silent: a non-default kernel selection is announced
     static const char* names[] = {"NO_FUSED_STACKS", "NO_FUSED_WIDE", "NO_FUSED_UNET", "NO_PERSISTENT_C64", "NO_PAIRS", "NO_SPLITK",
-                                  "F32_TRUNK", "SMALL_2D_TILES", "DEBUG_POISON_ARENA"};
+                                  "F32_TRUNK", "SMALL_2D_TILES", "DEBUG_POISON_ARENA", "NO_FUSED_UPSAMPLERS"};
     std::string msg;
-    for (int b = 0; b < 9; ++b)
+    for (int b = 0; b < 10; ++b)
       if (h->cfg.tuning & (1 << b)) msg += std::string(msg.empty() ? "" : " | ") + "VFX_TUNE_" + names[b];
     fprintf(stderr, "[libvfx] handle on device %d uses non-default kernel selection: tuning = 0x%x (%s)\n", device, h->cfg.tuning,
             msg.c_str());

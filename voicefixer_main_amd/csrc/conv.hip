@@ -570,6 +570,10 @@ int conv_block_n(const TapConvParams& hp) {
 }
 
 void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream) {
+  if (hp.up16) {  // a ConvTranspose1d of the 16-bit mode on its own kernel (upsample16.hip)
+    launch_upsample16(hp, dparams, stream);
+    return;
+  }
   VFX_CHECK(hp.nstages > 0 && hp.P > 0 && hp.P <= kPatchMaxRows && hp.TH * hp.TW <= CBM, "conv: bad stage geometry");
   VFX_CHECK(hp.Cout % 32 == 0, "conv: Cout=%d is not a multiple of 32", hp.Cout);
   bool elu = false;

@@ -254,6 +254,10 @@ struct TapConvParams {
   // addresses its output in INPUT positions).  NULL = every clip has the full length (all other launches).  No split-K with it.
   const int* lens;
   int lens_mul_in, lens_mul_out;
+  // Set by PlanBuilder::add_conv_phased: this phased launch (a ConvTranspose1d of the vocoder's 16-bit mode: activated fp16 source,
+  // one fp16 output) runs on k_up16 (upsample16.hip) -- one block per tile of input positions and ALL its output phases, the patch
+  // staged once -- instead of k_conv's block per (tile, phase, cout range).  Same stage tables, same sums.
+  int up16;
 };
 
 // One fused TFGAN ResStack layer (resblock.hip): y = x + conv2(LeakyReLU(conv1(LeakyReLU(x)) + b1)) + b2.
@@ -366,6 +370,8 @@ void launch_splitk_reduce(const TapConvParams& hp, hipStream_t stream);  // hp: 
 void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out);  // p: absolute pointers
 void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
 int conv_block_n(const TapConvParams& hp);
+bool upsample16_ok(const TapConvParams& hp);  // upsample16.hip
+void launch_upsample16(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
 double conv_flops(const TapConvParams& hp);
 
 // ---------------------------------------------------------------------------------------------
