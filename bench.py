@@ -738,8 +738,9 @@ def aux_workload(name, args, device, weights):
 
 def aux_varlen(args, device, weights, n=128, lo=2.0, hi=8.0):
     """A test set of clips of UNEQUAL length (VCTK-shaped: 2 .. 8 s, no two alike) -- what the reference's harness iterates, one
-    handler call per file (evaluation_proc/eval.py:119-134) -- through dist.restore_sharded_lengths in a world of one: clips
-    bucketed by the ResUNet's padded frame count, one vfx_restore_gsr_varlen call per bucket (round 5).  Reported beside it: the
+    handler call per file (evaluation_proc/eval.py:119-134) -- through dist.restore_sharded_lengths in a world of one: sorted by
+    length, one vfx_restore_gsr_varlen call per 128 clips (round 6: inside the call the ResUNet runs once per padded frame count,
+    the vocoder per run of clips of similar length; round 5: one call per padded frame count).  Reported beside it: the
     same clips one call per clip (rounds 1-4), bit-equality of the two on every clip, the shortest clip against the oracle."""
     try:
         from voicefixer_main_amd import dist as vdist
@@ -763,7 +764,7 @@ def aux_varlen(args, device, weights, n=128, lo=2.0, hi=8.0):
                 torch.cuda.synchronize(device)
                 ts.append(time.perf_counter() - t0)
             return float(np.median(ts)), out
-        dt, got = timed(lambda: vdist.restore_sharded_lengths(fn, clips, device))
+        dt, got = timed(lambda: vdist.restore_sharded_lengths(fn, clips, device, max_batch=128))
         dt1, one = timed(lambda: [eng.restore_gsr(c[None])[0] for c in clips], reps=1)
         res = {"config": {"workload": "varlen_vctk", "clips": n, "clip_seconds_min_max": [round(min(lens) / 44100.0, 2), round(max(lens) / 44100.0, 2)],
                           "audio_seconds": round(total, 1), "buckets": len({eng.padded_frames(L) for L in lens})},

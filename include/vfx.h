@@ -192,8 +192,10 @@ int vfx_restore_gsr(vfx_handle* h, const float* wav, int B, int L, float* wav_ou
  * clip b, n_fft/2 < lengths[b] <= Lmax; logmel_out (B, Lmax / hop + 1, 128) optional.  Every clip gets what its own
  * vfx_restore_gsr(B = 1, L = lengths[b]) call computes -- frames and reflect padding at its own end (fDomainHelper.py:26-28),
  * the ResUNet's zero time padding behind its own last frame (unet.py:75-77), the vocoder stopped at its own length, its own
- * peak normalisation and trim_center -- and zeros past its end in both outputs.  REQUIREMENT: the clips of one call share the
- * padded frame count 64 * ceil((lengths[b] / hop + 1) / 64) of the ResUNet (the caller buckets by it; a violation is an error).
+ * peak normalisation and trim_center -- and zeros past its end in both outputs.  The clips of one call may have ANY lengths
+ * (round 6): the mel ResUNet runs once per padded frame count 64 * ceil((lengths[b] / hop + 1) / 64) among them (its clips gathered
+ * into a compact batch), the vocoder ONCE over the whole batch.  Hand the batch over with Lmax = (the largest padded frame count)
+ * x hop - 1 when many batches follow each other: the launch plans are cached per (B, Lmax).
  */
 int vfx_restore_gsr_varlen(vfx_handle* h, const float* wav, int B, int Lmax, const int* lengths, float* wav_out,
                            float* logmel_out, int flags, void* stream);

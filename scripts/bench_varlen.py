@@ -2,8 +2,8 @@
 """A test set of clips of UNEQUAL length (the reference iterates files of any length, one handler call each:
 evaluation_proc/eval.py:119-134) through `VoiceFixer.restore_list`, timed three ways on the same clips, resident in HBM:
 
-  varlen      the shipped path: clips bucketed by the ResUNet's padded frame count, one `vfx_restore_gsr_varlen` call per
-              bucket (round 5);
+  varlen      the shipped path: padded batches of up to 37 clips of ANY lengths through `vfx_restore_gsr_varlen` (round 6: the
+              ResUNet once per padded frame count inside the call, ONE vocoder pass; round 5: one call per padded frame count);
   per_clip    one `restore` call per clip (what rounds 1-4 did for a real test set: equal lengths are rare);
   equal       the same amount of audio as ONE batch of equal-length clips (`restore`; the configs[1] shape when the total
               is 160 s) -- the ceiling a padded batch is compared with.
@@ -59,6 +59,9 @@ def main():
 
     dt, got = timed(lambda: m.restore_list(clips))
     res["varlen_s"], res["varlen_audio_s_per_s"] = round(dt, 4), round(total / dt, 1)
+    if "--only-varlen" in sys.argv:            # (a profiler run: nothing but the shipped path in the trace)
+        print(json.dumps(res))
+        return
     dt1, one = timed(lambda: [m.restore(c[None])[0] for c in clips])
     res["per_clip_s"], res["per_clip_audio_s_per_s"] = round(dt1, 4), round(total / dt1, 1)
     res["varlen_equals_per_clip"] = bool(all(torch.equal(a, b) for a, b in zip(got, one)))

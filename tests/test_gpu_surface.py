@@ -222,8 +222,13 @@ def test_restore_varlen_sub_batches_and_errors(engine, monkeypatch):
     got = engine.restore_gsr_varlen(x, VARLEN)
     monkeypatch.delenv("VFX_MAX_CLIPS")
     assert torch.equal(got, want)
-    with pytest.raises(RuntimeError, match="share 64"):            # 20000 samples = 46 frames pad to 64, the others to 128
-        engine.restore_gsr_varlen(x, [20000] + VARLEN[1:])
+    # clips of DIFFERENT padded frame counts in one call (round 6): 20000 samples = 46 frames pad to 64, the others to 128 -- the
+    # ResUNet runs per padded count inside the call, the vocoder once; every clip still equals its own call
+    mixed = [20000] + VARLEN[1:]
+    got = engine.restore_gsr_varlen(x, mixed)
+    for j, L in enumerate(mixed):
+        assert torch.equal(got[j, :L], engine.restore_gsr(x[j:j + 1, :L].contiguous())[0]), j
+        assert not bool(got[j, L:].any())
     with pytest.raises(RuntimeError, match="samples"):
         engine.restore_gsr_varlen(x, [900] + VARLEN[1:])
     with pytest.raises(RuntimeError, match="samples"):
@@ -309,8 +314,8 @@ def test_graph_replay_takes_its_turn_beside_a_live_call_on_another_stream(engine
 
 
 def test_restore_list_buckets_by_padded_frames(voicefixer):
-    """restore_list on clips of seven lengths in two padded-frame buckets: two calls of the library instead of seven, results
-    equal to one `restore` per clip."""
+    """restore_list on clips of seven lengths with two padded frame counts: ONE call of the library instead of seven (round 6: the
+    ResUNet per padded count inside the call, one vocoder pass), results equal to one `restore` per clip."""
     lens = [30000, 12345, 41000, 20001, 12345, 28224, 50017]       # T = 69, 28, 93, 46, 28, 65, 114 -> padded 128, 64, 128, 64, 64, 128, 128
     clips, _ = _varlen_batch(lens, seed=110)
     calls = []
@@ -322,7 +327,7 @@ def test_restore_list_buckets_by_padded_frames(voicefixer):
         got = voicefixer.restore_list(clips)
     finally:
         del eng.restore_gsr_varlen, eng.restore_gsr
-    assert sorted(calls) == [("varlen", 3), ("varlen", 4)], calls
+    assert sorted(calls) == [("varlen", 7)], calls
     for c, g in zip(clips, got):
         assert torch.equal(g, voicefixer.restore(c[None])[0])
 

@@ -470,6 +470,39 @@ void launch_copy_rows_masked(const float* src, float* dst, int B, int T, int F, 
   VFX_HIP(hipGetLastError());
 }
 
+// A ResUNet group of a varlen call (api.cpp: vfx_restore_gsr_varlen): the rows of the group's clips idx[j] of src (B, T, F) as a
+// compact (n, Tg, F) tensor (rows past T: zeros), and back (rows < min(T, Tg)).
+__global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int T, int Tg, int F4,
+                              int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int64_t r = i / F4;
+  const int f = (int)(i - r * F4);
+  const int j = (int)(r / Tg), t = (int)(r - (int64_t)j * Tg);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (t < T) v = reinterpret_cast<const f32x4*>(src)[((int64_t)idx[j] * T + t) * F4 + f];
+  reinterpret_cast<f32x4*>(dst)[i] = v;
+}
+__global__ void k_scatter_rows(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int T, int Tg, int F4,
+                               int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int64_t r = i / F4;
+  const int f = (int)(i - r * F4);
+  const int j = (int)(r / Tg), t = (int)(r - (int64_t)j * Tg);
+  if (t < T) reinterpret_cast<f32x4*>(dst)[((int64_t)idx[j] * T + t) * F4 + f] = reinterpret_cast<const f32x4*>(src)[i];
+}
+void launch_gather_rows(const float* src, const int* idx, float* dst, int n, int T, int Tg, int F, hipStream_t s) {
+  const int64_t total4 = (int64_t)n * Tg * (F / 4);
+  hipLaunchKernelGGL(k_gather_rows, dim3(nblocks(total4, 256)), dim3(256), 0, s, src, idx, dst, T, Tg, F / 4, total4);
+  VFX_HIP(hipGetLastError());
+}
+void launch_scatter_rows(const float* src, const int* idx, float* dst, int n, int T, int Tg, int F, hipStream_t s) {
+  const int64_t total4 = (int64_t)n * Tg * (F / 4);
+  hipLaunchKernelGGL(k_scatter_rows, dim3(nblocks(total4, 256)), dim3(256), 0, s, src, idx, dst, T, Tg, F / 4, total4);
+  VFX_HIP(hipGetLastError());
+}
+
 void launch_peak_trim_varlen(const float* wav_long, int B, int64_t Llong, int L, int hop, const int* lens_l, const int* lens_tp,
                              const float* peak, float* out, hipStream_t s, int* flags) {
   hipLaunchKernelGGL(k_trim_scale_varlen, dim3((L + 255) / 256, B), dim3(256), 0, s, wav_long, Llong, L, hop, lens_l, lens_tp,

@@ -414,6 +414,9 @@ void launch_voc_final(const float* x, int x_f16, int B, int T, int C, const floa
 // d_lens[r * cap + b] = host[r * B + b], r < 3 (samples, frames, vocoder frames per clip): as kernel arguments, in stream order
 void launch_set_lens(int* d_lens, int cap, const int* host, int B, hipStream_t s);
 void launch_copy_rows_masked(const float* src, float* dst, int B, int T, int F, const int* lens_t, hipStream_t s);
+// dst (n, Tg, F) compact <- rows of src (B, T, F) of the clips idx[j] (rows >= T: zeros);  ... and back (rows < min(T, Tg))
+void launch_gather_rows(const float* src, const int* idx, float* dst, int n, int T, int Tg, int F, hipStream_t s);
+void launch_scatter_rows(const float* src, const int* idx, float* dst, int n, int T, int Tg, int F, hipStream_t s);
 void launch_peak_trim_varlen(const float* wav_long, int B, int64_t Llong, int L, int hop, const int* lens_l, const int* lens_tp,
                              const float* peak, float* out, hipStream_t s, int* flags);
 void launch_from_log(const float* logmel, const float* mel_in, int B, int T, int unify, float* sums, float* mel_out,
@@ -595,11 +598,15 @@ struct vfx_handle {
   std::shared_ptr<vfx::UNetWeights> unet[2];
   std::shared_ptr<vfx::VocoderWeights> voc;
   std::map<std::string, std::shared_ptr<vfx::Plan>> plans;  // at most kMaxCachedPlans, least recently used evicted
+  std::vector<std::shared_ptr<vfx::Plan>> retired;  // evicted plans whose device blocks are freed in batches (get_plan)
   uint64_t plan_tick = 0;
   char* arena = nullptr;
   size_t arena_bytes = 0;
   int* d_flags = nullptr;
-  int* d_lens = nullptr;     // [3][kMaxVarlenClips]: samples / frames / vocoder frames per clip of the varlen call in flight
+  int* d_lens = nullptr;     // [6][kMaxVarlenClips]: samples / frames / vocoder frames per clip of the varlen call in flight; frames /
+                             // batch index of the clips of its ResUNet group in flight (row 5 unused)
+  char* scratch = nullptr;   // the tensors between the plans of a varlen call (api.cpp: ensure_scratch), grow-only
+  size_t scratch_bytes = 0;
   float* d_ones = nullptr;   // identity prologue tables (kIdentityLen floats)
   float* d_zeros = nullptr;
   vfx::ConvProfile prof;

@@ -115,13 +115,22 @@ def checked_restore(engine, **kw):
     rank: a batch whose vocoder activations left the fp16 range (VFX_FLAG_F16_SATURATED) is re-run on the split-bf16 twin, a
     negative mel (to_log's assert) raises (Engine.restore_gsr_checked; one device sync per call).  Called with `lengths` it
     restores a padded batch of clips of unequal length (Engine.restore_gsr_varlen_checked); `fn.bucket_key(L)` tells
-    restore_sharded_lengths which clips may share such a call (the ResUNet's padded frame count)."""
+    restore_sharded_lengths which clips may share such a call (all of them), `fn.bucket_len(L)` the row length to pad a batch
+    whose longest clip has L samples to."""
     def fn(x, lengths=None):
         if lengths is None or len(set(int(v) for v in lengths)) == 1 and int(lengths[0]) == x.shape[-1]:
             return engine.restore_gsr_checked(x, **kw)
         return engine.restore_gsr_varlen_checked(x, lengths, **kw)
-    # an engine that cannot run padded batches (Engine.supports_varlen: the 16-bit mode on the fp32 trunk) buckets by exact length
-    fn.bucket_key = engine.padded_frames if engine.supports_varlen() else (lambda L: int(L))
+    # one bucket for everything (round 6: vfx_restore_gsr_varlen takes any mix of lengths -- the ResUNet per padded frame count inside
+    # the call, the vocoder once over the batch); the clips of a call are neighbours in the length order, so little of a padded
+    # batch is padding.  An engine that cannot run padded batches (Engine.supports_varlen: the 16-bit mode on the fp32 trunk)
+    # buckets by exact length
+    fn.bucket_key = (lambda L: 0) if engine.supports_varlen() else (lambda L: int(L))
+    # a padded batch is handed over at the bucket's LARGEST length (padded_frames * hop - 1 samples: the same frame count), not at
+    # the longest clip it happens to hold: the library caches a plan per (B, row length) (15 ms of host work to build, 0.6 ms to
+    # reuse), and a real test set has a new longest length in nearly every bucket call
+    if engine.supports_varlen():
+        fn.bucket_len = lambda L: engine.padded_frames(L) * engine.hop - 1
     return fn
 
 
@@ -230,7 +239,8 @@ def restore_sharded_lengths(engine_fn, clips, device, src=0, max_batch=37, dtype
                 if min(lens) == max(lens):
                     out = engine_fn(torch.stack([pieces[i] for i in chunk]))
                 else:
-                    x = torch.zeros((len(chunk), max(lens)), device=device, dtype=dtype)
+                    blen = getattr(engine_fn, "bucket_len", None)
+                    x = torch.zeros((len(chunk), blen(max(lens)) if blen else max(lens)), device=device, dtype=dtype)
                     for j, i in enumerate(chunk):
                         x[j, :lengths[i]] = pieces[i]
                     out = engine_fn(x, lens)

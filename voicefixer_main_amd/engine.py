@@ -275,7 +275,7 @@ class Engine:
 
     def padded_frames(self, L):
         """The ResUNet's padded frame count of a clip of L samples (unet.py:75-77): 64 * ceil(T / 64) -- the bucket key of
-        restore_gsr_varlen."""
+        restore_ssr_varlen, and the granule restore_gsr_varlen's callers pad a batch's row length to (one cached plan per row length)."""
         return -(-self.frames(L) // 64) * 64
 
     def supports_varlen(self):
@@ -290,7 +290,8 @@ class Engine:
     def restore_gsr_varlen(self, wav, lengths, unify_energy=False, want_logmel=False, out=None):
         """The handler() segment body for a batch of clips of UNEQUAL length: wav (B, Lmax), clip b = wav[b, :lengths[b]]
         -> restored (B, Lmax), zero past a clip's end.  Every clip gets what its own restore_gsr(wav[b:b+1, :lengths[b]])
-        computes (vfx_restore_gsr_varlen); the clips of one call must share `padded_frames(length)`."""
+        computes (vfx_restore_gsr_varlen).  Any mix of lengths (round 6): the library runs the mel ResUNet once per padded frame
+        count among the clips and the vocoder once over the whole batch."""
         wav = _dev_f32(wav, self.device)
         B, L = wav.shape
         lengths = [int(v) for v in lengths]

@@ -377,12 +377,13 @@ class VoiceFixer(_Base):
         out = _rerun_if_saturated(self.engine, out, lambda e: e.restore_gsr(x, unify_energy=unify_energy))
         return out[:, None] if squeeze else out
 
-    def restore_list(self, wavs, unify_energy=False, max_batch=37):
+    def restore_list(self, wavs, unify_energy=False, max_batch=128):
         """A test set of clips of ARBITRARY lengths (what the reference's harness iterates, one handler call per file:
-        evaluation_proc/eval.py:119-134): list of 1-D tensors -> list of restored 1-D tensors in the same order.  Clips whose
-        frame counts pad to the same multiple of 64 share ONE call of the library as a padded batch with their lengths
-        (vfx_restore_gsr_varlen: every clip's result is the one its own batch-of-one call gives), buckets are visited longest
-        first; with torch.distributed initialised the list is dealt over the ranks by length and gathered on rank 0
+        evaluation_proc/eval.py:119-134): list of 1-D tensors -> list of restored 1-D tensors in the same order.  The clips go
+        through the library sorted by length, up to `max_batch` per call, as padded batches with their lengths
+        (vfx_restore_gsr_varlen: every clip's result is the one its own batch-of-one call gives; inside a call the mel ResUNet
+        runs once per padded frame count over all its clips, the vocoder per run of clips of similar length); with
+        torch.distributed initialised the list is dealt over the ranks by length and gathered on rank 0
         (dist.restore_sharded_lengths).  The 16-bit mode's re-run guarantee holds per batch."""
         from . import dist as vdist
         fn = vdist.checked_restore(self.engine, unify_energy=unify_energy)
@@ -426,6 +427,7 @@ class SSR_UNet(_Base):
                 return eng.resunet_spec(eng.stft(x, want_mel=False, want_sp=True)["sp"], x)
             return eng.restore_ssr_varlen(x, lengths)
         fn.bucket_key = eng.padded_frames
+        fn.bucket_len = lambda L: eng.padded_frames(L) * eng.hop - 1      # one plan per (B, bucket), cf. dist.checked_restore
         return vdist.restore_sharded_lengths(fn, wavs, self.device, max_batch=max_batch)
 
 
