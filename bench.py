@@ -411,7 +411,7 @@ def live_traffic(args):
         last = first[-1] if first else 0                      # launches of the last step
         per = collections.OrderedDict()
         for (k, r), (_, w) in list(zip(rd, wr))[last:]:
-            if not (k.startswith("k_conv") or k.startswith("k_resblock")):
+            if not (k.startswith("k_conv") or k.startswith("k_resblock") or k.startswith("k_up16")):
                 continue
             t = per.setdefault(k, [0, 0.0, 0.0])
             t[0] += 1

@@ -1614,6 +1614,8 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       char kname[64];
       if (d.nseg == 0) {  // fused ResStack layer
         snprintf(kname, sizeof(kname), "%s<%d; %d>%s", d.seg[0].ntaps == 12 ? "k_resblock_pair" : "k_resblock", d.Cout, d.nstages, d.hionly ? " f16" : "");
+      } else if (d.up16) {  // a ConvTranspose1d of the 16-bit mode on its own kernel (upsample16.hip)
+        snprintf(kname, sizeof(kname), "k_up16<%d; 128> f16", d.seg[0].C / 64);
       } else {
         bool elu = false;
         for (int s2 = 0; s2 < d.nseg; ++s2) elu = elu || d.seg[s2].act == ACT_ELU;
