@@ -41,6 +41,9 @@ constexpr int R128_PR = 160;  // patch rows per chunk buffer
 // the CU: raw, it replaces x in the 64 registers that hold the residual; activated, it is written as the operand patch of the
 // second layer over the first one's.  Both layers work over the 128-index space of the tile: y1 is valid on indices 1 .. 126, the
 // second layer's h on 1 + d2 .. 126 - d2, the outputs on 2 + d2 .. 125 - d2 (plan_resblock: 128 - 4 - 2 d2 positions per tile).
+// Measured and NOT kept (round 6, profiles/r06_c15_voc_layers_r128_persistent_loser.txt): the single layers as PERSISTENT blocks (two
+// per CU, each walking its XCD's tiles, set-up paid once per block): 3.94 -> 4.14 ms for the six layers on one box, alternating.  A
+// fresh workgroup's set-up runs beside the other block's arithmetic either way; the loop only adds its barrier and registers.
 template <bool PAIR, bool X16>
 __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* __restrict__ pp) {
   constexpr int C = 128, NW = 4, NTHR = NW * 64, MT = 128;
