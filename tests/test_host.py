@@ -495,7 +495,8 @@ def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
     # (and k_conv<64, ELU, split, ring 3>: 8 bytes since round 1, split-bf16 mode of the vocoder's ELU convolutions only)
     # (and the VL twin of k_conv<64, split>: 8 bytes, the split-bf16 vocoder launches of a varlen batch only -- precision 1)
     may_spill = ("k_convILi64ELb1ELb1ELi0ELi3ELb0ELb0E", "k_convILi64ELb0ELb1ELi0ELi3ELb0ELb0ELb0ELb1E")
-    for name in ("conv.hip", "resblock.hip", "resblock_w64.hip", "resblock_r128.hip", "resblock_rw.hip", "stft.hip", "small_ops.hip"):
+    for name in ("conv.hip", "resblock.hip", "resblock_w64.hip", "resblock_r128.hip", "resblock_rw.hip", "upsample16.hip", "stft.hip",
+                 "small_ops.hip"):
         out = str(tmp_path / (name + ".s"))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                         "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, name)], check=True,

@@ -164,6 +164,46 @@ def _pre(model, segment, device):
     return sp, mel_orig, x
 
 
+class _PinnedPool:
+    """Page-locked staging buffers, reused across segments and files.  `torch.empty(..., pin_memory=True)` / `.pin_memory()` per
+    segment hands the buffer back to torch's caching host allocator, which can only recycle it once the copy that used it has
+    finished -- every other file of a back-to-back evaluation found its block still busy and paid a fresh hipHostMalloc (10-20 ms:
+    round 6, the handler's calls on one file alternated between 40 and 59 ms).  Here a buffer is taken with `take`, given back with
+    `give` together with the event behind its last use, and handed out again only when that event has completed."""
+
+    def __init__(self):
+        self.free = []          # (tensor, event or None)
+
+    def take(self, n, dtype):
+        for i, (t, ev) in enumerate(self.free):
+            if t.dtype == dtype and t.numel() >= n and (ev is None or ev.query()):
+                del self.free[i]
+                return t
+        return torch.empty((max(int(n), 1),), dtype=dtype, pin_memory=torch.cuda.is_available())
+
+    def give(self, t, ev=None):
+        self.free.append((t, ev))
+        if len(self.free) > 16:       # bounded: drop the smallest
+            self.free.sort(key=lambda p: -p[0].numel())
+            self.free.pop()
+
+
+_PINNED = _PinnedPool()
+
+
+def _staged_upload(host, n, device):
+    """host[:n] (a pool buffer) -> a tensor on `device`; the buffer goes back to the pool behind the copy."""
+    if torch.device(device).type != "cuda":
+        out = host[:n].clone()
+        _PINNED.give(host)
+        return out
+    out = host[:n].to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _PINNED.give(host, ev)
+    return out
+
+
 class _WavReader:
     """librosa.load(path, 44100) semantics of `load_wav`, streamed: the PCM16 frames of a 44.1 kHz file are read one segment
     at a time, so the GPU starts on the first 60 s while the host is still reading the rest.  Anything else (other sample
@@ -212,10 +252,13 @@ class _WavReader:
                 self.n = self.pos
             if n == 0:
                 return torch.empty((0,), dtype=torch.float32, device=device)
-            pcm = torch.frombuffer(bytearray(raw), dtype=torch.int16).pin_memory().to(device, non_blocking=True)
-            return pcm.to(torch.float32) / 32768.0
+            host = _PINNED.take(n, torch.int16)
+            host[:n].numpy()[:] = np.frombuffer(raw, dtype="<i2")      # one copy, into page-locked memory
+            return _staged_upload(host, n, device).to(torch.float32) / 32768.0
         x = self.read(count)
-        return torch.from_numpy(np.ascontiguousarray(x)).pin_memory().to(device, non_blocking=True)
+        host = _PINNED.take(x.shape[0], torch.float32)
+        host[:x.shape[0]].numpy()[:] = x
+        return _staged_upload(host, x.shape[0], device)
 
     def close(self):
         if self.f is not None:
@@ -241,18 +284,20 @@ class _WavWriter:
     def put(self, seg):
         """seg: (n,) float32 on the device; enqueues conversion + download, writes what has arrived before."""
         pcm = (seg.double() * 2 ** 15).to(torch.int32).to(torch.int16)   # float64 -> int32 truncation, then the 16-bit wrap of numpy
-        host = torch.empty(pcm.shape, dtype=torch.int16, pin_memory=True)
+        buf = _PINNED.take(pcm.numel(), torch.int16)
+        host = buf[:pcm.numel()]
         host.copy_(pcm, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending.append((host, ev))
+        self.pending.append((host, ev, buf))
         self.flush(block=False)
 
     def flush(self, block=True):
         while self.pending and (block or self.pending[0][1].query()):
-            host, ev = self.pending.pop(0)
+            host, ev, buf = self.pending.pop(0)
             ev.synchronize()
             self.f.writeframes(host.numpy())     # (the buffer itself: writeframes takes any bytes-like object, no copy)
+            _PINNED.give(buf)
 
     def close(self, ok=True):
         import os
