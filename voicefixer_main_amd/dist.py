@@ -173,7 +173,7 @@ def deal_by_length(lengths, world):
     return owner
 
 
-def restore_sharded_lengths(engine_fn, clips, device, src=0, max_batch=37, dtype=torch.float32):
+def restore_sharded_lengths(engine_fn, clips, device, src=0, max_batch=128, dtype=torch.float32):
     """A test set of clips of ARBITRARY lengths (the reference iterates files of any length, one handler call each:
     evaluation_proc/eval.py:119-134) on N ranks.  `clips`: list of 1-D tensors on rank `src` (ignored elsewhere).  Returns the
     restored clips, same lengths, original order, on `src` (None elsewhere).
@@ -182,8 +182,9 @@ def restore_sharded_lengths(engine_fn, clips, device, src=0, max_batch=37, dtype
     * every rank receives its clips as ONE flat buffer (one message per peer and direction, all of rank `src`'s links driven
       concurrently by the grouped isend / irecv) -- the lengths travel first, as one small object;
     * within a rank, clips that share `engine_fn.bucket_key(length)` run as one PADDED batch with their lengths
-      (engine_fn(x (B, Lmax), lengths) -> (B, Lmax); `checked_restore`: the key is the ResUNet's padded frame count, the call
-      vfx_restore_gsr_varlen, round 5) -- every clip's result is still the one its own batch-of-one call gives: the reflection
+      (engine_fn(x (B, Lmax), lengths) -> (B, Lmax); `checked_restore`: ONE key for all clips since round 6 -- the call is
+      vfx_restore_gsr_varlen, which runs the ResUNet per padded frame count and the vocoder per run of clips inside; the rows are
+      padded to `engine_fn.bucket_len(longest)`) -- every clip's result is still the one its own batch-of-one call gives: the reflection
       at ITS end (fDomainHelper.py:26-28), the ResUNet's zero padding behind ITS last frame (unet.py:75-77), the vocoder stopped
       at ITS length (tests/test_gpu_surface.py).  An engine_fn without `bucket_key` gets clips of EQUAL length only
       ((B, L) -> (B, L), rounds 1-4).  At most `max_batch` clips per call;
