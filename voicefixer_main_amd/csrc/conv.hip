@@ -150,11 +150,14 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   // cycles) -- a wave of this tile reads all 128 pixel fragments per K step, 85 B/clk/CU at full MFMA rate before conflicts.
   constexpr bool SWZ2D = BN <= 64 || !HI;
   const int hTW = p.TW >> 1;
+  // prow / PW as multiply-shift (prow < 192 = kPatchMaxRows, PW <= 192: exact): keyq[] and set_origin() were twelve integer
+  // divisions of ~25 VALU instructions per thread and block (round 6)
+  const unsigned inv_pw = ((1u << 20) + (unsigned)PW - 1u) / (unsigned)PW;
   int keyq[CNQ];  // key of this thread's patch pixels lr + 32q
 #pragma unroll
   for (int q = 0; q < CNQ; ++q) {
     const int prow = lr + 32 * q;
-    const int pi = prow / PW, pj = prow - pi * PW;
+    const int pi = (int)(((unsigned)prow * inv_pw) >> 20), pj = prow - pi * PW;
     keyq[q] = SWZ2D ? ((pj >> 1) + hTW * pi) & 7 : (prow >> 1) & 7;
   }
   if (tid < CBM) {
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
 #pragma unroll
     for (int q = 0; q < CNQ; ++q) {
       const int prow = lr + 32 * q;  // patch pixel -> (row, col) of the PH x PW window
-      const int pi = prow / PW, pj = prow - pi * PW;
+      const int pi = (int)(((unsigned)prow * inv_pw) >> 20), pj = prow - pi * PW;
       const int si = prow < P ? i0 + dh + pi : -1;
       int sj = j0 + dw + pj;
       int rj = sj < 0 ? -sj : sj;

@@ -136,6 +136,10 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   const int wm = wave_u / WAVES_N, wn = wave_u % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
   const int key_l = (lr >> 1) & 7;
+  // row / PW and pixel / W1 as multiply-shift (rows < 512, divisors <= 320: exact, cf. resblock_rw.hip): the per-thread tables below were
+  // up to fourteen integer divisions of ~25 VALU instructions each -- a seventh of the block's instructions (round 6: the fused blocks
+  // are bound by the instructions they issue, ~6 cycles each per SIMD, like the 1-D layers were)
+  const unsigned inv_pw = ((1u << 20) + (unsigned)PW - 1u) / (unsigned)PW, inv_w1 = ((1u << 20) + (unsigned)W1 - 1u) / (unsigned)W1;
 
   // ---- per-thread tables ------------------------------------------------------------------------------
   // x patch pixel lr + 32q -> byte offset in x (chunk 0) / validity
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
 #pragma unroll
   for (int q = 0; q < NG; ++q) {
     const int prow = lr + RG * q;
-    const int pi = prow / PW, pj = prow - pi * PW;
+    const int pi = (int)(((unsigned)prow * inv_pw) >> 20), pj = prow - pi * PW;
     keyq[q] = G2 ? (((pj >> 1) + hW1 * pi) & 7) : key_l;
     if constexpr (G2) {  // patch pixel (pi, pj) = image pixel (i0 - 2 + pi, j0 - 2 + pj)
       const int r = i0 - 2 + pi, c = j0 - 2 + pj;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
     const int ml = (wm * WM + a) * 32 + l31;
-    const int li = ml / W1, lj = ml - li * W1;
+    const int li = (int)(((unsigned)ml * inv_w1) >> 20), lj = ml - li * W1;
     arow1[a] = li < TH ? li * PW + lj : 0;
     arow2[a] = ml;
     kq0[a] = li < TH ? (lj >> 1) + hW1 * li : 0;
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
   // ---- phase 4: y = conv2 + b2 + x --------------------------------------------------------------------------
   int* otab = reinterpret_cast<int*>(lds + OTAB_OFF);
   if (tid < MT) {
-    const int li = tid / W1, lj = tid - li * W1;
+    const int li = (int)(((unsigned)tid * inv_w1) >> 20), lj = tid - li * W1;
     if constexpr (G2) {  // outputs = interior of the h grid, inside the image
       const int r = i0 - 1 + li, c = j0 - 1 + lj;
       const bool ok = (li >= 1) & (li <= TH - 2) & (lj >= 1) & (lj <= W1 - 2) & (r < Hh) & (c < Ww);
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
       const int pr = lr + RG * q;
       int m;
       if (p.fold) {
-        const int pi = pr / PW, pj = pr - pi * PW;
+        const int pi = (int)(((unsigned)pr * inv_pw) >> 20), pj = pr - pi * PW;
         m = (pi >= 1 && pi <= TH) ? (pi - 1) * W1 + pj : -1;
       } else {
         m = pr - d;
