@@ -68,6 +68,8 @@ enum {
                                       level, which exist on 16 x 16 tiles only, as two launches each */
   VFX_TUNE_NO_FUSED_UPSAMPLERS = 512, /* 16-bit mode: the vocoder's ConvTranspose1d upsamplers as phased tap-convolution launches (one block per
                                       tile, phase and cout range) instead of k_up16 (one block per tile of input positions, all phases) */
+  VFX_TUNE_OLD_BLOCK2D = 1024,     /* the identity ConvBlockRes of ResUNet level 1 (C = 32, 16 x 16 tiles) on k_resblock (one tile per block, LDS-DMA
+                                      patch, swizzled rows) instead of the persistent k_block2d32 (round 6) */
   VFX_TUNE_DEBUG_POISON_ARENA = 256 /* debug aid, no kernel selection: the handle's workspace arena is filled with NaN patterns when
                                       it grows and before every call, so that a kernel reading a buffer nobody wrote shows up */
 };

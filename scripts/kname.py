@@ -31,6 +31,8 @@ def short(n, width=40):
         return "k_resblock_pair<64, 8> f16" if args and args[0] == "true" else "k_resblock<64, 8> f16"
     if name == "k_up16" and args:                        # round 6: the x3 ConvTranspose1d upsamplers of the 16-bit mode; <Cin / 64, TM>
         return "k_up16<%s> f16" % ", ".join(args)
+    if name == "k_block2d32":                            # round 6: the persistent C = 32 ConvBlockRes of ResUNet level 1
+        return "k_block2d<32, 4>"
     if name == "k_resblock" and len(args) >= 2:
         hi = len(args) >= 3 and args[2] == "true"
         return "k_resblock<%s, %s>%s" % (args[0], args[1], " f16" if hi else "")

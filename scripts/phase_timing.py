@@ -51,6 +51,65 @@ def rw_case(eng, buf, g, d, d2, out):
     out[name] = res
 
 
+def block2d_case(eng, buf, g, C, H, W, out, prec):
+    """A fused 2-D ConvBlockRes of the ResUNets (resblock.hip, G2) at a level's shape: 4 waves per block, one tile per block."""
+    B = 16
+    x = torch.randn((B, H, W, C), generator=g).cuda()
+    w1, w2 = (torch.randn((C, C, 3, 3), generator=g) * 0.05).numpy(), (torch.randn((C, C, 3, 3), generator=g) * 0.05).numpy()
+    one, zero = np.ones(C, np.float32), np.zeros(C, np.float32)
+    call = lambda: eng.op_block2d(x, w1, one, zero, w2, one, zero, 0.01)
+    call()
+    buf.zero_()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    call()
+    ev1.record()
+    torch.cuda.synchronize()
+    ts = buf.cpu().numpy().astype(np.uint64).reshape(-1, 4, 16)
+    ts = ts[ts[:, 0, 12] != 0].astype(np.float64)
+    n = ts.shape[0]
+    dt = np.diff(ts[:, :, :13], axis=2)
+    life = ts[:, :, 12] - ts[:, :, 0]
+    span = ts[:, :, 12].max() - ts[:, :, 0].min()
+    res = {"tiles": int(n), "mean_block_cycles": float(life.mean()), "kernel_span_cycles": float(span),
+           "phases": {("%02d %s" % (i, PHASES[i])): float(dt[:, :, i].mean()) for i in range(12)},
+           "call_ms_incl_host_prep": ev0.elapsed_time(ev1)}
+    out["block2d_C%d" % C] = res
+    print("== 2-D block, C = %d, %d x %d x %d (precision %d): %d tiles, block lifetime %.0f cycles (mean), kernel span %.0f cycles, "
+          "blocks in flight = %.1f per CU; the call: %.3f ms" % (C, B, H, W, prec, n, life.mean(), span, n * life.mean() / span / 256.0,
+                                                                  res["call_ms_incl_host_prep"]))
+    # per-CU concurrency from the stamps themselves (s_memtime is not synchronised across XCDs: use each block's own start / end and
+    # the kernel's duration): sum of tile lifetimes / (256 CUs x the call's duration in cycles at the clock the stamps imply)
+    if C == 32:  # block2d32.hip: [start, end] of every block on the chip-wide 100 MHz clock + HW_ID / XCC_ID
+        raw = buf.cpu().numpy().astype(np.uint64)
+        nt = 16 * ((H + 13) // 14) * ((W + 13) // 14)
+        tb = raw[nt * 64: nt * 64 + 768 * 4].reshape(768, 4)
+        tb = tb[tb[:, 1] != 0]
+        if tb.shape[0]:
+            t0 = tb[:, 0].astype(np.float64) - float(tb[:, 0].min())
+            t1 = tb[:, 1].astype(np.float64) - float(tb[:, 0].min())
+            mid = 0.5 * float(t1.max())
+            hw = tb[:, 2] & np.uint64(0xffffffff)
+            xcc = (tb[:, 2] >> np.uint64(32)) & np.uint64(0xf)
+            cu = (hw >> np.uint64(8)) & np.uint64(0xf)
+            sh = (hw >> np.uint64(12)) & np.uint64(0x1)
+            se = (hw >> np.uint64(13)) & np.uint64(0x7)
+            key = xcc * np.uint64(1000) + se * np.uint64(100) + sh * np.uint64(20) + cu
+            print("   blocks: %d; kernel %.1f us on the 100 MHz clock; starts: %d within 5 us, %d later; running at mid-kernel: %d; "
+                  "distinct (XCC, SE, SH, CU): %d; blocks per CU: max %d" % (
+                      tb.shape[0], t1.max() / 100.0, int((t0 < 500).sum()), int((t0 >= 500).sum()), int(((t0 < mid) & (t1 > mid)).sum()),
+                      len(set(key.tolist())), max(np.bincount(np.unique(key, return_inverse=True)[1]))))
+            late = np.sort(t0)[-8:] / 100.0
+            print("   latest block starts (us):", " ".join("%.1f" % v for v in late), "; block durations (us): min %.1f mean %.1f max %.1f" % (
+                (t1 - t0).min() / 100.0, (t1 - t0).mean() / 100.0, (t1 - t0).max() / 100.0))
+    first, last = ts[:, :, 0].min(axis=1), ts[:, :, 12].max(axis=1)
+    print("   sum of tile lifetimes %.3e cycles; mean tile %.0f; tiles x mean / 768 blocks = %.0f cycles per block" % (
+        float((last - first).sum()), float((last - first).mean()), float((last - first).sum()) / 768.0))
+    for i, (k, v) in enumerate(res["phases"].items()):
+        print("   %-22s %9.0f cycles  %5.1f %%   (slowest wave of a block: %7.0f)" % (k, v, 100.0 * v / life.mean(), dt[:, :, i].max(axis=1).mean()))
+
+
 PHASES = ["setup+request", "patch wait", "transform", "barrier", "conv1", "barrier", "h write", "barrier", "conv2", "barrier",
           "stage / pass 0", "epilogue rest"]
 
@@ -63,10 +122,17 @@ def main():
     eng = Engine("cuda:0", config={"precision": 2})
     out = {}
     g = torch.Generator().manual_seed(0)
-    if "--c64" in sys.argv or "--only-c64" in sys.argv:
+    only2d = "--only-block2d" in sys.argv
+    if "--block2d" in sys.argv or only2d:
+        eng1 = Engine("cuda:0", config={"precision": 1})
+        block2d_case(eng1, buf, g, 32, 1016, 128, out, 1)
+        block2d_case(eng1, buf, g, 64, 504, 64, out, 1)
+    if only2d:
+        pass
+    elif "--c64" in sys.argv or "--only-c64" in sys.argv:
         for d, d2 in ((1, None), (81, None), (243, None), (2187, None), (1, 3), (9, 27)):
             rw_case(eng, buf, g, d, d2, out)
-    for C, T in (() if "--only-c64" in sys.argv else ((256, 49294), (128, 147882))):
+    for C, T in (() if ("--only-c64" in sys.argv or only2d) else ((256, 49294), (128, 147882))):
         B = 16
         x = torch.randn((B, T, C), generator=g).cuda()
         w1, w2 = (torch.randn((C, C, 3), generator=g) * 0.05).numpy(), (torch.randn((C, C, 3), generator=g) * 0.05).numpy()

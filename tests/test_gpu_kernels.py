@@ -295,6 +295,33 @@ def test_mel_project(engine):
     assert np.abs(got - ref).max() < 1e-5 * ref.max()
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 40, 127), (3, 7, 5), (1, 100, 128), (5, 14, 14), (2, 61, 30), (1, 16, 16), (19, 33, 45), (16, 310, 128)])
+def test_block2d32_equals_the_one_tile_per_block_kernel(engine, B, H, W):
+    """The persistent C = 32 block kernel (block2d32.hip: padded LDS rows, tables computed once per block, masks on border tiles
+    only) against k_resblock's 16 x 16 form of the same block (VFX_TUNE_OLD_BLOCK2D): the same products summed in the same order,
+    so every output must be bit-identical -- interior tiles, all four borders, images smaller than a tile, fewer tiles than
+    blocks and (16 x 310 x 128: 3 680 tiles on 768 blocks) several tiles per block, where the loop-carried state and the hazards
+    between a tile's last MFMAs and its staged stores show."""
+    if engine.tol['name'] == 'fp32':
+        pytest.skip("the fused block exists for the split-bf16 ResUNet arithmetic (precision 1 and 2) only")
+    from voicefixer_main_amd import _lib
+    from voicefixer_main_amd.engine import Engine
+    C = 32
+    x = _rand((B, C, H, W), 51) * 3.0
+    w1, w2 = _rand((C, C, 3, 3), 52, 0.06), _rand((C, C, 3, 3), 53, 0.06)
+    g = torch.Generator().manual_seed(54)
+    sc1, sc2 = torch.rand(C, generator=g) + 0.5, torch.rand(C, generator=g) + 0.5
+    sh1, sh2 = _rand((C,), 55, 0.2), _rand((C,), 56, 0.2)
+    args = (w1.numpy(), sc1.numpy(), sh1.numpy(), w2.numpy(), sc2.numpy(), sh2.numpy(), 0.01)
+    y = engine.op_block2d(_nhwc(x), *args).cpu()
+    old = Engine("cuda:0", config={"precision": 1, "tuning": _lib.TUNE_OLD_BLOCK2D})
+    y_old = old.op_block2d(_nhwc(x), *args).cpu()
+    assert torch.isfinite(y).all()
+    assert torch.equal(y, y_old), (y - y_old).abs().max().item()
+    again = engine.op_block2d(_nhwc(x), *args).cpu()  # no state between calls
+    assert torch.equal(y, again)
+
+
 @pytest.mark.parametrize("C,H,W", [(32, 40, 127), (64, 33, 63), (32, 7, 5), (64, 130, 20)])
 def test_fused_conv_block_res(engine, C, H, W):
     """One ConvBlockRes with identity shortcut as ONE launch (k_resblock, 2-D mode): bn1 -> lrelu -> 3x3 -> bn2 -> lrelu ->

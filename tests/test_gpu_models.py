@@ -281,7 +281,7 @@ def test_fp16_vocoder_dynamic_range_flag_and_rerun(unet_sd, voc_sd):
 # replaces one kernel family by an older / simpler form of the same arithmetic; the results must stay within the mode's bars.
 TUNING = [("NO_FUSED_STACKS", 1, 2), ("NO_FUSED_WIDE", 2, 2), ("NO_FUSED_UNET", 4, 1), ("NO_PERSISTENT_C64", 8, 2),
           ("NO_PAIRS", 16, 2), ("NO_SPLITK", 32, 1), ("F32_TRUNK", 64, 2), ("SMALL_2D_TILES", 128, 1), ("NO_FUSED_STACKS", 1, 1),
-          ("DEBUG_POISON_ARENA", 256, 2), ("NO_FUSED_UPSAMPLERS", 512, 2)]
+          ("DEBUG_POISON_ARENA", 256, 2), ("NO_FUSED_UPSAMPLERS", 512, 2), ("OLD_BLOCK2D", 1024, 1)]
 
 
 @pytest.mark.parametrize("name,bit,precision", TUNING, ids=["%s-p%d" % (n, p) for n, _, p in TUNING])

@@ -621,7 +621,7 @@ void PlanBuilder::add_resblock(ResBlockParams p) {
       d.seg[0].ntaps = 6;
       d.hionly = hp.hionly;
       d.nstages = resblock_block_waves(hp);                                             // waves per block
-      d.seg[0].ntaps = hp.dil2 > 0 ? 12 : 6;                                            // pairs: four convolutions
+      d.seg[0].ntaps = hp.dil2 > 0 ? 12 : (block2d32_ok(hp) ? 18 : 6);                  // pairs: four convolutions; 18: the persistent 2-D block
       c.prof->desc.push_back(d);
     } else {
       launch_resblock(hp, pl->dev_rb + idx, c.stream);
@@ -864,12 +864,12 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   h->device = device;
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
   VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
-  VFX_CHECK((h->cfg.tuning & ~1023) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
+  VFX_CHECK((h->cfg.tuning & ~2047) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
   if (h->cfg.tuning) {  // never silent: a non-default kernel selection is announced
     static const char* names[] = {"NO_FUSED_STACKS", "NO_FUSED_WIDE", "NO_FUSED_UNET", "NO_PERSISTENT_C64", "NO_PAIRS", "NO_SPLITK",
-                                  "F32_TRUNK", "SMALL_2D_TILES", "DEBUG_POISON_ARENA", "NO_FUSED_UPSAMPLERS"};
+                                  "F32_TRUNK", "SMALL_2D_TILES", "DEBUG_POISON_ARENA", "NO_FUSED_UPSAMPLERS", "OLD_BLOCK2D"};
     std::string msg;
-    for (int b = 0; b < 10; ++b)
+    for (int b = 0; b < 11; ++b)
       if (h->cfg.tuning & (1 << b)) msg += std::string(msg.empty() ? "" : " | ") + "VFX_TUNE_" + names[b];
     fprintf(stderr, "[libvfx] handle on device %d uses non-default kernel selection: tuning = 0x%x (%s)\n", device, h->cfg.tuning,
             msg.c_str());
@@ -1613,7 +1613,8 @@ int vfx_profile_end(vfx_handle* h, int64_t* launches, double* total_ms, double* 
       for (int s2 = 0; s2 < d.nseg; ++s2) K += d.seg[s2].ntaps * d.seg[s2].C;
       char kname[64];
       if (d.nseg == 0) {  // fused ResStack layer
-        snprintf(kname, sizeof(kname), "%s<%d; %d>%s", d.seg[0].ntaps == 12 ? "k_resblock_pair" : "k_resblock", d.Cout, d.nstages, d.hionly ? " f16" : "");
+        snprintf(kname, sizeof(kname), "%s<%d; %d>%s", d.seg[0].ntaps == 12 ? "k_resblock_pair" : (d.seg[0].ntaps == 18 ? "k_block2d" : "k_resblock"), d.Cout,
+                 d.nstages, d.hionly ? " f16" : "");
       } else if (d.up16) {  // a ConvTranspose1d of the 16-bit mode on its own kernel (upsample16.hip)
         snprintf(kname, sizeof(kname), "k_up16<%d; 128> f16", d.seg[0].C / 64);
       } else {

@@ -114,6 +114,8 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  VFX_TS_DECL;  // timing builds (-DVFX_TIMING, scripts/phase_timing.py --block2d): s_memtime at the phase boundaries, 2-D blocks
+  VFX_TS(0);
   const int tj = tile % p.tiles_w;
   const int ti = (tile / p.tiles_w) % p.tiles_h;
   const int img = tile / (p.tiles_w * p.tiles_h);
@@ -458,14 +460,18 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
     issue_patch(1, PBYTES);
     issue_patch(2, 2 * PBYTES);
   }
+  VFX_TS(1);  // patch requested
   drain();
+  VFX_TS(2);  // patch arrived
   transform_patch(0, 0);
+  VFX_TS(3);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     // the patch requested while this chunk is computed: the next one, or (three buffers) chunk 3 during chunk 1
     const int dma_chunk = NBUF == 3 ? (c == 1 ? 3 : NCH) : c + 1;
     const bool has_dma = dma_chunk < NCH;
     __syncthreads();  // patch c is visible; the buffer of the chunk before it is free
+    if (c == 0) VFX_TS(4);
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const int g = KT * c + k;
@@ -490,7 +496,9 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
     if (c + 1 < NCH) transform_patch(((c + 1) % NBUF) * PBYTES, c + 1);
   }
 
+  VFX_TS(5);  // conv1 done
   __syncthreads();  // every wave is done reading the patch buffers that h overlays
+  VFX_TS(6);
   }  // !SC2
 
   // ---- phase 2: h = LeakyReLU(conv1 + b1) in operand form, zero outside the sequence ---------------------------
@@ -531,7 +539,9 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
     }
   }
   if constexpr (HI) report_f16_saturation(f16_sat_bits_bad(f16_sat), p.flags);
+  VFX_TS(7);  // h written
   __syncthreads();  // h is complete
+  VFX_TS(8);
   }  // !IN1
 
   // ---- phase 3: conv2 from the resident h ------------------------------------------------------------------
@@ -552,7 +562,9 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
       __builtin_amdgcn_sched_barrier(0);
     }
   drain();
+  VFX_TS(9);  // conv2 done
   __syncthreads();  // every wave is done with h and the patch buffers
+  VFX_TS(10);
 
   // ---- phase 3b (SC2): + shortcut(cat(x, x2)), a 1x1 convolution of the RAW sources -- one more 32-channel K segment per source ----
   if constexpr (SC2) {
@@ -627,6 +639,7 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
           f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
     }
   __syncthreads();
+  VFX_TS(11);  // staged
   if constexpr (KEEPRES) {
     // + x from the registers: patch pixel pr is the input sample of h pixel m = pr - d (1-D) or, folded, of the pixel one
     // patch row up -- every staged (row, 4 channels) is touched by exactly one thread
@@ -705,6 +718,8 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
       }
     }
   }
+  VFX_TS(12);  // stores issued
+  if constexpr (G2) VFX_TS_FLUSH(p.timing, tile, wave_u, NW);
 }
 
 static size_t resblock_lds_bytes(int C, int MT = CBM) {
@@ -716,7 +731,11 @@ static size_t resblock_lds_bytes(int C, int MT = CBM) {
 
 template <int C, int NW, bool HI, bool G2 = false, int MT = 128, bool IN1 = false, bool SC2 = false>
 static void launch_rb(int grid, hipStream_t stream, const ResBlockParams* dparams) {
+#ifdef VFX_RB_EXTRA_LDS  // measurement builds: a larger LDS allocation than the kernel needs (occupancy experiments)
+  const size_t lds = resblock_lds_bytes(C, MT) + VFX_RB_EXTRA_LDS;
+#else
   const size_t lds = resblock_lds_bytes(C, MT);
+#endif
   static uint64_t attr_devices = 0;  // one static per instantiation
   if (first_use_on_current_device(attr_devices)) {
     VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock<C, NW, HI, G2, MT, IN1, SC2>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -762,6 +781,9 @@ void plan_block2d(ResBlockParams& p) {
       p.tile_m = c.TH * c.W1 == 256 ? 256 : 0;
     }
   }
+#ifdef VFX_TIMING
+  p.timing = getenv("VFX_TIMING_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("VFX_TIMING_PTR"), nullptr, 0)) : nullptr;
+#endif
   p.geo2d = 1;
   p.fold = 0;
   p.dil = 1;
@@ -780,6 +802,11 @@ void plan_block2d(ResBlockParams& p) {
   VFX_CHECK(p.P <= MT2 + MT2 / 2 && p.TH * p.W1 == MT2, "block2d: bad tile geometry");
   VFX_CHECK((int64_t)p.B * p.H * p.W * p.C * 4 < ((int64_t)1 << 32) - 4096, "block2d: tensor exceeds 4 GiB");
   VFX_CHECK(!(p.in1 || p.two_src) || p.tile_m == 256, "block2d: entry / two-source block tile");
+  // tile -> (image, tile row, tile column) of the persistent kernel (block2d32.hip), cf. plan_resblock
+  const int64_t tpi = (int64_t)p.tiles_w * p.tiles_h;
+  p.inv_tiles_w = (((uint64_t)1 << 32) + p.tiles_w - 1) / p.tiles_w;
+  p.inv_tiles_per_img = (((uint64_t)1 << 32) + tpi - 1) / tpi;
+  p.recip_ok = (double)p.B * (double)tpi * (double)tpi < 4294967296.0 ? 1 : 0;
 }
 
 // Fills the tile geometry of a fused ResStack layer (B, T, C, dil must be set).
@@ -897,6 +924,10 @@ void launch_resblock(const ResBlockParams& hp, const ResBlockParams* dparams, hi
     VFX_CHECK(!hp.hionly, "block2d: split-bf16 only");
     // C = 32: two waves of 64 pixels, not four of 32 -- every wave of a block fetches ALL the weight fragments, so fewer,
     // larger waves halve that traffic (measured -12 %; the timing-only build without weight refreshes ran this block 25 % faster)
+    if (block2d32_ok(hp)) {
+      launch_block2d32(hp, dparams, stream);
+      return;
+    }
     if (hp.in1) launch_rb<32, 4, false, true, 256, true>((int)grid, stream, dparams);
     else if (hp.two_src) launch_rb<32, 4, false, true, 256, false, true>((int)grid, stream, dparams);
     else if (hp.C == 32 && hp.tile_m == 256) launch_rb<32, 4, false, true, 256>((int)grid, stream, dparams);

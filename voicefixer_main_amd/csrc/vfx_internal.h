@@ -329,6 +329,7 @@ struct ResBlockParams {
   unsigned inv_pw, inv_w1;
   // ceil(2^32 / n) for n = tiles_w, tiles_w * tiles_h: 33 bits when n = 1 (one tile per image: short sequences) -- div_recip()
   unsigned long long inv_tiles_w, inv_tiles_per_img;
+  int recip_ok;      // plan_block2d: the reciprocal tile split is exact for this launch's tile count
   int patch_rows;    // set by plan_resblock: rows of a patch buffer when they are not tile_m + 64 (resblock_w64.hip: 160)
   int tuning;        // vfx_config.tuning of the handle: which kernel family runs the layer (plan_resblock)
   // Batches of clips of unequal length (cf. TapConvParams::lens): clip b's sequence ends at lens[b] * lens_mul positions; T stays
@@ -370,6 +371,8 @@ void launch_splitk_reduce(const TapConvParams& hp, hipStream_t stream);  // hp: 
 void build_stages(const TapConvParams& p, const float* ones, const float* zeros, ConvStage* out);  // p: absolute pointers
 void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
 int conv_block_n(const TapConvParams& hp);
+bool block2d32_ok(const ResBlockParams& hp);  // block2d32.hip
+void launch_block2d32(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 bool upsample16_ok(const TapConvParams& hp);  // upsample16.hip
 void launch_upsample16(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
 double conv_flops(const TapConvParams& hp);
