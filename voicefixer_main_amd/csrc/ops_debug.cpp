@@ -484,6 +484,21 @@ extern "C" int vfx_op_block2d(vfx_handle* h, const float* x, int B, int H, int W
   ResBlockParams* d = static_cast<ResBlockParams*>(sc.blob.alloc(sizeof(ResBlockParams)));
   VFX_HIP(hipMemcpy(d, &rp, sizeof(rp), hipMemcpyHostToDevice));
   launch_resblock(rp, d, s);
+  if (const char* reps = getenv("VFX_OP_REPS")) {  // measurement aid: the same launch N more times between two events, average on stderr
+    const int n = atoi(reps);
+    hipEvent_t e0, e1;
+    VFX_HIP(hipEventCreate(&e0));
+    VFX_HIP(hipEventCreate(&e1));
+    VFX_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < n; ++i) launch_resblock(rp, d, s);
+    VFX_HIP(hipEventRecord(e1, s));
+    VFX_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    VFX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    fprintf(stderr, "[vfx_op_block2d] %d launches: %.2f us each\n", n, 1000.0 * ms / (n > 0 ? n : 1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
   VFX_HIP(hipStreamSynchronize(s));
   } catch (const vfx::Error&) {
     return 1;
