@@ -597,8 +597,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_resblock_rw(const ResBlockParams
 // Measured and NOT kept (profiles/r06_c4_voc_layers_store_pairing_and_nt_losers.txt, same box, alternating): pairing the two 32-byte
 // pieces a lane pair holds of a row with those of the pixel 16 lanes away (v_permlane16_swap: two stores of 64 bytes of 16 rows each
 // instead of two of 32 bytes of all 32 rows) -- singles 2.34-2.38 -> 2.85 ms; the same with non-temporal stores (aux = 2): 2.95 ms.
-template <bool PAIR, int HALO = 64>
+template <bool PAIR, int HALO = 64, bool DOWN = false>
 __global__ __launch_bounds__(512, 2) void k_resblock_rw16(const ResBlockParams* __restrict__ pp, int ntiles, int per_block) {
+  static_assert(!(PAIR && DOWN), "pairs have no folded tiles");
   constexpr int C = 64, NW = 8, NTHR = NW * 64, WM = 2, MT = 256, PR = MT + HALO;
   constexpr int RQ = NTHR / 8;              // rows per load group: 8 lanes x 16 bytes = one 128-byte row of the fp16 trunk
   constexpr int NCQ = MT / RQ;              // centre loads per thread (4)
@@ -706,15 +707,34 @@ __global__ __launch_bounds__(512, 2) void k_resblock_rw16(const ResBlockParams* 
 
   // ---- tile cursor: (img, ti, tj) of the current tile and of the next one, advanced by increments -------------------------------------
   const int t_begin = blockIdx.x * per_block, t_end = min(t_begin + per_block, ntiles);
+  // Folded layers walk DOWN the columns of tiles (tile row fastest): a 4 x 63 h tile reads 6 rows of d samples, two of them the rows the
+  // tile above it read one tile earlier -- walked along the rows (35-odd tiles between vertical neighbours, ~50 MB through a 4 MB L2) every
+  // tile fetched all six from HBM: 1.27-1.37 GB read per layer for a 0.91 GB tensor (PMC, profiles/r06_pmc.txt).
+  constexpr bool down = DOWN;  // (a template argument: a run-time flag is three registers the 256-register singles do not have)
   int img = 0, ti = 0, tj = 0;
   if (t_begin < t_end) {
-    tj = t_begin % tiles_w;
-    const int r = t_begin / tiles_w;
-    ti = r % tiles_h;
-    img = r / tiles_h;
+    if (down) {
+      ti = t_begin % tiles_h;
+      const int r = t_begin / tiles_h;
+      tj = r % tiles_w;
+      img = r / tiles_w;
+    } else {
+      tj = t_begin % tiles_w;
+      const int r = t_begin / tiles_w;
+      ti = r % tiles_h;
+      img = r / tiles_h;
+    }
   }
   auto advance = [&](int& im, int& i, int& j) __attribute__((always_inline)) {
-    if (++j == tiles_w) {
+    if (down) {
+      if (++i == tiles_h) {
+        i = 0;
+        if (++j == tiles_w) {
+          j = 0;
+          ++im;
+        }
+      }
+    } else if (++j == tiles_w) {
       j = 0;
       if (++i == tiles_h) {
         i = 0;
@@ -1008,8 +1028,8 @@ int cu_count_of_current_device() {
   return cus[dev];
 }
 
-template <bool PAIR, int HALO = 64>
-static void launch_rw16(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {
+template <bool PAIR, int HALO = 64, bool DOWN = false>
+static void launch_rw16(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {  // DOWN: see the tile cursor
   constexpr int MT = 256;
   // the layout of k_resblock_rw<8, PAIR, true, HALO>: the two operand regions, the raw rows (singles: a third region), the biases,
   // a pair's three sets of weight fragments
@@ -1019,9 +1039,9 @@ static void launch_rw16(const ResBlockParams* dparams, int64_t ntiles, hipStream
   const int grid = (int)((ntiles + per_block - 1) / per_block);
   static uint64_t attr_devices = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_rw16<PAIR, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resblock_rw16<PAIR, HALO, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_resblock_rw16<PAIR, HALO>), dim3(grid), dim3(512), lds, stream, dparams, (int)ntiles, per_block);
+  hipLaunchKernelGGL((k_resblock_rw16<PAIR, HALO, DOWN>), dim3(grid), dim3(512), lds, stream, dparams, (int)ntiles, per_block);
 }
 
 template <int NW, bool PAIR, bool X16, int HALO = 64>
@@ -1063,7 +1083,12 @@ void launch_resblock_rw(const ResBlockParams& hp, const ResBlockParams* dparams,
     else launch_rw<8, true, false>(dparams, ntiles, stream);
   } else if (hp.tile_m == 256) {
     VFX_CHECK(hp.patch_rows == 0 || (hp.patch_rows == 256 + 128 && hp.x16 && hp.fold), "resblock_rw: bad patch geometry");
+#ifdef VFX_RW16_ROWMAJOR  // measurement builds: folded tiles walked along the rows, as before
     if (hp.x16 && hp.patch_rows && !kOldRw16) launch_rw16<false, 128>(dparams, ntiles, stream);
+#else
+    if (hp.x16 && hp.patch_rows && !kOldRw16) launch_rw16<false, 128, true>(dparams, ntiles, stream);  // (the wide tiles are folded ones)
+    else if (hp.x16 && hp.fold && !kOldRw16) launch_rw16<false, 64, true>(dparams, ntiles, stream);
+#endif
     else if (hp.x16 && !kOldRw16) launch_rw16<false>(dparams, ntiles, stream);
     else if (hp.x16 && hp.patch_rows) launch_rw<8, false, true, 128>(dparams, ntiles, stream);
     else if (hp.x16) launch_rw<8, false, true>(dparams, ntiles, stream);
