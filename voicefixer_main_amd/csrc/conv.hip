@@ -536,6 +536,21 @@ static bool launch_ablated(int abl, int grid, hipStream_t stream, const TapConvP
     default: return false;
   }
 }
+// the same for the 16-bit launches on activated fp16 sources (H64: the C = 512 stack, the wide upsamplers, the condnet)
+template <bool RA>
+static bool launch_ablated_h64(int abl, int grid, hipStream_t stream, const TapConvParams* dparams) {
+  switch (abl) {
+    case 1: launch_one<128, false, true, 1, 2, true, true, RA>(grid, stream, dparams); return true;
+    case 2: launch_one<128, false, true, 2, 2, true, true, RA>(grid, stream, dparams); return true;
+    case 4: launch_one<128, false, true, 4, 2, true, true, RA>(grid, stream, dparams); return true;
+    case 7: launch_one<128, false, true, 7, 2, true, true, RA>(grid, stream, dparams); return true;
+    case 16: launch_one<128, false, true, 16, 2, true, true, RA>(grid, stream, dparams); return true;
+    case 32: launch_one<128, false, true, 32, 2, true, true, RA>(grid, stream, dparams); return true;
+    case 64: launch_one<128, false, true, 64, 2, true, true, RA>(grid, stream, dparams); return true;
+    case 68: launch_one<128, false, true, 68, 2, true, true, RA>(grid, stream, dparams); return true;
+    default: return false;
+  }
+}
 #endif
 
 template <bool ELU, bool SPLIT, bool HI = false, bool H64 = false, bool RA = false, bool VL = false>
@@ -604,6 +619,9 @@ void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStrea
     VFX_CHECK(!hp.residual_act || n_act, "conv: an activated residual goes with activated sources");
     if (n_act) {
       VFX_CHECK(!elu, "conv: an activated source has no prologue");
+#ifdef VFX_ABLATION_BUILD
+      if (abl && BN == 128 && !vl && (hp.residual_act ? launch_ablated_h64<true>(abl, (int)grid, stream, dparams) : launch_ablated_h64<false>(abl, (int)grid, stream, dparams))) return;
+#endif
       if (hp.residual_act) launch_vl<true, true, true, true>(vl, false, BN, (int)grid, stream, dparams);
       else launch_vl<true, true, true>(vl, false, BN, (int)grid, stream, dparams);
     } else {
