@@ -580,7 +580,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
             const auto s0 = __builtin_amdgcn_permlane32_swap(pack_f16x2_sat16(v[0][0], v[0][1], true, sat16), pack_f16x2_sat16(v[1][0], v[1][1], true, sat16), false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(pack_f16x2_sat16(v[0][2], v[0][3], true, sat16), pack_f16x2_sat16(v[1][2], v[1][3], true, sat16), false, false);
             const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+#ifdef VFX_ABL_NOSTORE  // timing-only build (wrong results): what the direct stores cost
+            asm volatile("" : : "v"(w));
+#else
             __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+#endif
           }
           if (have_ya) {  // last layer of the stack: also the activated fp16 form for the upsampler that follows
             unsigned q2[2][2];
@@ -595,7 +599,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
             const auto s0 = __builtin_amdgcn_permlane32_swap(q2[0][0], q2[1][0], false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(q2[0][1], q2[1][1], false, false);
             const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+#ifdef VFX_ABL_NOSTORE  // timing-only build (wrong results): what the direct stores cost
+            asm volatile("" : : "v"(w));
+#else
             __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+#endif
           }
         }
       }

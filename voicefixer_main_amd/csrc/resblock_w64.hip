@@ -389,7 +389,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_w64(const ResBlockParams* _
           const auto s0 = __builtin_amdgcn_permlane32_swap(q[0][0], q[1][0], false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(q[0][1], q[1][1], false, false);
           const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+#ifdef VFX_ABL_NOSTORE  // timing-only build (wrong results): what the direct stores cost
+          asm volatile("" : : "v"(w));
+#else
           __builtin_amdgcn_raw_buffer_store_b128(w, rya, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+#endif
         }
       }
     }

@@ -166,7 +166,11 @@ __global__ __launch_bounds__(256) void k_up16(const TapConvParams* __restrict__ 
         const auto s0 = __builtin_amdgcn_permlane32_swap(q2[0][0], q2[1][0], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(q2[0][1], q2[1][1], false, false);
         const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+#ifdef VFX_ABL_NOSTORE  // timing-only build (wrong results): what the direct stores cost
+        asm volatile("" : : "v"(w));
+#else
         __builtin_amdgcn_raw_buffer_store_b128(w, ro, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+#endif
       }
     }
   }
