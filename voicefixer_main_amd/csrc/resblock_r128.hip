@@ -554,6 +554,16 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
     const bool have_y = p.y != nullptr, have_ya = p.ya != nullptr;
     int l31e = l31, lhe = lh;
     asm volatile("" : "+v"(l31e), "+v"(lhe));  // the epilogue's index math stays behind the last conv2
+#ifndef VFX_R128_DIRECT_STORES
+    // Round 6: y leaves in FULL 128-byte lines.  Stored straight from the MFMA layout a 16-byte store instruction touches 32 rows with
+    // 32 bytes each (it writes at 0.65-0.73 of the full-line rate, profiles/r06_c50_direct_store_cost.txt, and the epilogue of this
+    // kernel is store-issue-bound: 5.7 k of a block's 27 k cycles).  A wave owns 64 couts = one whole line of each of its 64 positions:
+    // it turns its tile through a PRIVATE 9 KB slice of the dead h / patch buffers (144-byte rows: conflict-free column writes) -- one
+    // block barrier (every wave is done reading h), no second one.
+    constexpr int SROW = 144;
+    const int sbase = wave_u * (64 * SROW);
+    if (have_y) __syncthreads();
+#endif
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
       const int ch = 2 * wn + n;
@@ -582,8 +592,10 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
             const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
 #ifdef VFX_ABL_NOSTORE  // timing-only build (wrong results): what the direct stores cost
             asm volatile("" : : "v"(w));
-#else
+#elif defined(VFX_R128_DIRECT_STORES)
             __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)(rowoff + (unsigned)(16 * jp)), 0, 0);
+#else
+            *reinterpret_cast<u32x4*>(lds + sbase + (a * 32 + l31e) * SROW + n * 64 + 16 * lhe + 16 * jp) = w;
 #endif
           }
           if (have_ya) {  // last layer of the stack: also the activated fp16 form for the upsampler that follows
@@ -608,6 +620,23 @@ __global__ __launch_bounds__(256, 2) void k_resblock_r128(const ResBlockParams* 
         }
       }
     }
+#if !defined(VFX_R128_DIRECT_STORES) && !defined(VFX_ABL_NOSTORE)
+    if (have_y) {
+      const int srow = lane >> 3, piece = lane & 7;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = srow + 8 * q;  // this wave's position `row` of 64
+        const u32x4 w = *reinterpret_cast<const u32x4*>(lds + sbase + row * SROW + 16 * piece);
+        const int m = wm * 64 + row;
+        const int li = (int)(((unsigned)m * inv_w1) >> 20), lj = m - li * W1;
+        const int pos = PAIR ? base_h + m : base_h + li * rowstride + lj;
+        const bool ok = PAIR ? ((m >= 2 + d2) & (m <= MT - 3 - d2))
+                             : ((li < TH) & (lj >= 1) & (lj <= W1 - 2) & (!p.fold | (j0 + lj - 1 < d)));
+        const unsigned off = ok ? (unsigned)pos * (unsigned)(C * 2) + (unsigned)(wn * 128 + 16 * piece) : kOob;
+        __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)off, 0, 0);
+      }
+    }
+#endif
     report_f16_saturation(f16_sat16_bad(sat16), p.flags);
   } else
   // ---- y = conv2 + b2 + residual: whole staged rows read back, the kept rows (x; a pair: y1) added, stored --------------------------
