@@ -33,13 +33,31 @@ namespace vfx {
 
 namespace b2d {
 constexpr int PIX = 144;            // LDS bytes per pixel: [32 hi bf16 | 32 lo bf16 | 16 pad]
-constexpr int PITCH = 2816;         // LDS bytes per patch row (18 pixels = 2 592, rounded up to a multiple of 256)
-constexpr int PATCH_BYTES = 18 * PITCH;   // 50 688
-constexpr int HOFF = 17 * PIX;      // the h grid (256 pixels, PIX bytes each) overlays the patch; 17 pixels of slack either side: conv2's
-                                    // taps of the grid's border pixels read (finite or not) bytes that only feed outputs nobody stores
-constexpr int BN_OFF = PATCH_BYTES;       // bn1 scale, bn1 shift, bn2 scale, bn2 shift: 32 floats each
-constexpr int LDS_BYTES = PATCH_BYTES + 512;
-constexpr int NQ = 11;              // patch pixels per thread: pixel lr + 32 q, 324 = 10 x 32 + 4
+// Geometry of a tile: an h grid of TH x W1 <= 256 pixels (16 x 16, or 14 x 18: 12 x 16 outputs divide the 128 mel bins of level 1 without a
+// remainder -- 680 tiles per image instead of 730), outputs = its interior, patch (TH + 2) x (W1 + 2).
+template <int TH, int W1>
+struct Geo {
+  static constexpr int OH = TH - 2, OW = W1 - 2, PH = TH + 2, PW = W1 + 2, NPIX = PH * PW;
+  static constexpr int NQ = (NPIX + 31) / 32;          // patch pixels per thread: pixel lr + 32 q
+  static constexpr int LASTQ = NPIX - 32 * (NQ - 1);   // pixels of the last q (threads lr < LASTQ)
+  // LDS bytes per patch row: lanes of a ds_read_b128 group are consecutive h pixels ml = W1 li + lj of one or two grid rows; their
+  // 16-byte units li * (PITCH / 16) + 9 lj = 9 ml + li (PITCH / 16 - 9 W1) are distinct mod 16 iff PITCH / 16 = 9 W1 (mod 16)
+  static constexpr int pitch_units() {
+    int u = 9 * PW;
+    while (u % 16 != (9 * W1) % 16) ++u;
+    return u;
+  }
+  static constexpr int PITCH = 16 * pitch_units();     // 2 816 (16 x 16), 3 104 (14 x 18)
+  static constexpr int PATCH_BYTES = PH * PITCH;       // 50 688, 49 664
+  static constexpr int HOFF = (W1 + 1) * PIX;          // the h grid (256 slots of PIX bytes) overlays the patch; W1 + 1 pixels of slack either
+                                                       // side: conv2's taps of the grid's border pixels read bytes that only feed outputs nobody stores
+  static constexpr int BN_OFF = PATCH_BYTES;           // bn1 scale, bn1 shift, bn2 scale, bn2 shift: 32 floats each
+  static constexpr int LDS_BYTES = PATCH_BYTES + 512;
+  // the staged tile: outputs only, rows of 16 slots (OW <= 16), NE x 32 slots + one dummy slot for the lanes that hold no output
+  static constexpr int NE = (OH * 16 + 31) / 32;       // 7, 6: output pieces per thread
+  static_assert(TH * W1 <= 256 && OW <= 16 && HOFF + (256 + W1 + 1) * PIX <= PATCH_BYTES && (NE * 32 + 1) * PIX <= PATCH_BYTES &&
+                    2 * (NE - 1) + 1 <= OH - 1 && LDS_BYTES <= 53248, "tile geometry");
+};
 constexpr unsigned kOob = 0x80000000u;    // a byte offset past every descriptor's num_records: loads return zeros, stores are dropped
 constexpr int kNumRecords = 0x40000000;
 constexpr int RING = 3, AHEAD = RING - 1;
@@ -67,8 +85,11 @@ __device__ __forceinline__ void split_bf16x4(const f32x4 v, uint2& hi, uint2& lo
 #ifndef VFX_B2D_ABL  // timing-only ablations (wrong results): 1 no patch loads, 2 no MFMAs, 4 no stores, 8 no fragment reads, 16 no residual
 #define VFX_B2D_ABL 0  // loads, 32 no LDS writes of the two VALU phases, 64 no barriers
 #endif
+template <int TH, int W1>
 __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockParams* __restrict__ pp, int ntiles) {
   using namespace b2d;
+  using G = Geo<TH, W1>;
+  constexpr int PW = G::PW, NPIX = G::NPIX, NQ = G::NQ, PITCH = G::PITCH, HOFF = G::HOFF, BN_OFF = G::BN_OFF, NE = G::NE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = reinterpret_cast<char*>(smem);
   const ResBlockParams& p = *pp;
@@ -88,37 +109,42 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
   //   LDS offset = (lr + 32 q) * 144 + 8 cg + pi * (PITCH - 18 PIX) = wbase + [constant] + c_q * 224
   unsigned cbits = 0;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) cbits |= (unsigned)((lr + (32 * q) % 18) / 18) << (2 * q);
+  for (int q = 0; q < NQ; ++q) cbits |= (unsigned)((lr + (32 * q) % PW) / PW) << (2 * q);
   const unsigned vbase = (unsigned)lr * 128u + 16u * (unsigned)cg;
   const int wbase = lr * PIX + 8 * cg;
-  const unsigned wd = (unsigned)__builtin_amdgcn_readfirstlane(128 * (Ww - 18));
+  const unsigned wd = (unsigned)__builtin_amdgcn_readfirstlane(128 * (Ww - PW));
   unsigned cb = cbits;  // (re-defined opaquely per tile: otherwise the compiler hoists the eleven offsets out of the tile loop and spills them)
   auto voff = [&](int q) __attribute__((always_inline)) -> unsigned {   // (without the scalar part: xsoff())
     const unsigned v = vbase + ((cb >> (2 * q)) & 3u) * wd;
-    return (q == NQ - 1 && lr >= 4) ? kOob : v;                     // 324 = 10 x 32 + 4 pixels
+    return (q == NQ - 1 && lr >= G::LASTQ) ? kOob : v;              // (16 x 16: 324 = 10 x 32 + 4 pixels)
   };
   auto xsoff = [&](int q) __attribute__((always_inline)) -> int {
-    return __builtin_amdgcn_readfirstlane(q * 4096 + ((32 * q) / 18) * (int)wd);  // (an SGPR operand: without this the compiler parks the
+    return __builtin_amdgcn_readfirstlane(q * 4096 + ((32 * q) / PW) * (int)wd);  // (an SGPR operand: without this the compiler parks the
   };                                                                              // loop-invariant sums in VGPRs and builds waterfall loops)
   auto wr = [&](int q) __attribute__((always_inline)) -> int {
-    return wbase + 32 * q * PIX + ((32 * q) / 18) * (PITCH - 18 * PIX) + (int)((cb >> (2 * q)) & 3u) * (PITCH - 18 * PIX);
+    return wbase + 32 * q * PIX + ((32 * q) / PW) * (PITCH - PW * PIX) + (int)((cb >> (2 * q)) & 3u) * (PITCH - PW * PIX);
   };
   // h pixel of this lane in M block a: ml = wave * 64 + 32 a + l31 = (li, lj) of the 16 x 16 grid
-  int a1[2], a2[2], hw[2];
+  int a1[2], a2[2], hw[2], sw[2];
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    const int ml = wave * 64 + 32 * a + l31, li = ml >> 4, lj = ml & 15;
+    const int ml = wave * 64 + 32 * a + l31;
+    const bool in_grid = ml < TH * W1;              // (14 x 18: slots 252 .. 255 hold no h pixel; they compute on pixel 0 and store nothing)
+    const int li = in_grid ? ml / W1 : 0, lj = in_grid ? ml - li * W1 : 0;
     a1[a] = li * PITCH + lj * PIX + 16 * lh;        // conv1: tap (dy, dx) at + dy * PITCH + dx * PIX, K step s at + 32 s, lo halves at + 64
-    a2[a] = HOFF + (ml - 17) * PIX + 16 * lh;       // conv2: tap (dy, dx) at + (16 dy + dx) * PIX
+    a2[a] = HOFF + (ml - (W1 + 1)) * PIX + 16 * lh; // conv2: tap (dy, dx) at + (W1 dy + dx) * PIX
     hw[a] = HOFF + ml * PIX + 8 * lh;               // h write: channel run j at + 16 j, lo halves at + 64
+    // staged tile: output (oi, oj) = h pixel (oi + 1, oj + 1) at slot 16 oi + oj; the lanes of the grid's border at the dummy slot
+    const bool out = in_grid && li >= 1 && li <= TH - 2 && lj >= 1 && lj <= W1 - 2;
+    sw[a] = (out ? 16 * (li - 1) + (lj - 1) : NE * 32) * PIX + 16 * lh;
   }
   // Epilogue roles (the staged tile leaves through full 128-byte lines, as the patch came in): thread (lr, cg) adds the residual to and
-  // stores piece cg of grid pixels m = lr + 32 q = (li, lj) = ((lr >> 4) + 2 q, lr & 15), q = 0 .. 7 -- outputs are the grid's interior;
-  // h pixel (li, lj) = patch pixel (li + 1, lj + 1): byte offset e0 + q * 256 W from the patch window's first pixel
+  // stores piece cg of the outputs at slots lr + 32 q = (oi, oj) = ((lr >> 4) + 2 q, lr & 15), q = 0 .. NE - 1;
+  // output (oi, oj) = patch pixel (oi + 2, oj + 2): byte offset e0 + q * 256 W from the patch window's first pixel
   const int elj = lr & 15, eli0 = lr >> 4;
-  const unsigned e0 = (elj >= 1 && elj <= 14) ? (unsigned)((eli0 + 1) * Ww + elj + 1) * 128u + 16u * (unsigned)cg : kOob;
+  const unsigned e0 = elj < G::OW ? (unsigned)((eli0 + 2) * Ww + elj + 2) * 128u + 16u * (unsigned)cg : kOob;
   const int erow = __builtin_amdgcn_readfirstlane(256 * Ww);
-  const int srd = lr * PIX + 16 * cg;   // staged tile: pixel m at m * PIX (over h: every wave has passed the barrier behind conv2)
+  const int srd = lr * PIX + 16 * cg;   // staged tile: slot n at n * PIX (over h: every wave has passed the barrier behind conv2)
   if (tid < 32) {  // the folded BatchNorm affines: bn1 scale | bn1 shift | bn2 scale | bn2 shift, 32 floats each
     const float* src = tid < 8 ? p.sc1 : (tid < 16 ? p.sh1 : (tid < 24 ? p.sc2 : p.sh2));
     *reinterpret_cast<f32x4*>(lds + BN_OFF + 16 * tid) = *(const VFX_GLOBAL f32x4*)(src + 4 * (tid & 7));
@@ -168,10 +194,10 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
     const int img = div_recip(tile, p.inv_tiles_per_img);
     const int rem = tile - img * tpi;
     const int ti = div_recip(rem, p.inv_tiles_w), tj = rem - ti * p.tiles_w;
-    const int i0 = ti * 14, j0 = tj * 14;
+    const int i0 = ti * G::OH, j0 = tj * G::OW;
     ti0 = i0;
     tj0 = j0;
-    border = (i0 < 2) | (i0 + 16 > Hh) | (j0 < 2) | (j0 + 16 > Ww);
+    border = (i0 < 2) | (i0 + TH > Hh) | (j0 < 2) | (j0 + W1 > Ww);
     const int64_t px = ((int64_t)img * Hh + (i0 - 2)) * Ww + (j0 - 2);  // first pixel of the patch window (may lie outside the tensor)
     rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + px * 32, 0, kNumRecords, 0x00020000);
     ry = __builtin_amdgcn_make_buffer_rsrc(p.y + px * 32, 0, kNumRecords, 0x00020000);
@@ -180,8 +206,8 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int prow = lr + 32 * q;
-        const int pi = prow / 18, pj = prow - pi * 18;
-        const bool ok = (prow < 324) & ((unsigned)(i0 - 2 + pi) < (unsigned)Hh) & ((unsigned)(j0 - 2 + pj) < (unsigned)Ww);
+        const int pi = prow / PW, pj = prow - pi * PW;
+        const bool ok = (prow < NPIX) & ((unsigned)(i0 - 2 + pi) < (unsigned)Hh) & ((unsigned)(j0 - 2 + pj) < (unsigned)Ww);
         okbits |= ok ? (1u << q) : 0u;
       }
 #pragma unroll
@@ -190,7 +216,7 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((okbits & (1u << q)) ? voff(q) : kOob), xsoff(q), 0));
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const int ml = wave * 64 + 32 * a + l31, li = ml >> 4, lj = ml & 15;
+        const int ml = wave * 64 + 32 * a + l31, li = ml / W1, lj = ml - li * W1;
         const bool in = ((unsigned)(i0 - 1 + li) < (unsigned)Hh) & ((unsigned)(j0 - 1 + lj) < (unsigned)Ww);
         okbits |= in ? (1u << (16 + a)) : 0u;
       }
@@ -204,17 +230,13 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
   };
 
   f32x16 acc[2];
-  f32x4 res[8];     // the residual: x at this thread's output pieces (epilogue roles), requested late in conv2
+  f32x4 res[NE];    // the residual: x at this thread's output pieces (epilogue roles), requested late in conv2
   // byte offset of output piece q (without the scalar part q * erow), out of range where nothing is stored
   auto eoff = [&](int q, bool brd) __attribute__((always_inline)) -> unsigned {
-    unsigned v = e0;
-    if (q == 0) v = eli0 >= 1 ? v : kOob;   // grid row 0
-    if (q == 7) v = eli0 == 0 ? v : kOob;   // grid row 15
-    // the image bounds, on every tile (two compares; a branch on `brd` here made hipcc 7.2 emit two-path code around every second
-    // load whose results came back wrong in the first dword of some lanes -- scripts/b2d_check.py, profiles/r06_c37_*)
+    // the image bounds, on every tile (two compares; a branch on `brd` here made hipcc 7.2 emit two-path code around every second load)
     (void)brd;
-    const bool in = (ti0 - 1 + eli0 + 2 * q < Hh) & (tj0 - 1 + elj < Ww);
-    return in ? v : kOob;
+    const bool in = (ti0 + eli0 + 2 * q < Hh) & (tj0 + elj < Ww);
+    return in ? e0 : kOob;
   };
   // One convolution: nine taps of the LDS image behind `base[a]`; tap (dy, dx) sits `dyb` bytes per row and PIX bytes per column further
   // on.  18 K steps (tap k, channels 16 s .. 16 s + 15) of four fragment reads and six MFMAs; the reads of step i + 1 are issued
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
       if (sidx == 0 && g0 + k + AHEAD < 18) fetch(g0 + k + AHEAD);  // (the next tile's first taps come with its patch: begin_tile)
       if (SECOND && i == kResStep) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < NE; ++q)
           if (VFX_B2D_ABL & 16) asm volatile("" : "=v"(res[q]));
           else res[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)eoff(q, border), q * erow, 0));
       }
@@ -290,7 +312,7 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
       }
       uint2 hi, lo;
       split_bf16x4(v, hi, lo);
-      if (q < NQ - 1 || lr < 4) {  // (q = 10: the window's last four pixels)
+      if (q < NQ - 1 || lr < G::LASTQ) {  // (16 x 16, q = 10: the window's last four pixels)
         const int w = wr(q);
         if (VFX_B2D_ABL & 32) {
           asm volatile("" : : "v"(hi), "v"(lo), "v"(w));
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
     else hwrite(std::false_type{});
     B2D_TS(3);
     B2D_BARRIER();  // h is complete
-    conv(a2, 16 * PIX, 9, std::true_type{});
+    conv(a2, W1 * PIX, 9, std::true_type{});
     B2D_TS(4);
     // ---- y = conv2 + x: the tile is staged in LDS (pixel-major, PIX bytes per pixel) and leaves in full 128-byte lines ----------------------
     // (stored straight from the MFMA layout every instruction touches 32 lines with 32 bytes each: measured, profiles/r06_c31_*: the
@@ -364,11 +386,10 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(lds + hw[a] - HOFF + 8 * lh + 32 * j) =
-            f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
+        *reinterpret_cast<f32x4*>(lds + sw[a] + 32 * j) = f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
     B2D_BARRIER();  // the tile is staged
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < NE; ++q) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(lds + srd + 32 * q * PIX) + res[q];
       if (VFX_B2D_ABL & 4) asm volatile("" : : "v"(v));
       else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, (int)eoff(q, border_now), q * erow, 0);
@@ -412,14 +433,16 @@ bool block2d32_ok(const ResBlockParams& hp) {
   return hp.geo2d && hp.C == 32 && hp.tile_m == 256 && !hp.in1 && !hp.two_src && !hp.hionly && !(hp.tuning & VFX_TUNE_OLD_BLOCK2D) &&
          hp.recip_ok && hp.W <= 4096 && hp.H <= 65536;
 }
+// the 14 x 18 h grid (12 x 16 outputs) exists in this kernel only: plan_block2d may choose it where block2d32_ok() will hold
+bool block2d32_has_tile(int TH, int W1) { return (TH == 16 && W1 == 16) || (TH == 14 && W1 == 18); }
 
-void launch_block2d32(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
-  const int64_t ntiles = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
-  VFX_CHECK(ntiles > 0 && ntiles < ((int64_t)1 << 31), "block2d32: bad tile count");
-  static uint64_t attr_devices = 0;
+template <int TH, int W1>
+static void launch_b2d_t(const ResBlockParams* dparams, int64_t ntiles, hipStream_t stream) {
+  using G = b2d::Geo<TH, W1>;
+  static uint64_t attr_devices = 0;  // one static per instantiation
   static int ncu = 0;
   if (first_use_on_current_device(attr_devices)) {
-    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_block2d32), hipFuncAttributeMaxDynamicSharedMemorySize, b2d::LDS_BYTES));
+    VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_block2d32<TH, W1>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     int dev = 0;
     VFX_HIP(hipGetDevice(&dev));
     VFX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -429,10 +452,18 @@ void launch_block2d32(const ResBlockParams& hp, const ResBlockParams* dparams, h
   grid = std::min<int64_t>(grid, ((ntiles + 7) / 8) * 8);
   grid = std::max<int64_t>(8, grid & ~(int64_t)7);
 #ifdef VFX_B2D_FAKE_LDS  // measurement builds: a smaller LDS allocation than the kernel addresses (wrong results; occupancy experiments)
-  hipLaunchKernelGGL(k_block2d32, dim3((unsigned)grid), dim3(256), VFX_B2D_FAKE_LDS, stream, dparams, (int)ntiles);
+  hipLaunchKernelGGL((k_block2d32<TH, W1>), dim3((unsigned)grid), dim3(256), VFX_B2D_FAKE_LDS, stream, dparams, (int)ntiles);
 #else
-  hipLaunchKernelGGL(k_block2d32, dim3((unsigned)grid), dim3(256), b2d::LDS_BYTES, stream, dparams, (int)ntiles);
+  hipLaunchKernelGGL((k_block2d32<TH, W1>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, stream, dparams, (int)ntiles);
 #endif
+}
+
+void launch_block2d32(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream) {
+  const int64_t ntiles = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
+  VFX_CHECK(ntiles > 0 && ntiles < ((int64_t)1 << 31), "block2d32: bad tile count");
+  VFX_CHECK(block2d32_has_tile(hp.TH, hp.W1), "block2d32: no kernel for a %d x %d h grid", hp.TH, hp.W1);
+  if (hp.TH == 14) launch_b2d_t<14, 18>(dparams, ntiles, stream);
+  else launch_b2d_t<16, 16>(dparams, ntiles, stream);
   VFX_HIP(hipGetLastError());
 }
 

@@ -766,19 +766,26 @@ void plan_block2d(ResBlockParams& p) {
   struct Cand { int TH, W1; };
   std::vector<Cand> cands = {{8, 16}, {16, 8}};
   if (p.C == 32 && !(p.tuning & VFX_TUNE_SMALL_2D_TILES)) cands.push_back({16, 16});
+  // 14 x 18 (12 x 16 outputs; round 6): in the persistent kernel only (block2d32.hip) -- 128 mel bins are 8 tile columns instead of 10
+  if (p.C == 32 && !(p.tuning & (VFX_TUNE_SMALL_2D_TILES | VFX_TUNE_OLD_BLOCK2D)) && !p.in1 && !p.two_src && !p.hionly && p.W <= 4096 &&
+      p.H <= 65536) {
+    const double tpi = (double)((p.H + 11) / 12) * ((p.W + 15) / 16);
+    if ((double)p.B * tpi * tpi < 4294967296.0) cands.push_back({14, 18});  // (block2d32_ok: the reciprocal tile split must be exact)
+  }
   if (p.in1 || p.two_src) {  // the entry block (Cin = 1) and the two-source block exist on 16 x 16 tiles only
     VFX_CHECK(p.C == 32 && !(p.tuning & VFX_TUNE_SMALL_2D_TILES), "block2d: the entry / two-source block runs C = 32 on 16 x 16 tiles");
     cands = {{16, 16}};
   }
   for (const Cand& c : cands) {
     const int oh = c.TH - 2, ow = c.W1 - 2;
-    const double positions = (double)((p.H + oh - 1) / oh) * ((p.W + ow - 1) / ow) * c.TH * c.W1;  // h positions computed
+    const int slots = c.TH * c.W1 > CBM ? 256 : CBM;  // (a 14 x 18 tile costs what a 16 x 16 tile costs)
+    const double positions = (double)((p.H + oh - 1) / oh) * ((p.W + ow - 1) / ow) * slots;  // h positions computed
     const double util = (double)p.H * p.W / positions;
     if (util > best) {
       best = util;
       p.W1 = c.W1;
       p.TH = c.TH;
-      p.tile_m = c.TH * c.W1 == 256 ? 256 : 0;
+      p.tile_m = slots == 256 ? 256 : 0;
     }
   }
 #ifdef VFX_TIMING
@@ -799,7 +806,7 @@ void plan_block2d(ResBlockParams& p) {
       p.hoff9[dy * 3 + dx] = (dy - 1) * p.W1 + (dx - 1);    // conv2: h rows
     }
   const int MT2 = p.tile_m == 256 ? 256 : CBM;
-  VFX_CHECK(p.P <= MT2 + MT2 / 2 && p.TH * p.W1 == MT2, "block2d: bad tile geometry");
+  VFX_CHECK(p.P <= MT2 + MT2 / 2 && (p.TH * p.W1 == MT2 || (p.TH == 14 && p.W1 == 18 && MT2 == 256)), "block2d: bad tile geometry");
   VFX_CHECK((int64_t)p.B * p.H * p.W * p.C * 4 < ((int64_t)1 << 32) - 4096, "block2d: tensor exceeds 4 GiB");
   VFX_CHECK(!(p.in1 || p.two_src) || p.tile_m == 256, "block2d: entry / two-source block tile");
   // tile -> (image, tile row, tile column) of the persistent kernel (block2d32.hip), cf. plan_resblock

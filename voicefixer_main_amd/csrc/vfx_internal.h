@@ -372,6 +372,7 @@ void build_stages(const TapConvParams& p, const float* ones, const float* zeros,
 void launch_conv(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
 int conv_block_n(const TapConvParams& hp);
 bool block2d32_ok(const ResBlockParams& hp);  // block2d32.hip
+bool block2d32_has_tile(int TH, int W1);
 void launch_block2d32(const ResBlockParams& hp, const ResBlockParams* dparams, hipStream_t stream);
 bool upsample16_ok(const TapConvParams& hp);  // upsample16.hip
 void launch_upsample16(const TapConvParams& hp, const TapConvParams* dparams, hipStream_t stream);
