@@ -27,6 +27,23 @@ def test_resunet_mel_vs_oracle(engine, unet_sd, B, T):
     assert engine.take_flags() == 0
 
 
+def test_resunet_mel_same_bits_on_either_level_1_block_kernel(unet_sd):
+    """The whole mel ResUNet with the persistent C = 32 block kernel (k_block2d32: 14 x 18 h tiles at 128 mel bins) and with
+    k_resblock's 16 x 16 form (VFX_TUNE_OLD_BLOCK2D): same products summed in the same order per pixel, whatever the tiling --
+    the outputs are equal bit for bit, on a batch with a dozen tiles per persistent block (40 clips of 333 frames)."""
+    from voicefixer_main_amd import _lib
+    from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL
+    mel = torch.from_numpy(_mel_input(40, 333, seed=7)[:, 0])
+    outs = []
+    for tuning in (0, _lib.TUNE_OLD_BLOCK2D):
+        eng = Engine("cuda:0", config={"precision": 1, "tuning": tuning})
+        eng.load_state_dict(MODEL_UNET_MEL, unet_sd)
+        outs.append(eng.resunet_mel(mel).cpu())
+        assert eng.take_flags() == 0
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+
+
 def test_resunet_negative_input_flag(engine):
     mel = _mel_input(1, 64)
     mel[0, 0, 3, 5] = -1.0
