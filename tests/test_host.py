@@ -479,6 +479,28 @@ def test_length_bucketing_in_a_world_of_one():
     assert vdist.restore_sharded_lengths(eng, [], torch.device("cpu")) == []
 
 
+def test_store_hazard_checker_sees_the_pattern(tmp_path):
+    """scripts/asm_store_hazard_check.py on hand-written assembly: a 16-byte buffer store with a register soffset followed at once by a
+    VALU write of its data registers is reported; with an s_nop in between, with an immediate soffset, with a VALU write of other
+    registers, or with an 8-byte store it is not (profiles/r06_store_data_hazard.md)."""
+    import subprocess
+    head = "\n_ZN3vfx6k_testEv: ; @k\n"
+    cases = {
+        "hit": ("buffer_store_dwordx4 v[0:3], v9, s[16:19], s79 offen\n v_pk_add_f32 v[0:1], v[4:5], v[60:61]\n", 1),
+        "hit_x3": ("buffer_store_dwordx3 v[4:6], v9, s[16:19], s2 offen offset:16\n v_mov_b32_e32 v5, v1\n", 1),
+        "nop": ("buffer_store_dwordx4 v[0:3], v9, s[16:19], s79 offen\n s_nop 1\n v_pk_add_f32 v[0:1], v[4:5], v[60:61]\n", 0),
+        "imm": ("buffer_store_dwordx4 v[0:3], v9, s[16:19], 0 offen\n v_pk_add_f32 v[0:1], v[4:5], v[60:61]\n", 0),
+        "other_regs": ("buffer_store_dwordx4 v[0:3], v9, s[16:19], s79 offen\n v_pk_add_f32 v[4:5], v[4:5], v[60:61]\n", 0),
+        "x2": ("buffer_store_dwordx2 v[0:1], v9, s[16:19], s79 offen\n v_mov_b32_e32 v0, v1\n", 0),
+    }
+    for name, (body, hits) in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text(head + body + " s_endpgm\n")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "asm_store_hazard_check.py"), str(f)], capture_output=True, text=True)
+        assert r.returncode == (1 if hits else 0), (name, r.stdout)
+        assert ("%d unfenced" % hits) in r.stdout, (name, r.stdout)
+
+
 def test_no_compiler_touch_of_inflight_weight_registers(tmp_path):
     """The convolution kernels load weight fragments with inline-asm global loads and hand-counted s_waitcnt; a
     compiler-generated copy of such a register before its wait reads stale data (a bug that only shows when the
