@@ -56,7 +56,7 @@ for l in open('$O/same_box_ab.jsonl'):
     lib) local v=${rest%%:*}; ( export VFX_LIB_PATH=voicefixer_main_amd/abl/libvfx_$v.so; run_step "${rest#*:}" ) ;;
     handler) timeout 300 python scripts/bench_handler.py $(args "$rest") > $O/handler.json 2> $O/handler.err; cut -c1-400 $O/handler.json; tail -n 2 $O/handler.err ;;
     varlen) timeout 600 python scripts/bench_varlen.py $(args "$rest") > $O/varlen.json 2> $O/varlen.err; cut -c1-600 $O/varlen.json; tail -n 2 $O/varlen.err ;;
-    unet) timeout 200 python scripts/unet_time.py "${VFX_LIB_PATH:-$tag}" --reps=10 --json=$O/unet.jsonl $(args "$rest") 2>&1 | grep "==" ;;
+    unet) timeout 200 python scripts/unet_time.py "${VFX_LIB_PATH:-$tag}" --reps=10 --json=$O/unet.jsonl $(args "$rest") 2>&1 | grep -v "^\s*$" | tee -a $O/unet.txt | tail -n 70 ;;
     voc) timeout 300 python scripts/voc_layers.py $(args "$rest") >> $O/voc_layers.txt 2>&1; tail -n 45 $O/voc_layers.txt ;;
     prof) ( cd /tmp; export TMPDIR=/tmp; timeout 400 rocprofv3 --kernel-trace --stats -d "$ROOT/$O/prof" -o $tag -- \
               python "$ROOT/bench.py" --steps 5 --warmup 2 --no-alt --no-aux --cpu-baseline-clips 0 --traffic off --no-parity $(args "$rest") > "$ROOT/$O/prof.log" 2>&1; echo "prof rc=$?" )

@@ -2,9 +2,15 @@
 """Time the mel ResUNet alone at the benched shape (16 x 1001 frames), HIP events, median of the repeats -- the A/B harness of
 the ResUNet-side experiments (VFX_LIB_PATH = a variant library, --tuning=MASK).
 
-    [VFX_LIB_PATH=...] python scripts/unet_time.py TAG [--reps=10] [--tuning=0] [--json=out.jsonl]
+    [VFX_LIB_PATH=...] python scripts/unet_time.py TAG [--reps=10] [--tuning=0] [--json=out.jsonl] [--layers]
+
+--layers: after the timing, HIP events around every GEMM-shaped launch of five more calls (VFX_PROFILE_DUMP) and one line per group of
+equal launches (kernel, M, Cout, K, input channels) in plan order: calls per ResUNet pass, median ms of one, ms per pass, TFLOP/s.
 """
+import collections
+import csv
 import json
+import tempfile
 import os
 import sys
 
@@ -40,6 +46,30 @@ def main():
     res = {"tag": tag, "reps": reps, "median_ms": t[len(t) // 2], "min_ms": t[0], "checksum": float(out.double().abs().sum().item()),
            "flags": eng.take_flags()}
     print("== %s: mel ResUNet 16 x 1001 frames: median %.3f ms, min %.3f  (checksum %.6e)" % (tag, res["median_ms"], res["min_ms"], res["checksum"]))
+    if "--layers" in sys.argv:
+        n = 5
+        dump = tempfile.NamedTemporaryFile(suffix=".csv", delete=False).name
+        os.environ["VFX_PROFILE_DUMP"] = dump
+        eng.profile_begin()
+        for _ in range(n):
+            eng.resunet_mel(mel)
+        launches, ms, fl = eng.profile_end()
+        rows = list(csv.DictReader(open(dump)))
+        os.unlink(dump)
+        per = collections.OrderedDict()
+        for r in rows:
+            k = (r["kernel"].replace(";", ","), int(r["M"]), int(r["Cout"]), int(r["K"]), int(r["C0"]), int(r["nseg"]))
+            per.setdefault(k, []).append((float(r["ms"]), float(r["tflops"])))
+        print("  %-30s %9s %5s %6s %4s %4s %5s %9s %9s %7s" % ("kernel", "M", "Cout", "K", "C0", "nseg", "calls", "median ms", "ms/pass", "TF"))
+        tot, layers = 0.0, []
+        for (k, M, Cout, K, C0, nseg), v in per.items():
+            tms = sorted(x[0] for x in v)
+            med, calls, per_pass = tms[len(tms) // 2], len(v) // n, sum(tms) / n
+            tot += per_pass
+            print("  %-30s %9d %5d %6d %4d %4d %5d %9.4f %9.3f %7.0f" % (k, M, Cout, K, C0, nseg, calls, med, per_pass, sorted(x[1] for x in v)[len(v) // 2]))
+            layers.append({"kernel": k, "M": M, "Cout": Cout, "K": K, "C0": C0, "nseg": nseg, "calls": calls, "median_ms": med, "ms_per_pass": round(per_pass, 4)})
+        print("  GEMM-shaped launches: %d per pass, %.3f ms per pass (events around each)" % (launches // n, tot))
+        res["layers"] = layers
     j = opt("json", "")
     if j:
         with open(j, "a") as f:

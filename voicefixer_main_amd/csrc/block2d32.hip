@@ -3,26 +3,28 @@
 //
 //     y = x + conv2(lrelu(bn2(conv1(lrelu(bn1(x))))))        3x3 convolutions, split-bf16 operands
 //
-// Same arithmetic and tile as k_resblock<32, 4, false, true, 256> (resblock.hip): h grid of 16 x 16 pixels, 14 x 14 outputs, x patch
-// 18 x 18 pixels, four waves of 64 h pixels x all 32 channels, three blocks per CU.  What is different is what a tile costs in
-// INSTRUCTIONS.  Phase stamps + instruction counts of the old kernel (profiles/r06_c20_block2d_phase_stamps.txt): 1 368 VALU, 297 SALU,
-// 212 LDS and 118 VMEM instructions around 216 MFMAs per tile and wave, block lifetime 36.3 k cycles = 3 waves per SIMD x
-// (1 368 VALU x 4 cycles + 216 MFMAs x 32 cycles): the VALU work does not hide under the MFMAs, it adds to them.  Here:
+// Same arithmetic as k_resblock<32, 4, false, true, 256> (resblock.hip) -- the same products summed in the same order, the residual added
+// last: BIT-IDENTICAL (tests/test_gpu_kernels.py::test_block2d32_equals_the_one_tile_per_block_kernel) -- on an h grid of 16 x 16 pixels
+// (14 x 14 outputs, x patch 18 x 18) or 14 x 18 (12 x 16 outputs, patch 16 x 20), four waves of 64 h pixels x all 32 channels, three blocks
+// per CU.  What is different is what a tile costs in INSTRUCTIONS.  Phase stamps + instruction counts of the old kernel
+// (profiles/r06_c20_block2d_phase_stamps.txt): 1 368 VALU, 297 SALU, 212 LDS and 118 VMEM instructions around 216 MFMAs per tile and
+// wave, block lifetime 36.3 k cycles.  Here:
 //   * blocks are persistent (768 of them walk the tiles): everything that does not depend on the tile -- which patch pixels a thread
 //     stages, where they land in LDS, which LDS rows a lane's fragments come from, where its outputs go -- is computed once per block;
-//     per tile only three buffer descriptors (scalar arithmetic) change;
-//   * LDS rows are PADDED (144 bytes per pixel: 64 of hi halves, 64 of lo halves, 16 unused; patch rows of 2 816 bytes), not swizzled:
-//     pixels whose addresses differ by an odd multiple of 16 bytes (mod 256) never share a bank quad, so the ds_read_b128 lane groups of
-//     gfx950 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: consecutive pixels of two tile rows) are conflict-free without any XOR -- and
-//     every tap, every K step and the hi / lo halves are IMMEDIATE offsets of ONE address register per 32-pixel block.  The two
-//     convolution loops contain no VALU instruction at all;
+//     per tile only two buffer descriptors (scalar arithmetic) change;
+//   * LDS rows are PADDED (144 bytes per pixel: 64 of hi halves, 64 of lo halves, 16 unused; patch rows of 2 816 / 3 104 bytes), not
+//     swizzled: pixels whose addresses differ by an odd multiple of 16 bytes (mod 256) never share a bank quad, so the ds_read_b128 lane
+//     groups of gfx950 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: consecutive pixels of two tile rows) are conflict-free without any
+//     XOR -- and every tap, every K step and the hi / lo halves are IMMEDIATE offsets of ONE address register per 32-pixel block.  The
+//     two convolution loops contain no VALU instruction at all;
 //   * the patch goes global -> registers -> (bn1, LeakyReLU, hi/lo split) -> LDS instead of LDS-DMA + in-place rewrite: no raw landing
-//     zone, no second LDS pass, and the next tile's pixels are requested before the current tile's stores and last barrier;
+//     zone, no second LDS pass, and the next tile's pixels are requested before the barrier that ends the current tile;
 //   * interior tiles (78 % at level 1) run without any validity mask; border tiles take a second, masked copy of the two VALU phases;
-//   * the residual is loaded INTO the accumulators of conv2 (y = x + sum of products, one store per 16 bytes, no staging through LDS,
-//     no epilogue arithmetic); conv1 starts from the MFMA's zero constant instead of 32 cleared registers;
+//   * conv1 starts from the MFMA's zero constant instead of 32 cleared registers; the residual is requested late in conv2 (L2-hot) and
+//     added in the epilogue, where the tile is staged through LDS and leaves in full 128-byte lines (stored straight from the MFMA
+//     layout every store instruction touches 32 lines: 0.12 ms of a 0.33 ms launch);
 //   * weights: ordinary global loads into a ring of three register groups (the compiler counts vmcnt: there is no LDS-DMA beside them).
-// Not bit-identical to the old kernel: the residual enters the fp32 sum first instead of last.
+// Measured: profiles/r06_c40_block2d32_ablations.txt; DESIGN.md section 5.
 #include "conv_common.h"
 #include "vfx_internal.h"
 
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256, VFX_B2D_LB) void k_block2d32(const ResBlockPar
     conv(a2, W1 * PIX, 9, std::true_type{});
     B2D_TS(4);
     // ---- y = conv2 + x: the tile is staged in LDS (pixel-major, PIX bytes per pixel) and leaves in full 128-byte lines ----------------------
-    // (stored straight from the MFMA layout every instruction touches 32 lines with 32 bytes each: measured, profiles/r06_c31_*: the
+    // (stored straight from the MFMA layout every instruction touches 32 lines with 32 bytes each: measured, profiles/r06_c40_block2d32_ablations.txt: the
     // stores alone were 0.12 ms of a 0.33 ms launch)
     B2D_BARRIER();  // every wave is done reading h
 #pragma unroll
