@@ -70,6 +70,8 @@ enum {
                                       tile, phase and cout range) instead of k_up16 (one block per tile of input positions, all phases) */
   VFX_TUNE_OLD_BLOCK2D = 1024,     /* the identity ConvBlockRes of ResUNet level 1 (C = 32, 16 x 16 tiles) on k_resblock (one tile per block, LDS-DMA
                                       patch, swizzled rows) instead of the persistent k_block2d32 (round 6) */
+  VFX_TUNE_TWO_LAUNCH_UPSAMPLERS = 2048, /* the mel ResUNet's 2 x upsamplers (odd output width) as two launches of two column phases each (one
+                                      per output row class: the round-4 form) instead of one launch of four phases (round 6) */
   VFX_TUNE_DEBUG_POISON_ARENA = 256 /* debug aid, no kernel selection: the handle's workspace arena is filled with NaN patterns when
                                       it grows and before every call, so that a kernel reading a buffer nobody wrote shows up */
 };

@@ -174,9 +174,9 @@ def test_f32_trunk_layers(C):
 @pytest.mark.parametrize("prune_w,H,W", [(False, 5, 1), (False, 10, 3), (True, 4, 16), (False, 6, 7), (False, 3, 30), (False, 17, 63),
                                         (True, 9, 5), (True, 2, 2)])
 def test_conv_transpose2d(engine, prune_w, H, W):
-    """The ResUNets' upsampler.  W >= 2 and H >= 2 run the product's form -- the two column classes of a row class as the phases of
-    ONE launch (even output width: channel-half view; odd width 2 W + 1: `TapConvParams::out_cmul`, the second class one column
-    short) -- W = 1 the four parity launches."""
+    """The ResUNets' upsampler.  W >= 2 and H >= 2 run the product's form -- all FOUR parity classes as the phases of ONE launch
+    (`TapConvParams::out_cmul` + `phase_rows`; at an odd width 2 W + 1, the mel ResUNet's, the odd column class is one column short),
+    a block of k_conv covering up to four phases -- W = 1 the four parity launches."""
     B, Cin, Cout = 2, 64, 32
     x = _rand((B, Cin, H, W), 21)
     w = _rand((Cin, Cout, 3, 3), 22, 0.1)
@@ -190,6 +190,29 @@ def test_conv_transpose2d(engine, prune_w, H, W):
     assert tuple(_nchw(y).shape) == tuple(ref.shape)
     err = (_nchw(y.cpu()).double() - ref).abs().max().item()
     assert err < engine.tol['conv'], err
+
+
+@pytest.mark.parametrize("prune_w", [False, True])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 6, 64, 32), (3, 40, 33, 64, 64), (1, 2, 2, 32, 32), (2, 63, 16, 128, 64), (5, 17, 129, 32, 32),
+                                            (1, 12, 20, 64, 128), (2, 5, 9, 32, 96)])
+def test_conv_transpose2d_one_launch_equals_two(engine, B, H, W, Cin, Cout, prune_w):
+    """The upsampler as one launch of four phases whose blocks cover 1, 2 or 4 phases (round 6; 32 / 64 / 96 / 128 couts per phase)
+    against the two launches of two phases each with one phase per block (VFX_TUNE_TWO_LAUNCH_UPSAMPLERS, rounds 3-4): the same stage
+    tables and sums per output -- bit-identical, at an odd (2 W + 1) and at a pruned (2 W) output width."""
+    from voicefixer_main_amd import _lib
+    from voicefixer_main_amd.engine import Engine
+    x = _nhwc(_rand((B, Cin, H, W), 25))
+    w = _rand((Cin, Cout, 3, 3), 26, 0.1)
+    scale = torch.rand(Cin, generator=torch.Generator().manual_seed(27)) + 0.5
+    shift = _rand((Cin,), 28, 0.2)
+    prec = {'fp32': 0, 'split-bf16': 1, 'fp16-vocoder': 2}[engine.tol['name']]
+    two = Engine("cuda:0", config={"precision": prec, "tuning": _lib.TUNE_TWO_LAUNCH_UPSAMPLERS})
+    kw = dict(prune_w=prune_w, scale=scale.numpy(), shift=shift.numpy(), act=1, slope=0.0)
+    y1 = engine.op_conv_transpose(x, w.numpy(), 2, **kw)
+    y2 = two.op_conv_transpose(x, w.numpy(), 2, **kw)
+    assert tuple(y1.shape) == (B, 2 * H, 2 * W if prune_w else 2 * W + 1, Cout)
+    assert torch.isfinite(y1).all()
+    assert torch.equal(y1, y2), (y1 - y2).abs().max().item()
 
 
 @pytest.mark.parametrize("s", [7, 3])
@@ -320,6 +343,31 @@ def test_block2d32_equals_the_one_tile_per_block_kernel(engine, B, H, W):
     assert torch.equal(y, y_old), (y - y_old).abs().max().item()
     again = engine.op_block2d(_nhwc(x), *args).cpu()  # no state between calls
     assert torch.equal(y, again)
+
+
+def test_block2d32_random_shapes_equal_the_one_tile_per_block_kernel(engine):
+    """Seeded sweep of image shapes (1-20 images, 1-400 rows, 1-200 columns, plus the benched 16 x 1001 x 128) through both C = 32 block
+    kernels: bit-identical outputs whatever the tile grid the planner picks, the number of tiles per persistent block and the overhang at
+    the right and bottom borders."""
+    if engine.tol['name'] == 'fp32':
+        pytest.skip("the fused block exists for the split-bf16 ResUNet arithmetic (precision 1 and 2) only")
+    from voicefixer_main_amd import _lib
+    from voicefixer_main_amd.engine import Engine
+    C = 32
+    rng = np.random.default_rng(2026)
+    shapes = [(int(rng.integers(1, 21)), int(rng.integers(1, 401)), int(rng.integers(1, 201))) for _ in range(14)] + [(16, 1001, 128)]
+    old = Engine("cuda:0", config={"precision": 1, "tuning": _lib.TUNE_OLD_BLOCK2D})
+    w1, w2 = _rand((C, C, 3, 3), 62, 0.06), _rand((C, C, 3, 3), 63, 0.06)
+    g = torch.Generator().manual_seed(64)
+    sc1, sc2 = torch.rand(C, generator=g) + 0.5, torch.rand(C, generator=g) + 0.5
+    sh1, sh2 = _rand((C,), 65, 0.2), _rand((C,), 66, 0.2)
+    args = (w1.numpy(), sc1.numpy(), sh1.numpy(), w2.numpy(), sc2.numpy(), sh2.numpy(), 0.01)
+    for i, (B, H, W) in enumerate(shapes):
+        x = _nhwc(_rand((B, C, H, W), 70 + i) * 2.0)
+        y = engine.op_block2d(x, *args)
+        y_old = old.op_block2d(x, *args)
+        assert torch.isfinite(y).all(), (B, H, W)
+        assert torch.equal(y, y_old), ((B, H, W), (y - y_old).abs().max().item())
 
 
 @pytest.mark.parametrize("C,H,W", [(32, 40, 127), (64, 33, 63), (32, 7, 5), (64, 130, 20)])

@@ -44,6 +44,26 @@ def test_resunet_mel_same_bits_on_either_level_1_block_kernel(unet_sd):
     assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
 
 
+def test_resunet_mel_same_bits_with_one_or_two_launches_per_upsampler(unet_sd):
+    """The five 2 x upsamplers of the mel ResUNet (odd output widths) and of the spectrogram ResUNet (pruned, even widths) as one
+    launch of four phases each (round 6) and as two launches of two phases (VFX_TUNE_TWO_LAUNCH_UPSAMPLERS): equal outputs bit for bit."""
+    from voicefixer_main_amd import _lib, synth
+    from voicefixer_main_amd.engine import Engine, MODEL_UNET_MEL, MODEL_UNET_SPEC
+    mel = torch.from_numpy(_mel_input(5, 301, seed=9)[:, 0])
+    wav = torch.from_numpy(synth.make_clips(2, 1.3, seed=12)[:, 0])
+    outs = []
+    for tuning in (0, _lib.TUNE_TWO_LAUNCH_UPSAMPLERS):
+        eng = Engine("cuda:0", config={"precision": 1, "tuning": tuning})
+        eng.load_state_dict(MODEL_UNET_MEL, unet_sd)
+        eng.load_state_dict(MODEL_UNET_SPEC, synth.make_resunet_state_dict(2))
+        sp = eng.stft(wav.cuda(), want_mel=False, want_sp=True)["sp"]
+        outs.append((eng.resunet_mel(mel).cpu(), eng.resunet_spec(sp, wav.cuda()).cpu()))
+        assert eng.take_flags() == 0
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (a - b).abs().max().item()
+
+
 def test_resunet_negative_input_flag(engine):
     mel = _mel_input(1, 64)
     mel[0, 0, 3, 5] = -1.0
@@ -298,7 +318,8 @@ def test_fp16_vocoder_dynamic_range_flag_and_rerun(unet_sd, voc_sd):
 # replaces one kernel family by an older / simpler form of the same arithmetic; the results must stay within the mode's bars.
 TUNING = [("NO_FUSED_STACKS", 1, 2), ("NO_FUSED_WIDE", 2, 2), ("NO_FUSED_UNET", 4, 1), ("NO_PERSISTENT_C64", 8, 2),
           ("NO_PAIRS", 16, 2), ("NO_SPLITK", 32, 1), ("F32_TRUNK", 64, 2), ("SMALL_2D_TILES", 128, 1), ("NO_FUSED_STACKS", 1, 1),
-          ("DEBUG_POISON_ARENA", 256, 2), ("NO_FUSED_UPSAMPLERS", 512, 2), ("OLD_BLOCK2D", 1024, 1)]
+          ("DEBUG_POISON_ARENA", 256, 2), ("NO_FUSED_UPSAMPLERS", 512, 2), ("OLD_BLOCK2D", 1024, 1),
+          ("TWO_LAUNCH_UPSAMPLERS", 2048, 1)]
 
 
 @pytest.mark.parametrize("name,bit,precision", TUNING, ids=["%s-p%d" % (n, p) for n, _, p in TUNING])

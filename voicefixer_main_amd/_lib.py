@@ -17,8 +17,8 @@ VFX_MAX_STAGES = 8
 MODEL_UNET_MEL, MODEL_UNET_SPEC, MODEL_VOCODER, MODEL_FRONTEND = 0, 1, 2, 3
 # vfx_config.tuning bits (include/vfx.h)
 TUNE_NO_FUSED_STACKS, TUNE_NO_FUSED_WIDE, TUNE_NO_FUSED_UNET, TUNE_NO_PERSISTENT_C64, TUNE_NO_PAIRS, TUNE_NO_SPLITK, \
-    TUNE_F32_TRUNK, TUNE_SMALL_2D_TILES, TUNE_DEBUG_POISON_ARENA, TUNE_NO_FUSED_UPSAMPLERS, TUNE_OLD_BLOCK2D = \
-    1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
+    TUNE_F32_TRUNK, TUNE_SMALL_2D_TILES, TUNE_DEBUG_POISON_ARENA, TUNE_NO_FUSED_UPSAMPLERS, TUNE_OLD_BLOCK2D, \
+    TUNE_TWO_LAUNCH_UPSAMPLERS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
 FLAG_NEGATIVE_INPUT = 1
 FLAG_F16_SATURATED = 2   # precision 2: an activation of the vocoder left the fp16 range and was clamped
 FLAG_PEAK_NORMALISED = 4  # vfx_restore_gsr divided a clip by its peak (the reference's "Exceed energy limit" warning)

@@ -573,9 +573,10 @@ void PlanBuilder::add_conv_phased(TapConvParams p, const std::vector<TapSeg>& ph
   p.nphase = (int)phases.size();
   p.cout_phase = p.Cout / p.nphase;
   VFX_CHECK(p.cout_phase % 32 == 0, "phased conv: %d couts per phase", p.cout_phase);
-  VFX_CHECK(!p.out_cmul || (p.out_cmul == p.cout_phase && p.nphase == 2 && p.sw == 2 && p.ow0 == 0 && !p.residual && !p.residual_act &&
-                            !p.out_act && p.out && !p.bias),
+  VFX_CHECK(!p.out_cmul || (p.out_cmul == p.cout_phase && p.nphase == (p.phase_rows ? 4 : 2) && p.sw == 2 && p.ow0 == 0 && !p.residual &&
+                            !p.residual_act && !p.out_act && p.out && !p.bias),
             "phased conv: bad odd-width launch");
+  VFX_CHECK(!p.phase_rows || (p.out_cmul && p.sh == 2 && p.oh0 == 0 && p.Wo >= 2), "phased conv: bad row-phased launch");
   const size_t idx = plan->host_params.size();
   plan->phase_segs[idx] = phases;
   add_conv(p);
@@ -864,12 +865,12 @@ int vfx_create(int device, const vfx_config* cfg, vfx_handle** out) {
   h->device = device;
   if (cfg) h->cfg = *cfg; else vfx_default_config(&h->cfg);
   VFX_CHECK(h->cfg.voc_n_stages >= 1 && h->cfg.voc_n_stages <= VFX_MAX_STAGES, "bad voc_n_stages");
-  VFX_CHECK((h->cfg.tuning & ~2047) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
+  VFX_CHECK((h->cfg.tuning & ~4095) == 0, "vfx_create: unknown bits in vfx_config.tuning (0x%x)", h->cfg.tuning);
   if (h->cfg.tuning) {  // never silent: a non-default kernel selection is announced
     static const char* names[] = {"NO_FUSED_STACKS", "NO_FUSED_WIDE", "NO_FUSED_UNET", "NO_PERSISTENT_C64", "NO_PAIRS", "NO_SPLITK",
-                                  "F32_TRUNK", "SMALL_2D_TILES", "DEBUG_POISON_ARENA", "NO_FUSED_UPSAMPLERS", "OLD_BLOCK2D"};
+                                  "F32_TRUNK", "SMALL_2D_TILES", "DEBUG_POISON_ARENA", "NO_FUSED_UPSAMPLERS", "OLD_BLOCK2D", "TWO_LAUNCH_UPSAMPLERS"};
     std::string msg;
-    for (int b = 0; b < 11; ++b)
+    for (int b = 0; b < 12; ++b)
       if (h->cfg.tuning & (1 << b)) msg += std::string(msg.empty() ? "" : " | ") + "VFX_TUNE_" + names[b];
     fprintf(stderr, "[libvfx] handle on device %d uses non-default kernel selection: tuning = 0x%x (%s)\n", device, h->cfg.tuning,
             msg.c_str());

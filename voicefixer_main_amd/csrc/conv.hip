@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   constexpr int kEpiBytes = CBM * (BN / EPI_HALVES + 4) * 4;
   constexpr int kMainBytes = (2 * CPATCH > kEpiBytes) ? 2 * CPATCH : kEpiBytes;
   char* const lds = reinterpret_cast<char*>(smem);
-  int* otab = reinterpret_cast<int*>(lds + kMainBytes);  // [128] output pixel index or -1
+  int* otab = reinterpret_cast<int*>(lds + kMainBytes);  // [kOtabSlots][128] output pixel index or -1 (one slot per phase of the block)
 
   const TapConvParams& p = *pp;
   // The stage table is read-only for the whole launch: address it in the constant address space so
@@ -107,9 +107,16 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   const int ks = tile % KS;
   tile /= KS;
   const int n0 = (tile % n_tiles) * BN;
-  // phased launch: this block's couts belong to phase n0 / cout_phase -- own stage table, own weight tensor
-  const int phase = p.nphase > 1 ? n0 / p.cout_phase : 0;
-  const int n0w = p.nphase > 1 ? n0 - phase * p.cout_phase : n0;  // first cout inside the phase's weight tensor
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_u / WAVES_N, wn = wave_u % WAVES_N;
+  // phased launch: the 32 couts of a WAVE belong to phase (n0 + 32 wn) / cout_phase -- own stage table (own taps), own weight
+  // tensor.  The waves of a block may belong to different phases (BN a multiple of cout_phase, round 6: the ResUNets' 2 x upsamplers,
+  // whose phases are 32-64 couts wide -- one block stages the patch once for all of them); the patch, its prologue and the stage
+  // count are the same in every phase, the only block-wide synchronisation is the barrier at the start of a stage, so waves with
+  // fewer taps simply arrive early.
+  const int phase0 = p.nphase > 1 ? n0 / p.cout_phase : 0;              // first phase of the block
+  const int phase = p.nphase > 1 ? (n0 + 32 * wn) / p.cout_phase : 0;   // this wave's
+  const int n0w = p.nphase > 1 ? n0 + 32 * wn - phase * p.cout_phase : n0 + 32 * wn;  // the wave's first cout inside its weight tensor
   const int st_lo = (int)((int64_t)ks * p.nstages / KS), st_hi = (int)((int64_t)(ks + 1) * p.nstages / KS);
   const StageTab stages = (StageTab)(uintptr_t)p.stages + phase * p.nstages + st_lo;
   int mt = tile / n_tiles;  // spatial tile: (image, tile row, tile col), col fastest
@@ -139,7 +146,6 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   // Every stage of a launch stages the same PH x PW window around the tile; only its origin (dh0, dw0)
   // varies between stages.
   const int lr = tid >> 3, cg = tid & 7;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tw_shift = p.tw_shift, TWm1 = p.TW - 1, TH = p.TH;
   // Swizzle key of patch pixel (pi, pj): ((pj >> 1) + (TW / 2) * pi) & 7.  With an even patch width the bank half of
   // LDS row pi*PW + pj is pj & 1, and the 16 lanes of a ds_read_b128 group -- runs of consecutive columns in TW-wide
@@ -163,14 +169,22 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   if (tid < CBM) {
     const int li = tid >> tw_shift, lj = tid & TWm1;
     const int i = i0 + li, j = j0 + lj;
-    int idx = -1;
-    if (li < TH && i < p.Hg && j < p.Wg) {
-      const int oh = i * p.sh + p.oh0, ow = j * p.sw + p.ow0;
-      const int o = oh * p.Wo + ow;
-      // (out_cmul: phase r of an odd-width phased launch writes true column ow + r)
-      if (oh < p.Ho && ow + (p.out_cmul ? phase : 0) < p.Wo && o < out_limit) idx = img * p.out_img_stride + o;
+    // one table per phase of the block (conv_epilogue picks the slot of its couts); ordinary launches: one
+    const int nslots = (p.nphase > 1 && p.cout_phase < BN) ? BN / p.cout_phase : 1;
+    for (int s = 0; s < nslots; ++s) {
+      const int ph = phase0 + s;
+      int idx = -1;
+      if (li < TH && i < p.Hg && j < p.Wg) {
+        // (out_cmul: phase r of an odd-width phased launch writes true column ow + r -- the epilogue's channel offset r * C of a
+        // tensor addressed in units of C; phase_rows: phases 2 and 3 are the odd output rows, columns r & 1: the pixel index takes
+        // the row and gives back the two columns the channel offset adds)
+        const int prow = p.phase_rows ? ph >> 1 : 0, pcol = p.out_cmul ? (p.phase_rows ? ph & 1 : ph) : 0;
+        const int oh = i * p.sh + p.oh0 + prow, ow = j * p.sw + p.ow0;
+        const int o = oh * p.Wo + ow;
+        if (oh < p.Ho && ow + pcol < p.Wo && o < out_limit) idx = img * p.out_img_stride + o - 2 * prow;
+      }
+      otab[s * CBM + tid] = idx;
     }
-    otab[tid] = idx;
   }
 
   f32x16 acc[WM][WNB];
@@ -182,7 +196,6 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int lane = tid & 63;
-  const int wm = wave_u / WAVES_N, wn = wave_u % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
   int arow[WM];  // patch row of this lane's pixel of M block a (tap offset added per step)
   int ak0[WM];   // its swizzle key before the tap shift: (lj >> 1) + (TW / 2) * li, column parity in bit 16
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     arow[a] = li < TH ? li * PW + lj : 0;
     ak0[a] = li < TH ? (((lj >> 1) + hTW * li) | ((lj & 1) << 16)) : 0;
   }
-  const unsigned nb_off = (unsigned)(((n0w >> 5) + wn) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block
+  const unsigned nb_off = (unsigned)((n0w >> 5) * 1024 + lane * 4) * 4u;  // byte offset of this lane in a fragment block
 
   // ---- patch (A) staging ------------------------------------------------------------------------
   // The byte offset of every patch pixel is kept in registers and only recomputed when the patch
@@ -504,7 +517,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
 static size_t conv_lds_bytes(int BN, bool hi) {
   const int halves = (BN == 128 && hi) ? 2 : 1;  // as EPI_HALVES in the kernel
   const size_t main_bytes = std::max<size_t>((size_t)2 * CPATCH, (size_t)CBM * (BN / halves + 4) * 4);
-  return main_bytes + CBM * 4;
+  return main_bytes + kOtabSlots * CBM * 4;
 }
 
 template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false, bool VL = false>
@@ -581,8 +594,15 @@ static void launch_vl(bool vl, bool elu, int BN, int grid, hipStream_t stream, c
 // ResUNet levels have 16 .. 64 spatial tiles): then narrower tiles, i.e. more blocks of less work each.
 int conv_block_n(const TapConvParams& hp) {
   const int64_t spatial = (int64_t)hp.B * hp.tiles_h * hp.tiles_w;
-  const int cdiv = hp.nphase > 1 ? hp.cout_phase : hp.Cout;  // a block never straddles two phases
-  int bn = cdiv % 128 == 0 ? 128 : (cdiv % 64 == 0 ? 64 : 32);
+  // phased launch: a block covers a whole number of phases or a part of one (a wave's 32 couts never straddle two: 32 | cout_phase);
+  // VFX_TUNE_TWO_LAUNCH_UPSAMPLERS: at most one phase per block (the form of rounds 2-5)
+  const bool one_phase = hp.nphase > 1 && (hp.tuning & VFX_TUNE_TWO_LAUNCH_UPSAMPLERS);
+  auto fits = [&](int bn) {
+    if (hp.Cout % bn) return false;
+    if (hp.nphase <= 1) return true;
+    return hp.cout_phase % bn == 0 || (!one_phase && bn % hp.cout_phase == 0);
+  };
+  int bn = fits(128) ? 128 : (fits(64) ? 64 : 32);
   while (bn > 32 && spatial * (hp.Cout / bn) < 384) bn >>= 1;
   return bn;
 }

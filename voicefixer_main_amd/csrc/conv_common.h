@@ -117,6 +117,7 @@ __device__ __forceinline__ int div_recip(int n, unsigned long long r) {
 }
 
 constexpr int CBM = 128;                     // pixels per tile
+constexpr int kOtabSlots = 4;                // k_conv: output pixel tables per block (a block of a phased launch covers up to BN / 32 phases)
 constexpr int CROW = 128;                    // bytes per patch row (32 channels)
 constexpr int CNQ = kPatchMaxRows / 32;      // patch row groups (one DMA instruction / register group each)
 constexpr int CPATCH = kPatchMaxRows * CROW; // bytes per patch buffer

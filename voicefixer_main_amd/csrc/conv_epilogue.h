@@ -71,9 +71,11 @@ __device__ __forceinline__ void conv_epilogue(const TapConvParams& p, float* sme
     if (p.bias && !partial) bv = *(const VFX_CE_GLOBAL ce_f32x4*)(p.bias + ncol);
     int opix[NPASS];
     ce_f32x4 val[NPASS];
+    // a block of a phased launch that covers several phases (k_conv) keeps one pixel table per phase: the slot of this thread's couts
+    const int* otab_s = otab + ((p.nphase > 1 && p.cout_phase < BN) ? (hh * BH + 4 * c4) / p.cout_phase * 128 : 0);
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
-      opix[q] = otab[r0 + q * RPP];
+      opix[q] = otab_s[r0 + q * RPP];
       val[q] = *reinterpret_cast<const ce_f32x4*>(smem + (r0 + q * RPP) * LDO + 4 * c4) + bv;
     }
     if (partial) {

@@ -517,10 +517,46 @@ extern "C" int vfx_op_conv_transpose(vfx_handle* h, const float* x, int B, int H
     Scratch sc;
     const float* dbias = bias ? sc.blob.upload(bias, Cout) : nullptr;
     if (kh == 3 && kw == 3 && stride == 2 && !bias && H >= 2 && W >= 2 && Cout % 32 == 0 && !(h->cfg.tuning & VFX_TUNE_NO_FUSED_UNET)) {
-      // the product's form (resunet.cpp, TrunkBuilder::upsample): the two column classes of a row class as the PHASES of one
-      // launch -- even output width: the output viewed as (B, 2H, W, 2 Cout); odd width: addressed in units of Cout (out_cmul)
+      // the product's form (resunet.cpp, TrunkBuilder::upsample): all four parity classes as the PHASES of one launch, the output
+      // addressed in units of Cout (out_cmul, phase_rows); VFX_TUNE_TWO_LAUNCH_UPSAMPLERS: the two column classes of a row class as
+      // the phases of one launch -- even output width: the output viewed as (B, 2H, W, 2 Cout); odd width: out_cmul
       const int Ho = 2 * H, Wo = prune_w ? 2 * W : 2 * W + 1;
-      for (int a = 0; a < 2; ++a) {
+      const bool four = !(h->cfg.tuning & VFX_TUNE_TWO_LAUNCH_UPSAMPLERS);  // all four phases in one launch (either width)
+      if (four) {
+        TapConvParams p{};
+        p.B = B;
+        p.Hi = H;
+        p.Wi = W;
+        p.Ho = Ho;
+        p.Wo = Wo;
+        p.Cout = 4 * Cout;
+        p.out_cmul = Cout;
+        p.phase_rows = 1;
+        p.sh = 2;
+        p.sw = 2;
+        p.Hg = (Ho + 1) / 2;
+        p.Wg = (Wo + 1) / 2;
+        p.out = y;
+        p.nseg = 1;
+        std::vector<TapSeg> phases(4);
+        for (int ph = 0; ph < 4; ++ph) {
+          TapSeg& S = phases[ph];
+          S = TapSeg{};
+          std::vector<std::pair<int, int>> taps;
+          for (int r = ph >> 1; r < 3; r += 2)
+            for (int c = ph & 1; c < 3; c += 2) {
+              S.dh[taps.size()] = -(r / 2);
+              S.dw[taps.size()] = -(c / 2);
+              taps.push_back({r, c});
+            }
+          S.ntaps = (int)taps.size();
+          fill_seg(S, x, Cin, scale, shift, act, slope, sc.blob);
+          S.wt = sc.blob.upload(pack_conv_transposed(weight, Cin, Cout, 3, 3, taps, h->cfg.precision == 2 ? 2 : (h->cfg.precision != 0)));
+        }
+        p.seg[0] = phases[0];
+        run_phased(h, p, phases, sc.blob, s);
+      }
+      for (int a = 0; a < 2 && !four; ++a) {
         TapConvParams p{};
         p.B = B;
         p.Hi = H;

@@ -359,6 +359,47 @@ struct TrunkBuilder {
           ++S.ntaps;
         }
     };
+    // Round 6: ONE launch of four phases r = 2 a + b for either output width: the output is addressed in units of C channels at the TRUE
+    // pixel index (TapConvParams::out_cmul: phase r lands at column 2 j + (r & 1)), phases 2 and 3 write the odd output rows
+    // (TapConvParams::phase_rows), and a block of k_conv covers up to four phases (BN = 128 for 32 couts per phase): the patch is
+    // staged once for all of them and x is read from HBM once.  VFX_TUNE_TWO_LAUNCH_UPSAMPLERS keeps the forms of rounds 3-4 below (one
+    // launch per output row class, one phase per block); same stage tables, same sums: bit-identical.
+    if (x.H >= 2 && x.W >= 2 && !(pb.h->cfg.tuning & (VFX_TUNE_NO_FUSED_UNET | VFX_TUNE_TWO_LAUNCH_UPSAMPLERS))) {
+      TapConvParams p{};
+      p.B = B;
+      p.Hi = x.H;
+      p.Wi = x.W;
+      p.Ho = y.H;
+      p.Wo = y.W;
+      p.Cout = 4 * D.cout;
+      p.out_cmul = D.cout;
+      p.phase_rows = 1;
+      p.sh = 2;
+      p.sw = 2;
+      p.oh0 = 0;
+      p.ow0 = 0;
+      p.Hg = (y.H + 1) / 2;            // (row class 1 has y.H / 2 rows: masked, oh < Ho)
+      p.Wg = (y.W + 1) / 2;            // column class 0: W + 1 columns of an odd width 2 W + 1, W of a pruned one; class 1 masked (ow + 1 < Wo)
+      p.out = const_cast<float*>(rel_ptr(y.off));
+      p.act_slope = 1.f;
+      p.nseg = 1;
+      std::vector<TapSeg> phases(4);
+      for (int r = 0; r < 4; ++r) {
+        TapSeg& S = phases[r];
+        S = TapSeg{};
+        S.src = rel_ptr(x.off);
+        S.C = x.C;
+        S.scale = D.bn_scale;
+        S.shift = D.bn_shift;
+        S.act = ACT_LEAKY;
+        S.slope = 0.f;  // ReLU
+        S.wt = D.wT[r];
+        parity_taps(S, r >> 1, r & 1);
+      }
+      p.seg[0] = phases[0];  // phase (0, 0) reads kh, kw in {0, 2}: the union of all four windows
+      pb.add_conv_phased(p, phases);
+      return y;
+    }
     // (x.H, x.W >= 2: plan_conv then always finds a tile whose all-taps window fits one patch, which a phased launch needs;
     // an odd output width -- the mel ResUNet prunes the time axis only -- has no such view: addressed in units of C instead, below)
     if (prune_w && x.H >= 2 && x.W >= 2 && !(pb.h->cfg.tuning & VFX_TUNE_NO_FUSED_UNET)) {

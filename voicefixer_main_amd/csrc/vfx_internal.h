@@ -214,6 +214,10 @@ struct TapConvParams {
   // phase r at channel offset r * C, i.e. at true column 2 j + r; phase 1 has one column fewer (masked: ow + r < Wo).
   // 0 = ordinary addressing (pixel index * Cout).  No residual, activated output or split-K with it.
   int out_cmul;
+  // Round 6: BOTH output row classes of such an upsampler in one launch -- four phases r = 2 a + b, phase r writes output row
+  // 2 i + a (oh0 = 0, sh = 2) and true column 2 j + b; the four blocks of a spatial tile are neighbours in the tile order and share one
+  // patch through their XCD's L2: x is read from HBM once instead of twice, one launch instead of two.  Needs out_cmul.
+  int phase_rows;
   double flops_override;  // algorithmic flops when they are not 2 * M * Cout * K (phased launches)
   const float* bias;     // [Cout] or nullptr
   const float* residual; // (B, Ho, Wo, Cout) or nullptr, added in the epilogue
