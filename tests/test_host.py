@@ -904,8 +904,10 @@ def test_tall_narrow_images_keep_windowed_stages():
         TH, TW, PW, P, per_tap, tiles = plan(Hg, Wg)
         assert per_tap == 0 and P <= 192 and P == (TH + 2) * PW and TH * TW <= 128 and TH >= 1, (Hg, Wg, list(out))
         assert tiles == -(-Hg // TH) * -(-Wg // TW)
-    # unchanged: the levels of a 10-s clip (Tpad = 1024) and of the 1-s chunk
-    assert plan(32, 3)[:5] == [32, 2, 4, 136, 0] and plan(16, 1)[:5] == [16, 1, 4, 72, 0]
+    # the levels of a 10-s clip (Tpad = 1024) and of the 1-s chunk.  Round 6: an image narrower than the tile stages only the columns it
+    # has (window width min(TW, Wg) + 2) -- level 6 of a 10-s clip, 32 x 3 pixels, is ONE tile of 32 x 4 (34 x 5 patch pixels) instead of
+    # two of 32 x 2: 768 blocks per launch (one round of the chip's slots) instead of 1 536
+    assert plan(32, 3) == [32, 4, 5, 170, 0, 1] and plan(16, 1)[:5] == [16, 1, 4, 72, 0]
     assert plan(64, 7)[:2] == [16, 8] and plan(128, 15)[4] == 0 and plan(1024, 127)[4] == 0
 
 

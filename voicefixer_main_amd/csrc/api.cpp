@@ -263,18 +263,24 @@ static void plan_conv(TapConvParams& p) {
   // window fits at 128 / TW rows and fell back to one stage per (chunk, tap): nine times the stages, no split-K, 0.13 - 0.36 ms
   // per launch where a 16 x 10 s batch takes 0.05 (profiles/r05_1x60_vs_16x10_per_launch.txt).  Shapes that fitted before keep
   // their rows.
+  // Round 6: an image NARROWER than the tile (level 6 of the mel ResUNet: 3 columns on 4-wide tiles) stages only the columns it has --
+  // window width min(TW, Wg) + taps instead of TW + taps: 34 x 5 = 170 patch pixels hold all 32 rows of a 10-s clip's level 6 in ONE tile
+  // (34 x 6 = 204 did not fit: two tiles of 30 + 2 rows, i.e. 1 536 blocks = two rounds of the chip's 768 slots per launch, 44-55 us
+  // where one round takes 24-26).  The tile's dead columns read rows of the neighbouring patch pixels (the `dead` slack keeps them
+  // inside the buffer) into accumulator columns nobody stores.
+  auto win_w = [&](int TW) { return (int64_t)std::min(TW, p.Wg) + (int64_t)(dw_hi - dw_lo); };
   auto rows_of = [&](int sft) {
     const int TW = 1 << sft;
-    const int64_t PW = TW + (int64_t)(dw_hi - dw_lo);
-    const int64_t fit = kPatchMaxRows / PW - (int64_t)(dh_hi - dh_lo);
+    const int64_t PW = win_w(TW), dead = TW - std::min(TW, p.Wg);
+    const int64_t fit = (kPatchMaxRows - dead) / PW - (int64_t)(dh_hi - dh_lo);
     return (int)std::max<int64_t>(0, std::min<int64_t>(std::min(128 / TW, p.Hg), fit));
   };
   for (int sft = sft0; sft <= 7; ++sft) {
     const int TW = 1 << sft, TH = rows_of(sft);
     if (TW > 2 * p.Wg && sft > sft0) break;
     if (TH < 1) continue;
-    const int64_t PH = TH + (int64_t)(dh_hi - dh_lo), PW = TW + (int64_t)(dw_hi - dw_lo);
-    if (PH * PW > kPatchMaxRows || PW >= 65536) continue;
+    const int64_t PH = TH + (int64_t)(dh_hi - dh_lo), PW = win_w(TW);
+    if (PH * PW + (TW - std::min(TW, p.Wg)) > kPatchMaxRows || PW >= 65536) continue;
     const double covered = (double)((p.Hg + TH - 1) / TH) * ((p.Wg + TW - 1) / TW) * 128.0;
     const double util = (double)p.Hg * p.Wg / covered;
     if (util > best_util * 1.02 || (util > best_util * 0.98 && PH * PW < best_P)) {
@@ -306,13 +312,13 @@ static void plan_conv(TapConvParams& p) {
   p.tiles_w = (p.Wg + TW - 1) / TW;
   if (window) {
     const int64_t PH = TH + (int64_t)(dh_hi - dh_lo);
-    int64_t PW = TW + (int64_t)(dw_hi - dw_lo);
+    int64_t PW = win_w(TW);
     // An ODD patch width (the parity classes of a transposed 3x3 convolution: taps 0 / -1, window TW + 1) breaks what the 2-D
     // swizzle key rests on -- "the bank half of LDS row pi * PW + pj is pj & 1" (conv.hip) -- and every second fragment read of
     // those launches is a 2-way bank conflict (scripts/lds_conflicts_conv.py: 1.5 LDS cycles per lane group; PMC: 34-37 % conflict
     // cycles in the upsampler launches, review item 1d).  One unused column makes it even where it fits.
 #ifndef VFX_ABL_ODD_PATCH_WIDTH  // (measurement builds keep the odd width)
-    if (PH > 1 && (PW & 1) && PH * (PW + 1) <= kPatchMaxRows) PW += 1;
+    if (PH > 1 && (PW & 1) && PH * (PW + 1) + (TW - std::min(TW, p.Wg)) <= kPatchMaxRows) PW += 1;
 #endif
     p.per_tap = 0;
     p.PW = (int)PW;

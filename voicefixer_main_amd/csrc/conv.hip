@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   //   t == NT-1     everything in flight (next taps' weights, the patch) lands before the transform / barrier.
   constexpr int AHEAD = RING - 1;
   constexpr int WL = (HI32 ? 2 : 4) * WNB;  // weight loads per tap and wave
-  BGroup<WNB> R0 = {}, R1 = {}, R2 = {};
+  BGroup<WNB> R[RING < 3 ? 3 : RING] = {};
   const int nstages = st_hi - st_lo;  // stages of this block
   const int last = nstages - 1;
   // Cursor state lives in scalar registers; table fields are re-read only when a cursor enters a new stage, and the
@@ -467,36 +467,58 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     }
     tap = stages[st < last ? st : last].poff[t];  // next step's tap (all fragment reads of this step have been consumed)
   };
-  fetch(R0);
-  if constexpr (RING == 3) fetch(R1);
-  issue_patch(stages[0], 0);
-  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-  // Ring groups that no fetch has filled yet are defined by copies made AFTER the wait: a copy of a group whose
-  // load is still in flight reads stale registers, and since a copy makes the two groups the same value for the
-  // compiler, the stale one may end up feeding the first tap.
-  use_group(R0);
-  if constexpr (RING == 3) {
-    use_group(R1);
-  } else {
-    R1 = R0;
-  }
-  R2 = R1;
-  if (praw) transform_patch(stages[0], 0);
-  if constexpr (RING == 3) {
-    while (true) {
-      step(R0, R2);
-      if (st > last) break;
-      step(R1, R0);
-      if (st > last) break;
-      step(R2, R1);
-      if (st > last) break;
+  if constexpr (RING <= 3) {
+    fetch(R[0]);
+    if constexpr (RING == 3) fetch(R[1]);
+    issue_patch(stages[0], 0);
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    // Ring groups that no fetch has filled yet are defined by copies made AFTER the wait: a copy of a group whose
+    // load is still in flight reads stale registers, and since a copy makes the two groups the same value for the
+    // compiler, the stale one may end up feeding the first tap.
+    use_group(R[0]);
+    if constexpr (RING == 3) {
+      use_group(R[1]);
+    } else {
+      R[1] = R[0];
+    }
+    R[2] = R[1];
+    if (praw) transform_patch(stages[0], 0);
+    if constexpr (RING == 3) {
+      while (true) {
+        step(R[0], R[2]);
+        if (st > last) break;
+        step(R[1], R[0]);
+        if (st > last) break;
+        step(R[2], R[1]);
+        if (st > last) break;
+      }
+    } else {
+      while (true) {
+        step(R[0], R[1]);
+        if (st > last) break;
+        step(R[1], R[0]);
+        if (st > last) break;
+      }
     }
   } else {
-    while (true) {
-      step(R0, R1);
-      if (st > last) break;
-      step(R1, R0);
-      if (st > last) break;
+    // deeper rings (measurement builds, -DVFX_RING32=N): the same scheme for any depth
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) fetch(R[g]);
+    issue_patch(stages[0], 0);
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) use_group(R[g]);
+    R[RING - 1] = R[AHEAD - 1];
+    if (praw) transform_patch(stages[0], 0);
+    bool more = true;
+    while (more) {
+#pragma unroll
+      for (int g = 0; g < RING; ++g) {
+        if (more) {
+          step(R[g], R[(g + AHEAD) % RING]);
+          more = st <= last;
+        }
+      }
     }
   }
 
@@ -573,7 +595,10 @@ static void launch_bn(int BN, int grid, hipStream_t stream, const TapConvParams*
     // same time with a third less ring registers (with three groups the BN = 128 tile spills at three waves per SIMD)
     case 128: launch_one<128, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA, VL>(grid, stream, dparams); break;
     case 64: launch_one<64, ELU, SPLIT, 0, H64 ? 2 : 3, HI, H64, RA, VL>(grid, stream, dparams); break;
-    default: launch_one<32, ELU, SPLIT, 0, 2, HI, H64, RA, VL>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
+#ifndef VFX_RING32
+#define VFX_RING32 2
+#endif
+    default: launch_one<32, ELU, SPLIT, 0, VFX_RING32, HI, H64, RA, VL>(grid, stream, dparams); break;  // 6-MFMA taps: the third group only costs registers (A/B on one box: -4 %)
   }
 }
 // the same with the per-clip lengths of a varlen batch (TapConvParams::lens): the VL variants exist without an ELU prologue only
