@@ -628,6 +628,7 @@ int conv_block_n(const TapConvParams& hp) {
     return hp.cout_phase % bn == 0 || (!one_phase && bn % hp.cout_phase == 0);
   };
   int bn = fits(128) ? 128 : (fits(64) ? 64 : 32);
+  // (round 6, r06c65: 768 instead of 384 here, or level 5 of a 10-s batch without split-K on either tile: all slower, profiles/r06_c64_*)
   while (bn > 32 && spatial * (hp.Cout / bn) < 384) bn >>= 1;
   return bn;
 }
