@@ -71,8 +71,31 @@ namespace vfx {
 // the 32-channel form, and every fetched byte is an operand).  HI without H64: raw fp32 sources, 32-channel stages,
 // transformed in place to fp16 in the first half of the row, two K = 16 steps per tap.
 // RA (with H64): the launch's residual is an activated fp16 tensor, inverted in the epilogue (TapConvParams::residual_act).
+// Timing builds (-DVFX_TIMING, scripts/conv_timing.py): per wave, shader-clock stamps at entry / setup done / first patch + weights
+// landed / first transform done / tap loop done / epilogue done, and the chip-wide 100 MHz clock at entry and exit:
+// timing[(block * 4 + wave) * 8 + 0 .. 7]
+#ifdef VFX_TIMING
+#define KCONV_TIMING_PARAM , unsigned long long* __restrict__ kc_timing
+#define KCONV_TS_BEGIN() unsigned long long kc_ts[6] = {}; const unsigned long long kc_rt0 = __builtin_amdgcn_s_memrealtime(); kc_ts[0] = __builtin_readcyclecounter()
+#define KCONV_TS(i) kc_ts[i] = __builtin_readcyclecounter()
+#define KCONV_TS_END()                                                                                           \
+  do {                                                                                                           \
+    if (kc_timing && (threadIdx.x & 63) == 0) {                                                                  \
+      unsigned long long* tp_ = kc_timing + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;                  \
+      for (int i_ = 0; i_ < 6; ++i_) tp_[i_] = kc_ts[i_];                                                        \
+      tp_[6] = kc_rt0;                                                                                           \
+      tp_[7] = __builtin_amdgcn_s_memrealtime();                                                                 \
+    }                                                                                                            \
+  } while (0)
+#else
+#define KCONV_TIMING_PARAM
+#define KCONV_TS_BEGIN()
+#define KCONV_TS(i)
+#define KCONV_TS_END()
+#endif
 template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false, bool VL = false>
-__global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp) {
+__global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp KCONV_TIMING_PARAM) {
+  KCONV_TS_BEGIN();
   static_assert(!H64 || (HI && SPLIT), "H64 is a variant of the 16-bit mode");
   static_assert(!RA || H64, "an activated residual exists in the 16-bit mode's activated-source launches only");
   constexpr bool HI32 = HI && !H64;  // the hi fragments (f[0], f[2]) only
@@ -399,6 +422,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   constexpr int AHEAD = RING - 1;
   constexpr int WL = (HI32 ? 2 : 4) * WNB;  // weight loads per tap and wave
   BGroup<WNB> R[RING < 3 ? 3 : RING] = {};
+  KCONV_TS(1);
   const int nstages = st_hi - st_lo;  // stages of this block
   const int last = nstages - 1;
   // Cursor state lives in scalar registers; table fields are re-read only when a cursor enters a new stage, and the
@@ -442,13 +466,21 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     const int cur = (st & 1) * CPATCH, nxt = CPATCH - cur;
     if (t == 0 && !(ABL & 4)) __syncthreads();
     fetch(fetch_r);
+    // The last stage of a block requests nothing (round 6; it used to refetch its own patch and transform it again so that the
+    // waits below could count on CNQ loads in flight: phase stamps of the deep ResUNet levels, profiles/r06_c66_conv_timing.txt,
+    // put 1.7 us of patch latency + 1.3 us of transform on every stage of blocks that live 23-25 us)
+#ifdef VFX_LAST_STAGE_REFETCH  // (measurement builds: the form of rounds 1-5)
+    const bool more = true;
+#else
+    const bool more = st < last;
+#endif
     if constexpr (!(ABL & 1))
-      if (t == TP) issue_patch(stages[st < last ? st + 1 : last], nxt);  // past the end: refetched, never consumed
+      if (t == TP && more) issue_patch(stages[st < last ? st + 1 : last], nxt);
     // The waits carry no register operands on purpose: a conditional asm that redefined the ring group would end
     // in a merge, and a merge copy placed before the wait would read registers whose load is still in flight.  The
     // group becomes readable at the unconditional use_b() below.
     if (t >= AHEAD && !(ABL & 3)) {
-      if (t >= TP) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD + CNQ) : "memory");
+      if (t >= TP && more) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD + CNQ) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
     }
     use_group(cur_r);
@@ -458,7 +490,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD + CNQ) : "memory");  // patch latency never exposed
       else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (praw) transform_patch(stages[st < last ? st + 1 : last], nxt);
+      if (praw && more) transform_patch(stages[st < last ? st + 1 : last], nxt);
       ++st;
       t = 0;
       NT = stages[st < last ? st : last].ntaps;
@@ -475,6 +507,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     // Ring groups that no fetch has filled yet are defined by copies made AFTER the wait: a copy of a group whose
     // load is still in flight reads stale registers, and since a copy makes the two groups the same value for the
     // compiler, the stale one may end up feeding the first tap.
+    KCONV_TS(2);
     use_group(R[0]);
     if constexpr (RING == 3) {
       use_group(R[1]);
@@ -483,6 +516,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     }
     R[2] = R[1];
     if (praw) transform_patch(stages[0], 0);
+    KCONV_TS(3);
     if constexpr (RING == 3) {
       while (true) {
         step(R[0], R[2]);
@@ -522,6 +556,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     }
   }
 
+  KCONV_TS(4);
   // ---- epilogue: bias + residual, raw and / or activated output (conv_epilogue.h) ------------------
   if constexpr (ABL & 32) {
     float keep = 0.f;
@@ -534,6 +569,8 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
     float* partial = KS > 1 ? p.ws + (int64_t)ks * ((int64_t)p.B * p.out_img_stride * p.Cout) : nullptr;
     conv_epilogue<BN, WM, WNB, WAVES_N, SPLIT, EPI_HALVES, RA>(p, smem, otab, acc, n0, partial);
   }
+  KCONV_TS(5);
+  KCONV_TS_END();
 }
 
 static size_t conv_lds_bytes(int BN, bool hi) {
@@ -550,7 +587,12 @@ static void launch_one(int grid, hipStream_t stream, const TapConvParams* dparam
     VFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64, RA, VL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
+#ifdef VFX_TIMING
+  static unsigned long long* const timing = getenv("VFX_CONV_TIMING_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("VFX_CONV_TIMING_PTR"), nullptr, 0)) : nullptr;
+  hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64, RA, VL>), dim3(grid), dim3(256), lds, stream, dparams, timing);
+#else
   hipLaunchKernelGGL((k_conv<BN, ELU, SPLIT, ABL, RING, HI, H64, RA, VL>), dim3(grid), dim3(256), lds, stream, dparams);
+#endif
 }
 
 #ifdef VFX_ABLATION_BUILD
