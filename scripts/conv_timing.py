@@ -16,12 +16,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+TAPS = ["barrier + fetch + patch request + weight wait", "fragment reads + MFMAs", "stage end (wait, transform) + cursors"]
 PH = ["setup (params, tables)", "first patch + weights", "first transform", "tap loop (all stages)", "epilogue"]
 
 
 def main():
     assert "timing" in os.environ.get("VFX_LIB_PATH", ""), "run with VFX_LIB_PATH=.../abl/libvfx_convtiming.so"
-    buf = torch.zeros(8 * 1024 * 1024, dtype=torch.int64, device="cuda")      # [block][wave][8] u64
+    buf = torch.zeros(48 * 196608, dtype=torch.int64, device="cuda")      # [block][wave][12] u64
     os.environ["VFX_CONV_TIMING_PTR"] = hex(buf.data_ptr())
     from voicefixer_main_amd.engine import Engine
     eng = Engine("cuda:0", config={"precision": 1})
@@ -38,7 +39,7 @@ def main():
         torch.cuda.synchronize()
         eng.op_conv(x, w, scale=sc, shift=sh, act=1, slope=0.01)
         torch.cuda.synchronize()
-        ts = buf.cpu().numpy().astype(np.uint64).reshape(-1, 4, 8)
+        ts = buf.cpu().numpy().astype(np.uint64).reshape(-1, 4, 12)
         used = ts[:, 0, 7] != 0
         ts = ts[used].astype(np.float64)
         n = ts.shape[0]
@@ -58,6 +59,9 @@ def main():
         print("   block starts (us after the first): median %.1f, 90 %% %.1f, 99 %% %.1f" % tuple(q))
         for i in range(5):
             print("   %-26s mean %6.2f us   slowest wave of a block %6.2f us" % (PH[i], d[:, :, i].mean(), d[:, :, i].max(axis=1).mean()))
+        acc = ts[:, :, 8:11] / ghz / 1e3
+        res["tap_loop_split_us"] = {k: float(acc[:, :, i].mean()) for i, k in enumerate(TAPS)}
+        print("   inside the tap loop:  " + ";  ".join("%s %.2f us" % (k, acc[:, :, i].mean()) for i, k in enumerate(TAPS)))
     j = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--json=")]
     if j:
         json.dump(out, open(j[0], "w"), indent=1)

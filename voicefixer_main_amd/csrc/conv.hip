@@ -72,19 +72,23 @@ namespace vfx {
 // transformed in place to fp16 in the first half of the row, two K = 16 steps per tap.
 // RA (with H64): the launch's residual is an activated fp16 tensor, inverted in the epilogue (TapConvParams::residual_act).
 // Timing builds (-DVFX_TIMING, scripts/conv_timing.py): per wave, shader-clock stamps at entry / setup done / first patch + weights
-// landed / first transform done / tap loop done / epilogue done, and the chip-wide 100 MHz clock at entry and exit:
-// timing[(block * 4 + wave) * 8 + 0 .. 7]
+// landed / first transform done / tap loop done / epilogue done, and the chip-wide 100 MHz clock at entry and exit; inside the tap loop
+// the cycles summed over the taps of [barrier + fetch + patch request + weight wait], [fragment reads + MFMAs], [end of stage: wait,
+// transform; cursor updates]: timing[(block * 4 + wave) * 12 + 0 .. 10]
 #ifdef VFX_TIMING
 #define KCONV_TIMING_PARAM , unsigned long long* __restrict__ kc_timing
-#define KCONV_TS_BEGIN() unsigned long long kc_ts[6] = {}; const unsigned long long kc_rt0 = __builtin_amdgcn_s_memrealtime(); kc_ts[0] = __builtin_readcyclecounter()
+#define KCONV_TS_BEGIN() unsigned long long kc_ts[6] = {}, kc_acc[3] = {}, kc_a = 0, kc_b = 0; const unsigned long long kc_rt0 = __builtin_amdgcn_s_memrealtime(); kc_ts[0] = __builtin_readcyclecounter()
+#define KCONV_TAP_A() kc_a = __builtin_readcyclecounter()
+#define KCONV_TAP(i) do { kc_b = __builtin_readcyclecounter(); kc_acc[i] += kc_b - kc_a; kc_a = kc_b; } while (0)
 #define KCONV_TS(i) kc_ts[i] = __builtin_readcyclecounter()
 #define KCONV_TS_END()                                                                                           \
   do {                                                                                                           \
     if (kc_timing && (threadIdx.x & 63) == 0) {                                                                  \
-      unsigned long long* tp_ = kc_timing + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;                  \
+      unsigned long long* tp_ = kc_timing + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12;                 \
       for (int i_ = 0; i_ < 6; ++i_) tp_[i_] = kc_ts[i_];                                                        \
       tp_[6] = kc_rt0;                                                                                           \
       tp_[7] = __builtin_amdgcn_s_memrealtime();                                                                 \
+      for (int i_ = 0; i_ < 3; ++i_) tp_[8 + i_] = kc_acc[i_];                                                   \
     }                                                                                                            \
   } while (0)
 #else
@@ -92,6 +96,8 @@ namespace vfx {
 #define KCONV_TS_BEGIN()
 #define KCONV_TS(i)
 #define KCONV_TS_END()
+#define KCONV_TAP_A()
+#define KCONV_TAP(i)
 #endif
 template <int BN, bool ELU, bool SPLIT, int ABL = 0, int RING = 3, bool HI = false, bool H64 = false, bool RA = false, bool VL = false>
 __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const TapConvParams* __restrict__ pp KCONV_TIMING_PARAM) {
@@ -464,6 +470,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
   auto step = [&](BGroup<WNB>& cur_r, BGroup<WNB>& fetch_r) __attribute__((always_inline)) {
     const int TP = NT > AHEAD ? NT - 1 - AHEAD : 0;
     const int cur = (st & 1) * CPATCH, nxt = CPATCH - cur;
+    KCONV_TAP_A();
     if (t == 0 && !(ABL & 4)) __syncthreads();
     fetch(fetch_r);
     // The last stage of a block requests nothing (round 6; it used to refetch its own patch and transform it again so that the
@@ -483,9 +490,11 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       if (t >= TP && more) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD + CNQ) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD) : "memory");
     }
+    KCONV_TAP(0);
     use_group(cur_r);
     compute(cur_r, cur, tap);
     __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of the next tap below the MFMAs of this one (register pressure)
+    KCONV_TAP(1);
     if (t == NT - 1) {
       if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL * AHEAD + CNQ) : "memory");  // patch latency never exposed
       else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
@@ -498,6 +507,7 @@ __global__ __launch_bounds__(256, (BN <= 64 || HI) ? 3 : 2) void k_conv(const Ta
       ++t;
     }
     tap = stages[st < last ? st : last].poff[t];  // next step's tap (all fragment reads of this step have been consumed)
+    KCONV_TAP(2);
   };
   if constexpr (RING <= 3) {
     fetch(R[0]);
