@@ -41,6 +41,26 @@ def test_conv3x3_prologue_residual(engine, B, H, W, Cin, Cout):
     assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), err
 
 
+def test_conv3x3_narrow_images_sweep(engine):
+    """Seeded sweep of images NARROWER than their tile (1-15 columns, 1-200 rows): plan_conv clips the patch window to the image's own
+    columns there (round 6: level 6 of the mel ResUNet, 32 x 3 pixels, in one tile), the tile's dead columns read neighbouring patch rows
+    into accumulator columns nobody stores -- every shape against fp64 torch, with split-K where the planner chooses it (384 channels)."""
+    rng = np.random.default_rng(606)
+    shapes = [(int(rng.integers(1, 4)), int(rng.integers(1, 201)), int(rng.integers(1, 16)), int(rng.choice([32, 64, 384])), int(rng.choice([32, 64, 96])))
+              for _ in range(16)] + [(16, 32, 3, 384, 384), (2, 34, 3, 64, 32), (1, 33, 5, 32, 32), (3, 30, 3, 96, 64)]
+    for i, (B, H, W, Cin, Cout) in enumerate(shapes):
+        x = _rand((B, Cin, H, W), 100 + i)
+        w = _rand((Cout, Cin, 3, 3), 200 + i, 0.05)
+        scale = torch.rand(Cin, generator=torch.Generator().manual_seed(300 + i)) + 0.5
+        shift = _rand((Cin,), 400 + i, 0.2)
+        a = F.leaky_relu(x.double() * scale.double()[None, :, None, None] + shift.double()[None, :, None, None], 0.01)
+        ref = F.conv2d(a, w.double(), padding=1)
+        y = engine.op_conv(_nhwc(x), w.numpy(), scale.numpy(), shift.numpy(), act=1, slope=0.01)
+        assert torch.isfinite(y).all(), (B, H, W, Cin, Cout)
+        err = (_nchw(y.cpu()).double() - ref).abs().max().item()
+        assert err < engine.tol['conv'] * max(1.0, ref.abs().max().item()), ((B, H, W, Cin, Cout), err)
+
+
 def test_conv1d_dilated_and_reflect(engine):
     B, T, C = 2, 300, 64
     x = _rand((B, C, T), 11)
