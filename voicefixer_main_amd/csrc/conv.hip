@@ -681,7 +681,15 @@ int conv_block_n(const TapConvParams& hp) {
   };
   int bn = fits(128) ? 128 : (fits(64) ? 64 : 32);
   // (round 6, r06c65: 768 instead of 384 here, or level 5 of a 10-s batch without split-K on either tile: all slower, profiles/r06_c64_*)
+  // ... but never past ONE round of the chip's block slots once the K slices are counted (round 6: a group of ~13 clips of a mixed-length
+  // call ran level 5 as 26 tiles x 12 cout blocks x 4 slices = 1 248 blocks of k_conv<32>, two rounds of blocks that live ~24 us
+  // whatever they compute; 624 blocks of k_conv<64> are one round).  Batches of 16 x 10 s choose as before.
+  const int64_t ks = hp.ksplit > 1 ? hp.ksplit : 1;
+#ifdef VFX_BN_RULE_OLD  // (measurement builds)
   while (bn > 32 && spatial * (hp.Cout / bn) < 384) bn >>= 1;
+#else
+  while (bn > 32 && spatial * (hp.Cout / bn) < 384 && spatial * (hp.Cout / (bn / 2)) * ks <= 768) bn >>= 1;
+#endif
   return bn;
 }
 
