@@ -79,6 +79,14 @@ def block2d_case(eng, buf, g, C, H, W, out, prec):
     print("== 2-D block, C = %d, %d x %d x %d (precision %d): %d tiles, block lifetime %.0f cycles (mean), kernel span %.0f cycles, "
           "blocks in flight = %.1f per CU; the call: %.3f ms" % (C, B, H, W, prec, n, life.mean(), span, n * life.mean() / span / 256.0,
                                                                   res["call_ms_incl_host_prep"]))
+    if C == 64 and float(ts[:, :, 13].max()) > 0:  # k_resblock<64, 4>, 2-D: conv1 of chunk 0 split further (stamps 13-15)
+        c0 = (ts[:, :, 13] - ts[:, :, 4]).mean()
+        w1_ = (ts[:, :, 14] - ts[:, :, 13]).mean()
+        t1_ = (ts[:, :, 15] - ts[:, :, 14]).mean()
+        c1 = (ts[:, :, 5] - ts[:, :, 15]).mean()
+        print("   conv1 split: taps of chunk 0 %.0f cycles (incl. the request of chunk 1), wait for chunk 1 %.0f, transform of chunk 1 %.0f, "
+              "barrier + taps of chunk 1 + final wait %.0f" % (c0, w1_, t1_, c1))
+        res["conv1_split"] = {"chunk0_taps": float(c0), "chunk1_wait": float(w1_), "chunk1_transform": float(t1_), "chunk1_taps": float(c1)}
     # per-CU concurrency from the stamps themselves (s_memtime is not synchronised across XCDs: use each block's own start / end and
     # the kernel's duration): sum of tile lifetimes / (256 CUs x the call's duration in cycles at the clock the stamps imply)
     if C == 32:  # block2d32.hip: [start, end] of every block on the chip-wide 100 MHz clock + HW_ID / XCC_ID

@@ -492,8 +492,11 @@ __global__ __launch_bounds__(NW * 64, MT == 256 ? 3 : (NW == 2 ? 3 : (NW == 4 ? 
       mma(ring(g), lds + (c % NBUF) * PBYTES, CROW, rows, -1, kov, G2);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (c == 0) VFX_TS(13);  // (timing builds: the taps of chunk 0 / the next chunk's patch landed / its transform)
     drain();
+    if (c == 0) VFX_TS(14);
     if (c + 1 < NCH) transform_patch(((c + 1) % NBUF) * PBYTES, c + 1);
+    if (c == 0) VFX_TS(15);
   }
 
   VFX_TS(5);  // conv1 done
